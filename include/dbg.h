@@ -1,0 +1,156 @@
+/*
+ * dbg.h -- C ABI of the MI355X (gfx950) de Bruijn graph hot path.
+ *
+ * The reference (Zhijian-Mei/py-debruijn) has no FFI or plugin interface; the
+ * boundary it offers is the Python module surface of debruijn.py as consumed by
+ * II_assembleFromReads.py:11-12,58,61,63.  This header is the C-ABI a binding
+ * for that surface sits on (ctypes stub: INTEGRATION.md; the shipped binding is
+ * py-debruijn_amd/_dbg.py).  Each entry point names the reference lines it
+ * replaces.  All pointers are plain host pointers unless the name says
+ * "device"; every buffer is owned by the caller; the library owns only the
+ * opaque handle and the device memory behind it.
+ *
+ * Conventions
+ *   - every function returns 0 (DBG_OK) or a negative DBG_E_* code; the text of
+ *     the last failure is dbg_last_error(h).  Nothing throws or aborts.
+ *   - a handle is bound to one GPU and is not thread-safe; calls are
+ *     stream-synchronous on return.
+ *   - k-mers travel as 2-bit packed keys: base code = (ascii >> 1) & 3
+ *     (A=0, C=1, T=2, G=3), first base in the most significant used bits,
+ *     key = sum(code[i] << 2*(k-1-i)), 1 <= k <= 31.
+ *   - "stamp" of a node = (byte offset of its first occurrence in the
+ *     concatenated read buffer << 1) | (1 if that occurrence is NOT at position
+ *     0 of its read).  Ascending stamp == the reference's dict insertion order
+ *     (debruijn.py:121-147); stamp & 1 == the reference's Node.indegree.
+ *   - only upper-case A/C/G/T reads are accepted (DBG_E_ALPHABET otherwise);
+ *     the reference's str-based code is alphabet-agnostic, the peptide alphabet
+ *     is a later row of SURVEY.md section 8f.
+ */
+#ifndef DBG_H
+#define DBG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dbg dbg_t;
+
+#define DBG_OK 0
+#define DBG_E_ARG (-1)      /* bad argument or call order */
+#define DBG_E_HIP (-2)      /* HIP runtime failure (text in dbg_last_error) */
+#define DBG_E_ALPHABET (-3) /* a read holds a byte outside "ACGT" */
+#define DBG_E_CAPACITY (-4) /* hash table or an output limit was exceeded */
+#define DBG_E_NOMEM (-5)    /* host or device allocation failed */
+
+#define DBG_ABI_VERSION 1
+
+/* node flag bits (dbg_export_nodes: flags[]) */
+#define DBG_F_INDEG 0x01u    /* Node.indegree (0 or 1), debruijn.py:134,141-142 */
+#define DBG_F_KEEP_MASK 0x1Eu /* bit (1 + code) set: successor `code` survived pruningEdges */
+#define DBG_F_KEEP_SHIFT 1
+#define DBG_F_BRANCH 0x20u   /* > 1 surviving successor, debruijn.py:230-235 */
+#define DBG_F_PULLED 0x40u   /* in already_pull_out, debruijn.py:249-254 */
+
+#define DBG_NO_NODE 0xFFFFFFFFu
+
+typedef struct dbg_sizes {
+    int32_t k;
+    int32_t abi_version;
+    uint64_t n_reads;
+    uint64_t n_bytes;          /* bases in the concatenated read buffer */
+    uint64_t n_kmer_instances; /* N_k: k-mer windows of reads with len > k */
+    uint64_t n_edge_instances; /* N_e: (k+1)-mer windows */
+    uint64_t table_capacity;   /* hash slots */
+    uint64_t n_nodes;          /* distinct k-mers == len(vertices) */
+    uint64_t n_edges;          /* distinct (k+1)-mers == len(edge_count_table) */
+    uint64_t n_branch;
+    uint64_t n_pulled;
+    uint64_t n_pull_reads;
+    uint64_t n_starts;         /* nodes with indegree 0 */
+    uint64_t n_contigs;
+    uint64_t contig_chars;     /* total characters over all contigs */
+    uint64_t tip_rounds;       /* reservation rounds the tip removal needed */
+} dbg_sizes_t;
+
+typedef struct dbg_stats {
+    /* device time of each phase of the last call, milliseconds (HIP events on the handle's stream) */
+    double ms_startbits;  /* read-start bitmap */
+    double ms_table_init; /* hash table clear */
+    double ms_count;      /* encode + hash insert + edge counters (dominant kernel) */
+    double ms_compact;    /* occupied slots -> node arrays */
+    double ms_succ;       /* successor lookup -> 4-way adjacency */
+    double ms_csr;        /* degree scan + CSR fill */
+    double ms_build_total;
+    double ms_prune;
+    double ms_tips;
+    double ms_pull_reads;
+    double ms_walk;
+    double ms_h2d;        /* dbg_set_reads copy */
+    uint64_t count_launches; /* launches of the dominant kernel in the last dbg_build */
+} dbg_stats_t;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int dbg_create(int device, dbg_t **out);
+void dbg_destroy(dbg_t *h);
+const char *dbg_last_error(const dbg_t *h);
+int dbg_abi_version(void);
+
+/* ---- reads (replaces the `reads` list argument, debruijn.py:206; FASTA
+ *      ingest debruijn.py:22-32 stays on the host side of the boundary) ---- */
+/* bases: all reads concatenated without separators; offsets[n_reads+1], offsets[0]==0. Copies H2D. */
+int dbg_set_reads(dbg_t *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+/* Zero-copy: device pointers the caller keeps alive (16-byte aligned bases, u64 offsets[n_reads+1]). */
+int dbg_set_reads_device(dbg_t *h, const void *d_bases, uint64_t n_bytes, const void *d_offsets, uint64_t n_reads);
+/* Generate reads [first_read, first_read+n_reads) of the synthetic set on the device
+ * (bit-identical to py-debruijn_amd/synth.py).  err_thr24 = round(err_rate * 2^24). */
+int dbg_synth_reads(dbg_t *h, uint64_t seed, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                    uint32_t read_len, uint32_t err_thr24);
+int dbg_reads_checksum(dbg_t *h, uint64_t *out);              /* synth.checksum twin */
+int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets); /* D2H of the current read set */
+
+/* ---- a3 + a4: get_graph_from_reads (debruijn.py:98-147) + edge-count table (:213-222)
+ *      -> node table, 4-way successor edges, CSR ------------------------------------ */
+/* table_capacity_hint: 0 = size for the worst case (every k-mer instance distinct);
+ * otherwise a slot count (rounded up to a power of two); DBG_E_CAPACITY if too small. */
+int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint);
+
+/* ---- a5 + a6: pruningEdges (debruijn.py:150-166) + branch detection (:230-236) */
+int dbg_prune(dbg_t *h, double threshold);
+/* ---- a7: tip removal (debruijn.py:169-186 driven by :241-254) */
+int dbg_remove_tips(dbg_t *h);
+/* ---- a9: reads that contain a branch k-mer (debruijn.py:274-278) */
+int dbg_mark_pull_reads(dbg_t *h);
+/* ---- a11 + a12: output_contigs / DFS (debruijn.py:288-347); scores are getScore
+ *      (II_assembleFromReads.py:14-18).  final_mode != 0 walks with branch_kmer == []
+ *      (debruijn.py:281-283).  max_chars bounds the materialised contig text (0 = 1 GiB). */
+int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars);
+
+int dbg_get_sizes(dbg_t *h, dbg_sizes_t *out);
+int dbg_get_stats(dbg_t *h, dbg_stats_t *out);
+
+/* ---- exports: two-call pattern, sizes from dbg_get_sizes; NULL pointers are skipped */
+/* keys[n_nodes], stamps[n_nodes], counts[n_nodes*4] (by base code), flags[n_nodes]; table order */
+int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint32_t *counts, uint8_t *flags);
+/* succ[n_nodes*4]: node id of successor by base code or DBG_NO_NODE */
+int dbg_export_succ(dbg_t *h, uint32_t *succ);
+/* CSR over distinct edges: row_ptr[n_nodes+1], col[n_edges], cnt[n_edges] */
+int dbg_export_csr(dbg_t *h, uint64_t *row_ptr, uint32_t *col, uint32_t *cnt);
+/* ranks[n_nodes]: pull order key of pulled nodes (ascending == append order of
+ * already_pull_out, debruijn.py:253), UINT64_MAX for the rest */
+int dbg_export_pull_ranks(dbg_t *h, uint64_t *ranks);
+int dbg_export_pull_reads(dbg_t *h, uint8_t *read_flags /* [n_reads] */);
+/* contigs in emission order grouped by start: offsets[n_contigs+1] into chars[contig_chars],
+ * scores[n_contigs], start_stamp[n_contigs] (stamp of the start node: sort key for dict order),
+ * seq_in_start[n_contigs] (emission index within its start) */
+int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint64_t *scores, uint64_t *start_stamp,
+                       uint32_t *seq_in_start);
+/* device-side views for callers that stay on the GPU (valid until the next build/destroy) */
+int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const void **d_stamps,
+                     const void **d_flags, const void **d_succ);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DBG_H */

@@ -1,0 +1,270 @@
+"""ctypes binding of include/dbg.h (the C ABI of the gfx950 de Bruijn hot path).
+
+There is no CPU fallback: if ``libdbg_hip.so`` is missing or no GPU is visible the
+calls fail loudly.  Build the library with ``py-debruijn_amd/csrc/build.sh`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdbg_hip.so")
+
+DBG_OK, DBG_E_ARG, DBG_E_HIP, DBG_E_ALPHABET, DBG_E_CAPACITY, DBG_E_NOMEM = 0, -1, -2, -3, -4, -5
+F_INDEG, F_KEEP_MASK, F_KEEP_SHIFT, F_BRANCH, F_PULLED = 0x01, 0x1E, 1, 0x20, 0x40
+NO_NODE = 0xFFFFFFFF
+ABI_VERSION = 1
+
+# symbols declared in include/dbg.h; tests check that the library exports every one of them
+SYMBOLS = (
+    "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_reads", "dbg_set_reads_device",
+    "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_prune", "dbg_remove_tips",
+    "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
+    "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs", "dbg_device_views",
+)
+
+
+class Sizes(C.Structure):
+    _fields_ = [("k", C.c_int32), ("abi_version", C.c_int32)] + [
+        (n, C.c_uint64) for n in (
+            "n_reads", "n_bytes", "n_kmer_instances", "n_edge_instances", "table_capacity", "n_nodes", "n_edges",
+            "n_branch", "n_pulled", "n_pull_reads", "n_starts", "n_contigs", "contig_chars", "tip_rounds")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "ms_startbits", "ms_table_init", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total", "ms_prune",
+        "ms_tips", "ms_pull_reads", "ms_walk", "ms_h2d")] + [("count_launches", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class DbgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dbg error {code}: {msg}")
+        self.code = code
+
+
+class AlphabetError(DbgError, ValueError):
+    pass
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libdbg_hip.so (once).  Raises OSError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not found: build it with py-debruijn_amd/csrc/build.sh "
+                      f"(there is no CPU fallback for the device path)")
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    sig = {
+        "dbg_create": (C.c_int, [C.c_int, C.POINTER(H)]),
+        "dbg_destroy": (None, [H]),
+        "dbg_last_error": (C.c_char_p, [H]),
+        "dbg_abi_version": (C.c_int, []),
+        "dbg_set_reads": (C.c_int, [H, vp, vp, C.c_uint64]),
+        "dbg_set_reads_device": (C.c_int, [H, vp, C.c_uint64, vp, C.c_uint64]),
+        "dbg_synth_reads": (C.c_int, [H, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
+        "dbg_reads_checksum": (C.c_int, [H, u64p]),
+        "dbg_copy_reads": (C.c_int, [H, vp, vp]),
+        "dbg_build": (C.c_int, [H, C.c_int, C.c_uint64]),
+        "dbg_prune": (C.c_int, [H, C.c_double]),
+        "dbg_remove_tips": (C.c_int, [H]),
+        "dbg_mark_pull_reads": (C.c_int, [H]),
+        "dbg_walk": (C.c_int, [H, C.c_int, C.c_uint64]),
+        "dbg_get_sizes": (C.c_int, [H, C.POINTER(Sizes)]),
+        "dbg_get_stats": (C.c_int, [H, C.POINTER(Stats)]),
+        "dbg_export_nodes": (C.c_int, [H, vp, vp, vp, vp]),
+        "dbg_export_succ": (C.c_int, [H, vp]),
+        "dbg_export_csr": (C.c_int, [H, vp, vp, vp]),
+        "dbg_export_pull_ranks": (C.c_int, [H, vp]),
+        "dbg_export_pull_reads": (C.c_int, [H, vp]),
+        "dbg_export_contigs": (C.c_int, [H, vp, vp, vp, vp, vp]),
+        "dbg_device_views": (C.c_int, [H] + [C.POINTER(vp)] * 5),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dbg_abi_version() != ABI_VERSION:
+        raise OSError(f"{LIB_PATH}: ABI version {lib.dbg_abi_version()} != binding {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def default_device():
+    for var in ("DBG_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+class Graph:
+    """One handle of the C ABI: a read set plus the graph built from it, resident on one GPU."""
+
+    def __init__(self, device=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        rc = self._lib.dbg_create(default_device() if device is None else int(device), C.byref(self._h))
+        if rc != DBG_OK:
+            self._h = None
+            raise DbgError(rc, "dbg_create failed: no usable MI355X visible (the device path has no CPU fallback)")
+        self._keep = []  # buffers the device borrows
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.dbg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != DBG_OK:
+            msg = self._lib.dbg_last_error(self._h).decode("utf-8", "replace")
+            raise (AlphabetError if rc == DBG_E_ALPHABET else DbgError)(rc, msg)
+
+    # ---- reads
+    def set_reads(self, bases, offsets):
+        """bases: bytes-like of concatenated reads; offsets: uint64[n_reads+1]."""
+        b = np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else bases
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        assert o.ndim == 1 and o.size >= 1 and int(o[-1]) == b.size
+        self._chk(self._lib.dbg_set_reads(self._h, _ptr(b), _ptr(o), o.size - 1))
+
+    def set_reads_device(self, bases_ptr, n_bytes, offsets_ptr, n_reads, keepalive=()):
+        self._keep = list(keepalive)
+        self._chk(self._lib.dbg_set_reads_device(self._h, C.c_void_p(bases_ptr), n_bytes, C.c_void_p(offsets_ptr),
+                                                 n_reads))
+
+    def synth_reads(self, seed, genome_len, n_reads, read_len, err_rate=0.0, first_read=0):
+        thr = int(round(float(err_rate) * (1 << 24)))
+        self._chk(self._lib.dbg_synth_reads(self._h, seed, genome_len, first_read, n_reads, read_len, thr))
+
+    def reads_checksum(self):
+        out = C.c_uint64()
+        self._chk(self._lib.dbg_reads_checksum(self._h, C.byref(out)))
+        return out.value
+
+    def copy_reads(self):
+        s = self.sizes()
+        b = np.empty(s["n_bytes"], dtype=np.uint8)
+        o = np.empty(s["n_reads"] + 1, dtype=np.uint64)
+        self._chk(self._lib.dbg_copy_reads(self._h, _ptr(b), _ptr(o)))
+        return b, o
+
+    # ---- pipeline
+    def build(self, k, table_capacity_hint=0):
+        self._chk(self._lib.dbg_build(self._h, int(k), int(table_capacity_hint)))
+
+    def prune(self, threshold):
+        self._chk(self._lib.dbg_prune(self._h, float(threshold)))
+
+    def remove_tips(self):
+        self._chk(self._lib.dbg_remove_tips(self._h))
+
+    def mark_pull_reads(self):
+        self._chk(self._lib.dbg_mark_pull_reads(self._h))
+
+    def walk(self, final_mode, max_chars=0):
+        self._chk(self._lib.dbg_walk(self._h, 1 if final_mode else 0, int(max_chars)))
+
+    def sizes(self):
+        s = Sizes()
+        self._chk(self._lib.dbg_get_sizes(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def stats(self):
+        s = Stats()
+        self._chk(self._lib.dbg_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # ---- exports
+    def export_nodes(self, keys=True, stamps=True, counts=True, flags=True):
+        n = self.sizes()["n_nodes"]
+        a = np.empty(n, dtype=np.uint64) if keys else None
+        b = np.empty(n, dtype=np.uint64) if stamps else None
+        c = np.empty((n, 4), dtype=np.uint32) if counts else None
+        d = np.empty(n, dtype=np.uint8) if flags else None
+        self._chk(self._lib.dbg_export_nodes(self._h, _ptr(a), _ptr(b), _ptr(c), _ptr(d)))
+        return a, b, c, d
+
+    def export_succ(self):
+        n = self.sizes()["n_nodes"]
+        s = np.empty((n, 4), dtype=np.uint32)
+        self._chk(self._lib.dbg_export_succ(self._h, _ptr(s)))
+        return s
+
+    def export_csr(self):
+        sz = self.sizes()
+        rp = np.empty(sz["n_nodes"] + 1, dtype=np.uint64)
+        col = np.empty(sz["n_edges"], dtype=np.uint32)
+        cnt = np.empty(sz["n_edges"], dtype=np.uint32)
+        self._chk(self._lib.dbg_export_csr(self._h, _ptr(rp), _ptr(col), _ptr(cnt)))
+        return rp, col, cnt
+
+    def export_pull_ranks(self):
+        r = np.empty(self.sizes()["n_nodes"], dtype=np.uint64)
+        self._chk(self._lib.dbg_export_pull_ranks(self._h, _ptr(r)))
+        return r
+
+    def export_pull_reads(self):
+        f = np.empty(self.sizes()["n_reads"], dtype=np.uint8)
+        self._chk(self._lib.dbg_export_pull_reads(self._h, _ptr(f)))
+        return f
+
+    def export_contigs(self):
+        sz = self.sizes()
+        n, nc = sz["n_contigs"], sz["contig_chars"]
+        off = np.empty(n + 1, dtype=np.uint64)
+        chars = np.empty(nc, dtype=np.uint8)
+        score = np.empty(n, dtype=np.uint64)
+        stamp = np.empty(n, dtype=np.uint64)
+        seq = np.empty(n, dtype=np.uint32)
+        self._chk(self._lib.dbg_export_contigs(self._h, _ptr(off), _ptr(chars), _ptr(score), _ptr(stamp), _ptr(seq)))
+        return off, chars, score, stamp, seq
+
+
+# ---- 2-bit key <-> str helpers (host side of the boundary) -------------------------------
+_CODE_ASCII = np.frombuffer(b"ACTG", dtype=np.uint8)  # code = (ascii >> 1) & 3
+
+
+def decode_keys(keys, k):
+    """uint64 keys -> list of k-character str."""
+    keys = np.asarray(keys, dtype=np.uint64)
+    if keys.size == 0:
+        return []
+    shifts = (2 * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
+    codes = ((keys[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.intp)
+    buf = _CODE_ASCII[codes].tobytes().decode("ascii")
+    return [buf[i * k:(i + 1) * k] for i in range(keys.size)]
+
+
+def encode_kmer(s):
+    key = 0
+    for ch in s.encode("ascii"):
+        key = (key << 2) | ((ch >> 1) & 3)
+    return key

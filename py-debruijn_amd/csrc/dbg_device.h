@@ -1,0 +1,87 @@
+// Device-side helpers shared by the gfx950 kernels of the de Bruijn hot path.
+// Wavefront width is 64 everywhere in this file.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dbgk {
+
+constexpr uint64_t EMPTY_KEY = ~0ull;
+constexpr uint32_t NO_NODE = 0xFFFFFFFFu;
+
+// One hash slot: 32 bytes, so the key probe, the stamp min and the successor
+// counter add of one record touch a single 128-byte line.
+struct __attribute__((aligned(32))) Slot {
+    unsigned long long key;    // 2-bit packed k-mer, EMPTY_KEY when free
+    unsigned long long stamp;  // min over occurrences of (byte offset << 1 | pos != 0); node id after compaction
+    unsigned int cnt[4];       // occurrences of (k-mer, successor base code)
+};
+static_assert(sizeof(Slot) == 32, "slot layout");
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+// Hash of a packed k-mer; slot = hash >> (64 - log2(capacity)).
+__host__ __device__ inline uint64_t kmer_hash(uint64_t key) {
+    return mix64(key * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull);
+}
+
+// 4 ASCII bases in one dword (lowest address = lowest byte) -> 8 bits, first base in bits 7:6.
+__device__ inline uint32_t pack4(uint32_t d) {
+    return (((d >> 1) & 0x03030303u) * 0x40100401u) >> 24;
+}
+
+// per-byte exact zero detector (no cross-byte carries): 0x80 in every zero byte of v
+__device__ inline uint32_t zero_bytes(uint32_t v) {
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u;
+}
+
+// 0x80 in every byte of d that is one of 'A','C','G','T'
+__device__ inline uint32_t acgt_bytes(uint32_t d) {
+    return zero_bytes(d ^ 0x41414141u) | zero_bytes(d ^ 0x43434343u) |
+           zero_bytes(d ^ 0x47474747u) | zero_bytes(d ^ 0x54545454u);
+}
+
+__device__ inline char code_to_ascii(uint32_t code) {  // inverse of (ascii >> 1) & 3
+    return (char)((0x47544341u >> (8 * code)) & 0xFF);  // 0:A 1:C 2:T 3:G
+}
+
+// rank of a base code in ASCII order (A < C < G < T) -- tie order of equal edge counts
+__device__ inline uint32_t code_ascii_rank(uint32_t code) { return (0x2310u >> (4 * code)) & 3u; }  // 0->0,1->1,2->3,3->2
+
+// Exclusive scan of one value per thread over a 256-thread block (4 waves of 64).
+// Returns the exclusive prefix; *block_total receives the block sum (all threads).
+__device__ inline uint64_t block_exscan_256(uint64_t v, uint64_t *block_total) {
+    __shared__ uint64_t wave_sum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint64_t s = wave_sum[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return base + inc - v;
+}
+
+__device__ inline uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;  // valid in lane 0
+}
+
+}  // namespace dbgk

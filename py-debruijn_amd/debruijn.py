@@ -1,0 +1,188 @@
+"""Drop-in for the reference's ``debruijn.py`` backed by the gfx950 HIP library.
+
+Same module surface as the reference (``read_reads``, ``construct_graph``,
+``output_contigs``, ``Node``; used by II_assembleFromReads.py:11-12,58,61,63), same
+argument meaning, return shapes and stdout lines; the work happens on the MI355X
+through the C ABI of ``include/dbg.h`` (binding: ``_dbg.py``).  There is no CPU
+path: without the built library and a GPU every call raises.
+
+Differences a caller can observe, all documented in DESIGN.md:
+  * reads must be upper-case A/C/G/T and 1 <= k <= 31 (ValueError otherwise);
+  * where the reference orders equal-count successors by first appearance
+    (``Counter.most_common`` ties), this module orders them A < C < G < T.  Sets,
+    counts, degrees, branch/pulled/pull-out sets and non-final contig lists are
+    identical; only the order inside such tie groups can differ.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+import _dbg
+
+__all__ = ["Node", "read_reads", "construct_graph", "output_contigs", "get_score_device"]
+
+_ASCII_RANK_CODES = (0, 1, 3, 2)  # base codes in ASCII order A, C, G, T
+_CODE_CHAR = "ACTG"               # code = (ascii >> 1) & 3
+
+
+class Node:
+    """debruijn.py:8-14."""
+
+    __slots__ = ("label", "indegree", "outdegree")
+
+    def __init__(self, lab, indegree=0, outdegree=0):
+        self.label = lab
+        self.indegree = indegree
+        self.outdegree = outdegree
+
+
+def read_reads(fname):
+    """debruijn.py:22-32: every line that does not start with '>' is one read (rstrip'ed).
+
+    Linear time (the reference's ``reads = reads + [...]`` is quadratic); same result.
+    """
+    with open(fname, "r") as fh:
+        return [line.rstrip() for line in fh.readlines() if line[0] != ">"]
+
+
+class _Vertices(dict):
+    """``vertices`` dict that also carries the device handle for output_contigs."""
+    _graph = None
+    _state = None
+
+
+class _Tracked(list):
+    """list that remembers which construct_graph call produced it."""
+    _token = None
+
+
+class ContigList(list):
+    """list[str] of contigs plus the device-computed getScore of each (``.scores``)."""
+    scores = None
+
+
+def _pack_reads(reads):
+    try:
+        blob = "".join(reads).encode("ascii")
+    except UnicodeEncodeError as e:
+        raise ValueError("reads must be upper-case A/C/G/T for the device path") from e
+    arr = np.frombuffer(blob, dtype=np.uint8)
+    if arr.size:
+        ok = (arr == 65) | (arr == 67) | (arr == 71) | (arr == 84)
+        if not bool(ok.all()):
+            bad = chr(int(arr[np.argmin(ok)]))
+            raise ValueError(f"reads must be upper-case A/C/G/T for the device path (found {bad!r}); "
+                             f"other alphabets are not on the MI355X path yet")
+    lens = np.fromiter((len(r) for r in reads), dtype=np.uint64, count=len(reads))
+    offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    return arr, offsets
+
+
+def construct_graph(reads, k, threshold=3, final=False):
+    """debruijn.py:206-285 on the GPU.
+
+    Returns ((vertices, edges), pull_out_read, branch_kmer, already_pull_out, edge_count_table).
+    """
+    if not isinstance(k, (int, np.integer)) or not (1 <= int(k) <= 31):
+        raise ValueError("the device path supports 1 <= k <= 31")
+    k = int(k)
+    bases, offsets = _pack_reads(reads)
+    g = _dbg.Graph()
+    g.set_reads(bases, offsets)
+    g.build(k)
+    sz = g.sizes()
+    print('number of {}mer: '.format(k), sz["n_nodes"])  # debruijn.py:224
+
+    if threshold == 0:
+        # debruijn.py:163 divides by threshold as soon as a vertex has two distinct successors
+        _, _, counts, _ = g.export_nodes(keys=False, stamps=False, flags=False)
+        if ((counts != 0).sum(axis=1) > 1).any():
+            raise ZeroDivisionError("division by zero")
+        threshold = 1
+    g.prune(threshold)
+    n_branch = g.sizes()["n_branch"]
+    print('branch number: ', n_branch)  # debruijn.py:236
+    g.remove_tips()
+    if not final:
+        g.mark_pull_reads()
+
+    keys, stamps, counts, flags = g.export_nodes()
+    order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
+    labels = _dbg.decode_keys(keys[order], k)
+    counts_o = counts[order]
+    flags_o = flags[order]
+    outdeg = (counts_o != 0).sum(axis=1)
+    indeg = flags_o & _dbg.F_INDEG
+    pulled_o = (flags_o & _dbg.F_PULLED) != 0
+    keep_o = (flags_o & _dbg.F_KEEP_MASK) >> _dbg.F_KEEP_SHIFT
+
+    vertices = _Vertices()
+    edges = {}
+    ect = {}
+    for i, lab in enumerate(labels):
+        vertices[lab] = Node(lab, int(indeg[i]), int(outdeg[i]))
+        c = counts_o[i]
+        tail = lab[1:]
+        # successors ranked by (count desc, ASCII asc) -- Counter.most_common order up to ties
+        ranked = sorted((code for code in _ASCII_RANK_CODES if c[code]), key=lambda code: -int(c[code]))
+        for code in _ASCII_RANK_CODES:
+            if c[code]:
+                ect[lab + _CODE_CHAR[code]] = int(c[code])
+        if not pulled_o[i]:
+            kp = int(keep_o[i])
+            edges[lab] = [tail + _CODE_CHAR[code] for code in ranked if (kp >> code) & 1]
+
+    ranks = g.export_pull_ranks()[order]
+    pulled_idx = np.nonzero(pulled_o)[0]
+    pulled_idx = pulled_idx[np.argsort(ranks[pulled_idx], kind="stable")]
+    already_pull_out = _Tracked(labels[i] for i in pulled_idx)
+
+    if final:  # debruijn.py:281-283
+        pull_out_read = []
+        branch_kmer = _Tracked()
+    else:
+        rf = g.export_pull_reads()
+        pull_out_read = [reads[i] for i in np.nonzero(rf)[0]]
+        branch_kmer = _Tracked(labels[i] for i in np.nonzero(flags_o & _dbg.F_BRANCH)[0])
+
+    token = object()
+    vertices._graph = g
+    vertices._state = {"token": token, "final": bool(final), "k": k, "n_branch": int(n_branch)}
+    branch_kmer._token = token
+    already_pull_out._token = token
+    return (vertices, edges), pull_out_read, branch_kmer, already_pull_out, ect
+
+
+def output_contigs(g, branch_kmer, already_pull_out):
+    """debruijn.py:326-347 (DFS of :288-316) on the GPU.
+
+    ``g``, ``branch_kmer`` and ``already_pull_out`` must come from one construct_graph call
+    of this module (the graph lives on the device); ``branch_kmer == []`` selects the
+    reference's final-mode walk.
+    """
+    V = g[0]
+    graph = getattr(V, "_graph", None)
+    state = getattr(V, "_state", None)
+    if graph is None or state is None:
+        raise TypeError("output_contigs needs the (vertices, edges) returned by this module's construct_graph")
+    tok = state["token"]
+    if getattr(already_pull_out, "_token", None) is not tok or (
+            getattr(branch_kmer, "_token", None) is not tok and len(branch_kmer) != 0):
+        raise ValueError("branch_kmer / already_pull_out must be the lists returned with this graph "
+                         "(the device walk uses the graph state they describe)")
+    final_mode = len(branch_kmer) == 0  # identical to the chain walk when the graph has no branch node
+    sz = graph.sizes()
+    print('Number of kmers have no income edges: ', sz["n_starts"])  # debruijn.py:336
+    graph.walk(final_mode)
+    off, chars, score, stamp, seq = graph.export_contigs()
+    order = np.lexsort((seq, stamp))  # starts in dict order, emission order inside a start
+    text = chars.tobytes().decode("ascii")
+    out = ContigList(text[int(off[i]):int(off[i + 1])] for i in order)
+    out.scores = [int(score[i]) for i in order]
+    return out
+
+
+def get_score_device(contigs):
+    """getScore (II_assembleFromReads.py:14-18) of each contig as computed by the walk kernel."""
+    return list(contigs.scores)

@@ -1,0 +1,163 @@
+"""HIP path vs the oracle and the reference's golden vectors (run with -m gpu on an MI355X).
+
+Every call goes through the C ABI (ctypes -> libdbg_hip.so).  Integer/byte/index work: bit-exact.
+Ordering rule: the product orders equal-count successors A<C<G<T where the
+reference uses first-seen order, so successor lists, edge_count_table key order,
+already_pull_out order and final-mode contig order are compared order-independently;
+everything else is compared exactly, including dict order.
+"""
+import contextlib
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, case_reads, golden_case_names, load_golden
+from golden_util import canonical
+from oracle import dbg_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+DNA = set("ACGT")
+
+
+def is_dna(reads):
+    return all(set(r) <= DNA for r in reads)
+
+
+def run_product(reads, k, threshold, final):
+    import debruijn as prod
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        g, pull, branch, pulled, ect = prod.construct_graph(list(reads), k, threshold=threshold, final=final)
+        contigs = prod.output_contigs(g, branch, pulled)
+    res = canonical(g, pull, branch, pulled, ect, contigs)
+    res["stdout"] = buf.getvalue()
+    res["scores"] = list(contigs.scores)
+    res["ect"] = ect
+    return res
+
+
+def run_oracle(reads, k, threshold, final):
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        g, pull, branch, pulled, ect = orc.construct_graph(list(reads), k, threshold=threshold, final=final)
+        contigs = orc.output_contigs(g, branch, pulled)
+    res = canonical(g, pull, branch, pulled, ect, contigs)
+    res["stdout"] = buf.getvalue()
+    res["scores"] = [orc.get_score(ect, c, k) for c in contigs]
+    return res
+
+
+def assert_same(got, want, final, tag):
+    assert got["vertices"] == want["vertices"], f"{tag}: vertices (label, indegree, outdegree, dict order)"
+    assert [v for v, _ in got["edges"]] == [v for v, _ in want["edges"]], f"{tag}: edges keys / order"
+    for (v, a), (_, b) in zip(got["edges"], want["edges"]):
+        assert sorted(a) == sorted(b), f"{tag}: successors of {v}"
+    assert dict(map(tuple, got["edge_count_table"])) == dict(map(tuple, want["edge_count_table"])), f"{tag}: edge counts"
+    assert got["branch_kmer"] == want["branch_kmer"], f"{tag}: branch_kmer"
+    assert sorted(got["already_pull_out"]) == sorted(want["already_pull_out"]), f"{tag}: already_pull_out"
+    assert len(set(got["already_pull_out"])) == len(got["already_pull_out"])
+    assert got["pull_out_read"] == want["pull_out_read"], f"{tag}: pull_out_read"
+    if final:
+        assert sorted(got["contigs"]) == sorted(want["contigs"]), f"{tag}: contigs (final mode, as multiset)"
+        assert sorted(zip(got["contigs"], got["scores"])) == sorted(zip(want["contigs"], want["scores"]))
+    else:
+        assert got["contigs"] == want["contigs"], f"{tag}: contigs"
+        assert got["scores"] == want["scores"], f"{tag}: getScore"
+    assert got["stdout"] == want["stdout"], f"{tag}: stdout lines"
+
+
+@pytest.mark.parametrize("name", golden_case_names())
+def test_golden_case(name):
+    case = load_golden(name)
+    reads = case_reads(case)
+    if not is_dna(reads):
+        pytest.skip("peptide alphabet: not on the device path yet (SURVEY.md 8f-3)")
+    inp = case["inputs"]
+    got = run_product(reads, inp["k"], inp["threshold"], inp["final"])
+    want = run_oracle(reads, inp["k"], inp["threshold"], inp["final"])
+    assert_same(got, want, inp["final"], name)
+    s = case["summary"]  # numbers produced by the reference itself
+    assert len(got["vertices"]) == s["n_vertices"]
+    assert len(got["edge_count_table"]) == s["n_edge_names"]
+    assert sum(c for _, c in got["edge_count_table"]) == s["sum_edge_counts"]
+    assert len(got["already_pull_out"]) == s["n_pulled"]
+    assert len(got["pull_out_read"]) == s["n_pull_reads"]
+    assert len(got["contigs"]) == s["n_contigs"]
+    if "result" in case:  # full reference output available
+        ref = dict(case["result"])
+        ref["scores"] = want["scores"]
+        assert_same(got, ref, inp["final"], name + " (reference)")
+
+
+def test_fuzz_family_against_reference_vectors():
+    with open(os.path.join(GOLDEN, "fuzz_small.json")) as fh:
+        cases = json.load(fh)
+    n = 0
+    for i, case in enumerate(cases):
+        inp = case["inputs"]
+        if not is_dna(inp["reads"]):
+            continue
+        got = run_product(inp["reads"], inp["k"], inp["threshold"], inp["final"])
+        ref = dict(case["result"])
+        ect = dict(map(tuple, ref["edge_count_table"]))
+        ref["scores"] = [orc.get_score(ect, c, inp["k"]) for c in ref["contigs"]]
+        assert_same(got, ref, inp["final"], f"fuzz {i} {inp}")
+        n += 1
+    assert n >= 400
+
+
+def test_alphabet_rejected():
+    import debruijn as prod
+    with pytest.raises(ValueError):
+        prod.construct_graph(["ACGTN", "ACGTA"], 3)
+    with pytest.raises(ValueError):
+        prod.construct_graph(["acgtacgt"], 3)
+
+
+def test_device_rejects_bad_alphabet_through_abi():
+    import _dbg
+    g = _dbg.Graph()
+    b = np.frombuffer(b"ACGTNACGT", dtype=np.uint8)
+    g.set_reads(b, np.array([0, 9], dtype=np.uint64))
+    with pytest.raises(_dbg.AlphabetError):
+        g.build(3)
+
+
+def test_empty_and_degenerate_inputs():
+    import debruijn as prod
+    for reads in ([], [""], ["A"], ["ACG"], ["", "", "AC"]):
+        with contextlib.redirect_stdout(io.StringIO()):
+            g, pull, branch, pulled, ect = prod.construct_graph(reads, 3)
+            contigs = prod.output_contigs(g, branch, pulled)
+        assert len(g[0]) == 0 and len(g[1]) == 0 and not pull and not branch and not pulled and not ect
+        assert contigs == []
+
+
+def test_csr_matches_node_table():
+    import _dbg
+    import synth
+    reads = synth.reads_ascii(5, 20000, 3000, 100, 0.01)
+    g = _dbg.Graph()
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64))
+    g.build(21)
+    keys, stamps, counts, flags = g.export_nodes()
+    succ = g.export_succ()
+    rp, col, cnt = g.export_csr()
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == 3000 * 80 and sz["n_edge_instances"] == 3000 * 79
+    assert int(counts.sum()) == sz["n_edge_instances"]
+    deg = (counts != 0).sum(axis=1)
+    assert np.array_equal(np.diff(rp.astype(np.int64)), deg)
+    assert int(rp[-1]) == sz["n_edges"] == int(deg.sum())
+    assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+    # successor ids point at the shifted k-mer
+    mask = np.uint64((1 << 42) - 1)
+    for code in range(4):
+        has = counts[:, code] != 0
+        want = ((keys[has] << np.uint64(2)) | np.uint64(code)) & mask
+        assert np.array_equal(keys[succ[has, code]], want)
+    assert len(np.unique(keys)) == keys.size and len(np.unique(stamps)) == stamps.size
