@@ -96,6 +96,10 @@ int dbg_create(int device, dbg_t **out);
 void dbg_destroy(dbg_t *h);
 const char *dbg_last_error(const dbg_t *h);
 int dbg_abi_version(void);
+/* Tunables (no reference counterpart): "engine" 0 = partitioned super-k-mer build (default),
+ * 1 = single global hash table; "bucket_bits" 0 = auto, else log2 of the bucket count (<= 18);
+ * "lds_slots" 2048 or 4096 slots of the per-bucket LDS table. */
+int dbg_set_option(dbg_t *h, const char *name, int64_t value);
 
 /* ---- reads (replaces the `reads` list argument, debruijn.py:206; FASTA
  *      ingest debruijn.py:22-32 stays on the host side of the boundary) ---- */

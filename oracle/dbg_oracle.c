@@ -1,0 +1,135 @@
+/*
+ * CPU oracle, C restatement of the graph-construction half of the hot path.
+ * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg; the product never links or loads it.
+ *
+ * Restates, for the DNA alphabet, what debruijn.py:98-147 (get_graph_from_reads) and
+ * debruijn.py:213-222 (edge_count_table) compute:
+ *   - for every read with len > k (debruijn.py:126), every window pos in [0, len-k]
+ *     is a vertex occurrence; every pos < len-k is an occurrence of the edge
+ *     (k-mer, next base);
+ *   - per distinct k-mer: the 4 successor counts (the edge_count_table entries
+ *     k-mer + base) and the first occurrence, kept as
+ *     stamp = (byte offset << 1) | (pos != 0)   [indegree, debruijn.py:134,141-142].
+ * Output order is first-occurrence order == the reference's dict order.
+ *
+ * Parity status: pinned -- tests/test_oracle_c.py checks it against
+ * oracle/dbg_oracle.py, which is itself pinned by the reference's vectors.
+ *
+ * Base code = (ascii >> 1) & 3 (A=0 C=1 T=2 G=3), same packing as include/dbg.h.
+ * Single-threaded, plain C, open-addressing table.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    uint64_t key;
+    uint64_t stamp;
+    uint32_t cnt[4];
+} orc_slot;
+
+typedef struct {
+    orc_slot *tab;
+    uint64_t cap, n_nodes, n_kmer_inst, n_edge_inst;
+    int k;
+} orc_t;
+
+static uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+void orc_free(orc_t *o) {
+    if (!o) return;
+    free(o->tab);
+    free(o);
+}
+
+/* returns NULL on bad input (k outside 1..31, byte outside ACGT, allocation failure) */
+orc_t *orc_build(const char *bases, const uint64_t *offsets, uint64_t n_reads, int k) {
+    if (k < 1 || k > 31) return NULL;
+    uint64_t windows = 0;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        uint64_t len = offsets[r + 1] - offsets[r];
+        if (len > (uint64_t)k) windows += len - k + 1;
+    }
+    orc_t *o = (orc_t *)calloc(1, sizeof(orc_t));
+    if (!o) return NULL;
+    o->k = k;
+    o->cap = 1024;
+    while (o->cap < windows * 2) o->cap <<= 1;
+    o->tab = (orc_slot *)malloc(o->cap * sizeof(orc_slot));
+    if (!o->tab) { free(o); return NULL; }
+    memset(o->tab, 0xFF, o->cap * sizeof(orc_slot));
+    const uint64_t mask = o->cap - 1, kmask = (1ULL << (2 * k)) - 1;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        const uint64_t beg = offsets[r], len = offsets[r + 1] - beg;
+        if (len <= (uint64_t)k) continue; /* debruijn.py:126 */
+        const unsigned char *s = (const unsigned char *)bases + beg;
+        uint64_t key = 0;
+        for (uint64_t i = 0; i < len; ++i) {
+            const unsigned char c = s[i];
+            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { orc_free(o); return NULL; }
+            if (i >= (uint64_t)k) {
+                /* window [i-k, i) is complete in `key`; s[i] is its successor base */
+                const uint64_t pos = i - k;
+                uint64_t h = mix64(key) & mask;
+                while (o->tab[h].key != ~0ULL && o->tab[h].key != key) h = (h + 1) & mask;
+                orc_slot *e = &o->tab[h];
+                if (e->key == ~0ULL) {
+                    e->key = key;
+                    e->stamp = ((beg + pos) << 1) | (pos != 0);
+                    e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;
+                    o->n_nodes++;
+                }
+                e->cnt[(c >> 1) & 3]++;
+                o->n_kmer_inst++;
+                o->n_edge_inst++;
+            }
+            key = ((key << 2) | ((c >> 1) & 3)) & kmask;
+        }
+        { /* read-final window: vertex occurrence without a successor */
+            const uint64_t pos = len - k;
+            uint64_t h = mix64(key) & mask;
+            while (o->tab[h].key != ~0ULL && o->tab[h].key != key) h = (h + 1) & mask;
+            orc_slot *e = &o->tab[h];
+            if (e->key == ~0ULL) {
+                e->key = key;
+                e->stamp = ((beg + pos) << 1) | (pos != 0);
+                e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;
+                o->n_nodes++;
+            }
+            o->n_kmer_inst++;
+        }
+    }
+    return o;
+}
+
+uint64_t orc_n_nodes(const orc_t *o) { return o->n_nodes; }
+uint64_t orc_n_kmer_instances(const orc_t *o) { return o->n_kmer_inst; }
+uint64_t orc_n_edge_instances(const orc_t *o) { return o->n_edge_inst; }
+
+static int cmp_stamp(const void *a, const void *b) {
+    const uint64_t x = ((const orc_slot *)a)->stamp, y = ((const orc_slot *)b)->stamp;
+    return x < y ? -1 : x > y;
+}
+
+/* nodes in first-occurrence (dict) order; arrays sized orc_n_nodes (counts: n*4, by base code) */
+int orc_export(const orc_t *o, uint64_t *keys, uint64_t *stamps, uint32_t *counts) {
+    orc_slot *tmp = (orc_slot *)malloc((o->n_nodes ? o->n_nodes : 1) * sizeof(orc_slot));
+    if (!tmp) return -1;
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < o->cap; ++i)
+        if (o->tab[i].key != ~0ULL) tmp[n++] = o->tab[i];
+    qsort(tmp, n, sizeof(orc_slot), cmp_stamp);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (keys) keys[i] = tmp[i].key;
+        if (stamps) stamps[i] = tmp[i].stamp;
+        if (counts) memcpy(counts + 4 * i, tmp[i].cnt, 16);
+    }
+    free(tmp);
+    return 0;
+}

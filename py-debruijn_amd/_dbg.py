@@ -21,7 +21,7 @@ ABI_VERSION = 1
 
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
-    "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_reads", "dbg_set_reads_device",
+    "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_device",
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs", "dbg_device_views",
@@ -77,6 +77,7 @@ def load_library():
         "dbg_destroy": (None, [H]),
         "dbg_last_error": (C.c_char_p, [H]),
         "dbg_abi_version": (C.c_int, []),
+        "dbg_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
         "dbg_set_reads": (C.c_int, [H, vp, vp, C.c_uint64]),
         "dbg_set_reads_device": (C.c_int, [H, vp, C.c_uint64, vp, C.c_uint64]),
         "dbg_synth_reads": (C.c_int, [H, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
@@ -129,6 +130,9 @@ class Graph:
             self._h = None
             raise DbgError(rc, "dbg_create failed: no usable MI355X visible (the device path has no CPU fallback)")
         self._keep = []  # buffers the device borrows
+        for var, opt in (("DBG_ENGINE", "engine"), ("DBG_BUCKET_BITS", "bucket_bits"), ("DBG_LDS_SLOTS", "lds_slots")):
+            if os.environ.get(var, "") != "":
+                self.set_option(opt, int(os.environ[var]))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -145,6 +149,9 @@ class Graph:
         if rc != DBG_OK:
             msg = self._lib.dbg_last_error(self._h).decode("utf-8", "replace")
             raise (AlphabetError if rc == DBG_E_ALPHABET else DbgError)(rc, msg)
+
+    def set_option(self, name, value):
+        self._chk(self._lib.dbg_set_option(self._h, name.encode(), int(value)))
 
     # ---- reads
     def set_reads(self, bases, offsets):

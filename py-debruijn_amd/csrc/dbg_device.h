@@ -84,4 +84,62 @@ __device__ inline uint64_t wave_sum_u64(uint64_t v) {
     return v;  // valid in lane 0
 }
 
+// ------------------------------------------------------------------------------------------
+// tile loader shared by k_count and k_pull_reads: TILE positions + 64 halo, as a big-endian
+// 2-bit stream in LDS (16 bases per dword) plus the matching slice of the read-start bitmap
+// ------------------------------------------------------------------------------------------
+constexpr int TILE = 8192;
+constexpr int HALO = 64;
+constexpr int PK_WORDS = (TILE + HALO) / 16 + 2;  // +2: window reads touch word+2
+constexpr int SB_WORDS = (TILE + HALO) / 32 + 2;
+
+struct TileLds {
+    uint32_t pk[PK_WORDS];
+    uint32_t sb[SB_WORDS];
+};
+
+// returns nonzero if a byte outside ACGT was seen among the bytes < n_bytes
+__device__ inline uint32_t load_tile(TileLds &t, const char *bases, uint64_t n_bytes, const uint32_t *startbits,
+                                     uint64_t tile0) {
+    uint32_t bad = 0;
+    for (int v = threadIdx.x; v < PK_WORDS; v += blockDim.x) {
+        const uint64_t off = tile0 + (uint64_t)v * 16;
+        uint4 q = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);  // 'A' padding
+        if (v < (TILE + HALO) / 16 && off < n_bytes) {
+            if (off + 16 <= n_bytes) {
+                q = *reinterpret_cast<const uint4 *>(bases + off);
+            } else {
+                uint32_t w[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+                for (int b = 0; b < 16 && off + b < n_bytes; ++b) {
+                    w[b >> 2] &= ~(0xFFu << (8 * (b & 3)));
+                    w[b >> 2] |= (uint32_t)(uint8_t)bases[off + b] << (8 * (b & 3));
+                }
+                q = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            const uint32_t ok = acgt_bytes(q.x) & acgt_bytes(q.y) & acgt_bytes(q.z) & acgt_bytes(q.w);
+            bad |= (ok != 0x80808080u);
+        }
+        t.pk[v] = (pack4(q.x) << 24) | (pack4(q.y) << 16) | (pack4(q.z) << 8) | pack4(q.w);
+    }
+    const uint64_t w0 = tile0 >> 5;
+    for (int v = threadIdx.x; v < SB_WORDS; v += blockDim.x) t.sb[v] = startbits[w0 + v];
+    return bad;
+}
+
+// 32 bases starting at tile-relative position j, first base in bits 63:62
+__device__ inline uint64_t window32(const TileLds &t, int j) {
+    const int w = j >> 4, sh = (j & 15) * 2;
+    const uint64_t hi = ((uint64_t)t.pk[w] << 32) | t.pk[w + 1];
+    const uint64_t lo = (uint64_t)t.pk[w + 2] << 32;
+    return sh ? (hi << sh) | (lo >> (64 - sh)) : hi;
+}
+
+// read-start bits of positions j .. j+31 (bit 0 = position j)
+__device__ inline uint32_t startwin32(const TileLds &t, int j) {
+    const int w = j >> 5, sh = j & 31;
+    const uint64_t both = ((uint64_t)t.sb[w + 1] << 32) | t.sb[w];
+    return (uint32_t)(both >> sh);
+}
+
+
 }  // namespace dbgk

@@ -19,6 +19,7 @@
 
 #include "../../include/dbg.h"
 #include "dbg_device.h"
+#include "dbg_sk.h"
 
 using namespace dbgk;
 
@@ -54,6 +55,7 @@ struct dbg {
     uint8_t *d_flags = nullptr;
     uint8_t *d_order = nullptr;  // successor codes ranked by (count desc, ascii asc), 2 bits each
     uint32_t *d_succ = nullptr;
+    bool nodes_in_arena = false;  // node arrays borrowed from ar_node (super-k-mer engine)
     uint64_t *d_rowptr = nullptr;
     uint32_t *d_col = nullptr, *d_ecnt = nullptr;
 
@@ -75,8 +77,45 @@ struct dbg {
     uint32_t *d_ctg_seq = nullptr;
     bool walked = false;
 
+    // options (dbg_set_option)
+    int engine = 0;          // 0 = super-k-mer partitioned build, 1 = single global hash table
+    int bucket_bits = 0;     // 0 = auto (super-k-mer engine)
+    int lds_slots = 4096;    // LDS table slots per bucket workgroup (2048 or 4096)
+
+    // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
+    // so buffers survive across dbg_build calls on the same handle
+    struct Buf {
+        void *p = nullptr;
+        uint64_t bytes = 0;
+    };
+    Buf ar_rec[2][3], ar_q[2][2], ar_node[6], ar_misc[8];
+    // branch k-mer lookup (pull-out reads)
+    uint64_t *d_btab = nullptr;
+    uint64_t btab_cap = 0;
+
     dbg_stats_t stats{};
 };
+
+static int buf_ensure(dbg *h, dbg::Buf &b, uint64_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return DBG_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        h->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        b.p = nullptr;
+        return DBG_E_NOMEM;
+    }
+    b.bytes = bytes;
+    return DBG_OK;
+}
+static void buf_free(dbg::Buf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
 
 #define HIPCHK(h, call)                                                                      \
     do {                                                                                     \
@@ -281,63 +320,6 @@ __global__ __launch_bounds__(256) void k_startbits(const uint64_t *offsets, uint
         uint64_t p = offsets[i];
         atomicOr(&bits[p >> 5], 1u << (p & 31));
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// tile loader shared by k_count and k_pull_reads: TILE positions + 64 halo, as a big-endian
-// 2-bit stream in LDS (16 bases per dword) plus the matching slice of the read-start bitmap
-// ------------------------------------------------------------------------------------------
-constexpr int TILE = 8192;
-constexpr int HALO = 64;
-constexpr int PK_WORDS = (TILE + HALO) / 16 + 2;  // +2: window reads touch word+2
-constexpr int SB_WORDS = (TILE + HALO) / 32 + 2;
-
-struct TileLds {
-    uint32_t pk[PK_WORDS];
-    uint32_t sb[SB_WORDS];
-};
-
-// returns nonzero if a byte outside ACGT was seen among the bytes < n_bytes
-__device__ inline uint32_t load_tile(TileLds &t, const char *bases, uint64_t n_bytes, const uint32_t *startbits,
-                                     uint64_t tile0) {
-    uint32_t bad = 0;
-    for (int v = threadIdx.x; v < PK_WORDS; v += blockDim.x) {
-        const uint64_t off = tile0 + (uint64_t)v * 16;
-        uint4 q = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);  // 'A' padding
-        if (v < (TILE + HALO) / 16 && off < n_bytes) {
-            if (off + 16 <= n_bytes) {
-                q = *reinterpret_cast<const uint4 *>(bases + off);
-            } else {
-                uint32_t w[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
-                for (int b = 0; b < 16 && off + b < n_bytes; ++b) {
-                    w[b >> 2] &= ~(0xFFu << (8 * (b & 3)));
-                    w[b >> 2] |= (uint32_t)(uint8_t)bases[off + b] << (8 * (b & 3));
-                }
-                q = make_uint4(w[0], w[1], w[2], w[3]);
-            }
-            const uint32_t ok = acgt_bytes(q.x) & acgt_bytes(q.y) & acgt_bytes(q.z) & acgt_bytes(q.w);
-            bad |= (ok != 0x80808080u);
-        }
-        t.pk[v] = (pack4(q.x) << 24) | (pack4(q.y) << 16) | (pack4(q.z) << 8) | pack4(q.w);
-    }
-    const uint64_t w0 = tile0 >> 5;
-    for (int v = threadIdx.x; v < SB_WORDS; v += blockDim.x) t.sb[v] = startbits[w0 + v];
-    return bad;
-}
-
-// 32 bases starting at tile-relative position j, first base in bits 63:62
-__device__ inline uint64_t window32(const TileLds &t, int j) {
-    const int w = j >> 4, sh = (j & 15) * 2;
-    const uint64_t hi = ((uint64_t)t.pk[w] << 32) | t.pk[w + 1];
-    const uint64_t lo = (uint64_t)t.pk[w + 2] << 32;
-    return sh ? (hi << sh) | (lo >> (64 - sh)) : hi;
-}
-
-// read-start bits of positions j .. j+31 (bit 0 = position j)
-__device__ inline uint32_t startwin32(const TileLds &t, int j) {
-    const int w = j >> 5, sh = j & 31;
-    const uint64_t both = ((uint64_t)t.sb[w + 1] << 32) | t.sb[w];
-    return (uint32_t)(both >> sh);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -640,9 +622,23 @@ __global__ __launch_bounds__(256) void k_fill(T *p, uint64_t n, T v) {
 // ------------------------------------------------------------------------------------------
 // a9: reads that contain a branch k-mer as a substring (reads of length == k included)
 // ------------------------------------------------------------------------------------------
+// open-address set of the branch k-mers (few): the only lookup structure a9 needs
+__global__ __launch_bounds__(256) void k_branch_insert(uint64_t n_nodes, const uint8_t *flags, const uint64_t *keys,
+                                                       unsigned long long *btab, uint64_t cap_mask) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || !(flags[i] & DBG_F_BRANCH)) return;
+    const unsigned long long key = keys[i];
+    uint64_t slot = kmer_hash(key) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        const unsigned long long cur = atomicCAS(&btab[slot], EMPTY_KEY, key);
+        if (cur == EMPTY_KEY || cur == key) return;
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pull_reads(const char *__restrict__ bases, uint64_t n_bytes,
-                                                    const uint32_t *__restrict__ startbits, int k, const Slot *tab,
-                                                    uint64_t cap_mask, int hash_shift, const uint8_t *flags,
+                                                    const uint32_t *__restrict__ startbits, int k,
+                                                    const uint64_t *__restrict__ btab, uint64_t cap_mask,
                                                     const uint64_t *offsets, uint64_t n_reads, uint8_t *read_flags) {
     __shared__ TileLds t;
     const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
@@ -655,8 +651,15 @@ __global__ __launch_bounds__(256) void k_pull_reads(const char *__restrict__ bas
         const uint32_t sw = startwin32(t, j);
         if ((sw >> 1) & mid_mask) continue;
         const uint64_t kmer = window32(t, j) >> (64 - 2 * k);
-        const uint32_t node = tab_find(tab, cap_mask, hash_shift, kmer);
-        if (node == NO_NODE || !(flags[node] & DBG_F_BRANCH)) continue;
+        uint64_t slot = kmer_hash(kmer) & cap_mask;
+        bool hit = false;
+        for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+            const uint64_t cur = btab[slot];
+            if (cur == kmer) { hit = true; break; }
+            if (cur == EMPTY_KEY) break;
+            slot = (slot + 1) & cap_mask;
+        }
+        if (!hit) continue;
         // read index: last r with offsets[r] <= p (skipping empty reads that share the offset)
         uint64_t lo = 0, hi = n_reads;  // offsets[lo] <= p < offsets[hi]
         while (hi - lo > 1) {
@@ -832,6 +835,13 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
 // ==========================================================================================
 static void free_build(dbg *h) {
     dev_free(h->d_tab); dev_free(h->d_occ);
+    if (h->nodes_in_arena) {
+        h->d_keys = nullptr; h->d_stamps = nullptr; h->d_cnt = nullptr; h->d_flags = nullptr;
+        h->d_order = nullptr; h->d_succ = nullptr;
+        h->nodes_in_arena = false;
+    }
+    dev_free(h->d_btab);
+    h->btab_cap = 0;
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
     dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_rowptr); dev_free(h->d_col); dev_free(h->d_ecnt);
     dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
@@ -878,6 +888,10 @@ extern "C" void dbg_destroy(dbg_t *h) {
     (void)hipStreamSynchronize(h->stream);
     free_build(h);
     free_reads(h);
+    for (auto &lvl : h->ar_rec) for (auto &b : lvl) buf_free(b);
+    for (auto &lvl : h->ar_q) for (auto &b : lvl) buf_free(b);
+    for (auto &b : h->ar_node) buf_free(b);
+    for (auto &b : h->ar_misc) buf_free(b);
     dev_free(h->d_scalars);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -981,6 +995,45 @@ extern "C" int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets) {
 }
 
 // ------------------------------------------------------------------------------------------
+static int build_sk(dbg *h, int k, uint64_t node_capacity_hint);
+// CSR over distinct edges + start count; shared by both engines
+static int finish_graph(dbg *h) {
+    {
+        Timer t(h->stream);
+        CHK(dev_alloc(h, &h->d_rowptr, h->n_nodes + 1));
+        uint64_t total = 0;
+        CHK(exclusive_scan(h, h->n_nodes, DegOf{h->d_cnt}, h->d_rowptr, &total));
+        h->n_edges = total;
+        HIPCHK(h, hipMemcpyAsync(h->d_rowptr + h->n_nodes, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
+        CHK(dev_alloc(h, &h->d_col, total));
+        CHK(dev_alloc(h, &h->d_ecnt, total));
+        if (h->n_nodes) {
+            hipLaunchKernelGGL(k_csr_fill, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
+                               h->d_rowptr, h->d_cnt, h->d_succ, h->d_col, h->d_ecnt);
+            HIPCHK(h, hipGetLastError());
+        }
+        h->stats.ms_csr = t.stop();
+    }
+    // starts = nodes with indegree 0
+    {
+        uint64_t total = 0;
+        CHK(reduce_sum(h, h->n_nodes, FlagSet{h->d_flags, DBG_F_INDEG, 0}, &total));
+        h->n_starts = total;
+    }
+    return DBG_OK;
+}
+
+
+extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
+    if (!h || !name) return DBG_E_ARG;
+    const std::string n(name);
+    if (n == "engine" && (value == 0 || value == 1)) { h->engine = (int)value; return DBG_OK; }
+    if (n == "bucket_bits" && value >= 0 && value <= 18) { h->bucket_bits = (int)value; return DBG_OK; }
+    if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
+    h->err = "unknown option or value out of range: " + n;
+    return DBG_E_ARG;
+}
+
 extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     if (!h) return DBG_E_ARG;
     if (k < 1 || k > 31) { h->err = "k must be in 1..31 (64-bit (k+1)-mer words)"; return DBG_E_ARG; }
@@ -988,6 +1041,15 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     HIPCHK(h, hipSetDevice(h->device));
     free_build(h);
     h->k = k;
+    h->stats = dbg_stats_t{};
+    if (h->engine == 0) {
+        Timer t_total(h->stream);
+        int rc = build_sk(h, k, table_capacity_hint);
+        if (rc == DBG_OK) rc = finish_graph(h);
+        if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+        h->stats.ms_build_total = t_total.stop();
+        return DBG_OK;
+    }
     Timer t_total(h->stream);
 
     // table sizing: worst case every window is a distinct k-mer
@@ -1058,28 +1120,7 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
         }
         h->stats.ms_succ = t.stop();
     }
-    {
-        Timer t(h->stream);
-        CHK(dev_alloc(h, &h->d_rowptr, h->n_nodes + 1));
-        uint64_t total = 0;
-        CHK(exclusive_scan(h, h->n_nodes, DegOf{h->d_cnt}, h->d_rowptr, &total));
-        h->n_edges = total;
-        HIPCHK(h, hipMemcpyAsync(h->d_rowptr + h->n_nodes, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
-        CHK(dev_alloc(h, &h->d_col, total));
-        CHK(dev_alloc(h, &h->d_ecnt, total));
-        if (h->n_nodes) {
-            hipLaunchKernelGGL(k_csr_fill, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
-                               h->d_rowptr, h->d_cnt, h->d_succ, h->d_col, h->d_ecnt);
-            HIPCHK(h, hipGetLastError());
-        }
-        h->stats.ms_csr = t.stop();
-    }
-    // starts = nodes with indegree 0
-    {
-        uint64_t total = 0;
-        CHK(reduce_sum(h, h->n_nodes, FlagSet{h->d_flags, DBG_F_INDEG, 0}, &total));
-        h->n_starts = total;
-    }
+    CHK(finish_graph(h));
     h->stats.ms_build_total = t_total.stop();
     return DBG_OK;
 }
@@ -1166,9 +1207,16 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
     h->n_pull_reads = 0;
     if (h->n_branch && h->n_bytes) {
         const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+        uint64_t bcap = 1024;
+        while (bcap < h->n_branch * 2) bcap <<= 1;
+        dev_free(h->d_btab);
+        CHK(dev_alloc(h, &h->d_btab, bcap));
+        h->btab_cap = bcap;
+        HIPCHK(h, hipMemsetAsync(h->d_btab, 0xFF, bcap * 8, h->stream));
+        hipLaunchKernelGGL(k_branch_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
+                           h->d_flags, h->d_keys, (unsigned long long *)h->d_btab, bcap - 1);
         hipLaunchKernelGGL(k_pull_reads, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
-                           h->d_startbits, h->k, h->d_tab, h->cap - 1, 64 - h->cap_log2, h->d_flags, h->d_offsets,
-                           h->n_reads, h->d_read_flags);
+                           h->d_startbits, h->k, h->d_btab, bcap - 1, h->d_offsets, h->n_reads, h->d_read_flags);
         HIPCHK(h, hipGetLastError());
         uint64_t total = 0;
         CHK(reduce_sum(h, h->n_reads, ByteAt{h->d_read_flags}, &total));
@@ -1360,4 +1408,247 @@ extern "C" int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_co
     if (d_flags) *d_flags = h->d_flags;
     if (d_succ) *d_succ = h->d_succ;
     return DBG_OK;
+}
+
+// ==========================================================================================
+// super-k-mer engine: host orchestration
+// ==========================================================================================
+struct CeilDiv {
+    const uint64_t *cnt;
+    uint64_t d;
+    __device__ uint64_t operator()(uint64_t i) const { return (cnt[i] + d - 1) / d; }
+};
+
+// One multisplit level: parents (p_start/p_cnt, device) -> children (c_start/c_cnt, device,
+// n_parents * nb entries), records moved from in_* to out_*.
+template <class ST, bool HAS_ST>
+static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_cnt, uint32_t n_parents, uint64_t total,
+                            const uint64_t *in_w0, const uint64_t *in_w1, const ST *in_st, uint64_t *out_w0,
+                            uint64_t *out_w1, ST *out_st, int shift, int nb, uint64_t *c_start, uint64_t *c_cnt,
+                            dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs) {
+    CHK(buf_ensure(h, b_scpre, (uint64_t)(n_parents + 1) * 8));
+    uint64_t *sc_pre = (uint64_t *)b_scpre.p;
+    uint64_t nsc = 0;
+    CHK(exclusive_scan(h, n_parents, CeilDiv{p_cnt, (uint64_t)MS_SC}, sc_pre, &nsc));
+    HIPCHK(h, hipMemcpyAsync(sc_pre + n_parents, &nsc, 8, hipMemcpyHostToDevice, h->stream));
+    MsParents P{p_start, p_cnt, sc_pre, n_parents};
+    const uint64_t n_log = nsc * (uint64_t)nb;
+    CHK(buf_ensure(h, b_cmat, n_log * 4));
+    CHK(buf_ensure(h, b_offs, n_log * 8));
+    uint32_t *cmat = (uint32_t *)b_cmat.p;
+    uint64_t *offs = (uint64_t *)b_offs.p;
+    if (nsc) {
+        hipLaunchKernelGGL(k_ms_hist, dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb, cmat);
+        HIPCHK(h, hipGetLastError());
+        uint64_t tot = 0;
+        CHK(exclusive_scan(h, n_log, MsLogical{P, cmat, nb}, offs, &tot));
+        if (tot != total) { h->err = "multisplit: histogram total mismatch"; return DBG_E_HIP; }
+    }
+    const uint64_t n_child = (uint64_t)n_parents * nb;
+    hipLaunchKernelGGL(k_ms_children, dim3(grid_for(n_child, 256)), dim3(256), 0, h->stream, P, offs, nb, total, c_start,
+                       c_cnt);
+    if (nsc) {
+        auto kern = k_ms_scatter<ST, HAS_ST>;
+        const size_t lds = sizeof(MsLds<ST>);
+        HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(256), lds, h->stream, P, in_w0, in_w1, in_st, shift, nb, offs,
+                           out_w0, out_w1, out_st);
+    }
+    HIPCHK(h, hipGetLastError());
+    return DBG_OK;
+}
+
+// Two-level split of `total` records by the top (l1 + l2) bits of the 22-bit bucket hash that sits
+// at bit `field_lo` of w1.  On return the records are in set `*where` (0 or 1) of the ping-pong
+// buffers and final_start/final_cnt (2^(l1+l2) entries) describe the buckets.
+template <class ST, bool HAS_ST>
+static int multisplit_two_level(dbg *h, uint64_t total, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], int field_lo, int l1,
+                                int l2, uint64_t *final_start, uint64_t *final_cnt, int *where) {
+    // level-0 parent: the whole array
+    CHK(buf_ensure(h, h->ar_misc[0], 16));
+    uint64_t root[2] = {0, total};
+    HIPCHK(h, hipMemcpyAsync(h->ar_misc[0].p, root, 16, hipMemcpyHostToDevice, h->stream));
+    const uint64_t *p_start = (const uint64_t *)h->ar_misc[0].p, *p_cnt = p_start + 1;
+    uint32_t n_parents = 1;
+    int cur = 0;
+    const int top = field_lo + SK_BUCKET_BITS;
+    if (l1 > 0) {
+        const int nb = 1 << l1;
+        uint64_t *cs, *cc;
+        if (l2 > 0) {
+            CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb * 16));
+            cs = (uint64_t *)h->ar_misc[1].p;
+            cc = cs + nb;
+        } else {
+            cs = final_start;
+            cc = final_cnt;
+        }
+        CHK((multisplit_level<ST, HAS_ST>(h, p_start, p_cnt, n_parents, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
+                                           w1[cur ^ 1], st[cur ^ 1], top - l1, nb, cs, cc, h->ar_misc[2], h->ar_misc[3],
+                                           h->ar_misc[4])));
+        cur ^= 1;
+        p_start = cs;
+        p_cnt = cc;
+        n_parents = nb;
+    }
+    if (l2 > 0) {
+        const int nb = 1 << l2;
+        CHK((multisplit_level<ST, HAS_ST>(h, p_start, p_cnt, n_parents, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
+                                           w1[cur ^ 1], st[cur ^ 1], top - l1 - l2, nb, final_start, final_cnt,
+                                           h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+        cur ^= 1;
+    }
+    if (l1 == 0 && l2 == 0) {
+        HIPCHK(h, hipMemcpyAsync(final_start, root, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(final_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `root` lives on this stack frame
+    *where = cur;
+    return DBG_OK;
+}
+
+template <class ST, int CAP>
+static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
+    const int m = sk_m_for_k(k), w = k - m + 1;
+    unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
+    const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+    uint64_t sc[8] = {0};
+    uint64_t *w0[2], *w1[2];
+    ST *st[2];
+    // ---- K1: extraction
+    {
+        Timer t(h->stream);
+        uint64_t rec_cap = (w == 1) ? h->n_bytes + 64 : h->n_bytes / 3 + tiles * 8 + 1024;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            for (int set = 0; set < 2; ++set) {
+                CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
+                CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
+                CHK(buf_ensure(h, h->ar_rec[set][2], rec_cap * sizeof(ST)));
+                w0[set] = (uint64_t *)h->ar_rec[set][0].p;
+                w1[set] = (uint64_t *)h->ar_rec[set][1].p;
+                st[set] = (ST *)h->ar_rec[set][2].p;
+            }
+            HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+            if (tiles) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3((unsigned)tiles), dim3(256), 0, h->stream,
+                                   h->d_bases, h->n_bytes, h->d_startbits, k, m, w0[0], w1[0], st[0], rec_cap, sc_dev);
+                HIPCHK(h, hipGetLastError());
+            }
+            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
+            if (!(sc[0] & 4)) break;
+            if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
+            rec_cap = h->n_bytes + 64;
+        }
+        h->stats.ms_startbits += 0;
+        h->stats.ms_table_init = t.stop();  // phase slot re-used: extraction time
+    }
+    h->n_kmer_inst = sc[1];
+    h->n_edge_inst = sc[2];
+    const uint64_t n_rec = sc[3];
+
+    // ---- bucket geometry
+    int T = h->bucket_bits;
+    if (T == 0) {
+        const double want = (double)h->n_kmer_inst * 0.4 / (CAP * 0.375);
+        while (T < 18 && (double)(1ull << T) < want) ++T;
+    }
+    const int l1 = (T + 1) / 2, l2 = T - l1;
+    const uint64_t n_buckets = 1ull << T;
+
+    // ---- K2-K4: two-level multisplit of the records
+    CHK(buf_ensure(h, h->ar_misc[5], n_buckets * 16));
+    uint64_t *b_start = (uint64_t *)h->ar_misc[5].p, *b_cnt = b_start + n_buckets;
+    int where = 0;
+    {
+        Timer t(h->stream);
+        CHK((multisplit_two_level<ST, true>(h, n_rec, w0, w1, st, 6, l1, l2, b_start, b_cnt, &where)));
+        h->stats.ms_compact = t.stop();  // phase slot re-used: partition time
+    }
+
+    // ---- K5: per-bucket counting
+    uint64_t node_cap = node_capacity_hint ? node_capacity_hint : h->n_kmer_inst;
+    if (node_cap > 0xFFFFFFF0ull) node_cap = 0xFFFFFFF0ull;
+    CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
+    CHK(buf_ensure(h, h->ar_node[1], node_cap * 8));
+    CHK(buf_ensure(h, h->ar_node[2], node_cap * 16));
+    CHK(buf_ensure(h, h->ar_node[3], node_cap));
+    CHK(buf_ensure(h, h->ar_node[4], node_cap));
+    CHK(buf_ensure(h, h->ar_node[5], node_cap * 16));
+    h->d_keys = (uint64_t *)h->ar_node[0].p;
+    h->d_stamps = (uint64_t *)h->ar_node[1].p;
+    h->d_cnt = (uint32_t *)h->ar_node[2].p;
+    h->d_flags = (uint8_t *)h->ar_node[3].p;
+    h->d_order = (uint8_t *)h->ar_node[4].p;
+    h->d_succ = (uint32_t *)h->ar_node[5].p;
+    h->nodes_in_arena = true;
+    uint64_t q_cap = n_rec + 1024;
+    uint64_t *qk[2], *qm[2];
+    const uint64_t range_cap = n_buckets * 2 + 4096 + h->n_kmer_inst / (CAP / 4);
+    CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
+    SkRange *ranges = (SkRange *)h->ar_misc[6].p;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int set = 0; set < 2; ++set) {
+            CHK(buf_ensure(h, h->ar_q[set][0], q_cap * 8));
+            CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
+            qk[set] = (uint64_t *)h->ar_q[set][0].p;
+            qm[set] = (uint64_t *)h->ar_q[set][1].p;
+        }
+        Timer t(h->stream);
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_scalars + 4, 0, 24, h->stream));
+        SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_succ, node_cap,
+                       qk[0], qm[0], q_cap, ranges, range_cap, sc_dev};
+        auto kern = k_sk_count<ST, CAP>;
+        const size_t lds = sizeof(CntLds<ST, CAP>);
+        HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (n_rec) {
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_buckets), dim3(256), lds, h->stream, b_start, b_cnt, w0[where],
+                               w1[where], st[where], k, m, 0, out);
+            HIPCHK(h, hipGetLastError());
+        }
+        h->stats.count_launches = n_rec ? 1 : 0;
+        HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
+        h->stats.ms_count = t.stop();
+        // buckets that had to be split by hash sub-range turn in-bucket successors into queries:
+        // the usual bound (one query per record) no longer holds, retry with the safe one
+        if ((sc[0] & 64) && attempt == 0) { q_cap = h->n_edge_inst + 1024; continue; }
+        break;
+    }
+    if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
+    if (sc[0] & 16) { h->err = "node capacity exceeded"; return DBG_E_CAPACITY; }
+    if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
+    h->n_nodes = sc[4];
+    const uint64_t n_q = sc[5], n_ranges = sc[6];
+
+    // ---- K6-K8: successors that live in another bucket
+    {
+        Timer t(h->stream);
+        if (n_q) {
+            CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16));
+            uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets;
+            uint32_t *dummy[2] = {nullptr, nullptr};
+            int qwhere = 0;
+            CHK((multisplit_two_level<uint32_t, false>(h, n_q, qk, qm, dummy, 40, l1, l2, q_start, q_cnt, &qwhere)));
+            auto kern = k_q_answer<CAP>;
+            const size_t lds = sizeof(AnsLds<CAP>);
+            HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt,
+                               qk[qwhere], qm[qwhere], h->d_keys, h->d_succ, sc_dev);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (sc[0] & 128) { h->err = "internal: a successor k-mer was not found in its bucket"; return DBG_E_HIP; }
+        }
+        h->stats.ms_succ = t.stop();
+    }
+    return DBG_OK;
+}
+
+static int build_sk(dbg *h, int k, uint64_t node_capacity_hint) {
+    const bool small = (h->n_bytes < (1ull << 31));
+    if (h->lds_slots == 2048)
+        return small ? build_sk_t<uint32_t, 2048>(h, k, node_capacity_hint) : build_sk_t<uint64_t, 2048>(h, k, node_capacity_hint);
+    return small ? build_sk_t<uint32_t, 4096>(h, k, node_capacity_hint) : build_sk_t<uint64_t, 4096>(h, k, node_capacity_hint);
 }

@@ -1,0 +1,599 @@
+// Super-k-mer engine: the HBM-lean build path (included by dbg_hip.hip; one translation unit).
+//
+//   k_sk_extract   reads -> fixed 16-byte super-k-mer records (+ stamp), one per run of
+//                  consecutive k-mers that share a minimizer           [debruijn.py:123-128 windows]
+//   k_ms_hist / k_ms_scatter   two-level LDS multisplit of the records by minimizer-hash bucket
+//   k_sk_count     one workgroup per bucket: expand records, LDS open-address table with
+//                  successor counters + first-occurrence stamp, compaction to the node arrays,
+//                  in-bucket successor lookup                           [debruijn.py:129-143, :213-222]
+//   k_q_bucket / k_q_answer    the successors that live in another bucket (about one per record)
+//
+// No global atomics per k-mer: they run at ~2-3e10/s chip-wide (memory-side), far below what
+// this path needs; all per-k-mer atomics are LDS atomics.
+#pragma once
+#include "dbg_device.h"
+
+namespace dbgk {
+
+// ---- record layout -----------------------------------------------------------------------------
+// w0: bases 0..31 (first base in bits 63:62)
+// w1: bits 63..28 bases 32..49 | bits 27..6 bucket hash (22 bits) | bits 5..1 len-1 | bit 0 last k-mer has a successor
+// st: stamp of the first k-mer; k-mer i > 0 of the record has stamp (st | 1) + 2 i
+constexpr int SK_MAX_M = 13;        // minimizer length for k >= 13 (else m = k)
+constexpr int SK_BUCKET_BITS = 22;  // bucket hash bits carried in w1
+constexpr int SK_META_BITS = 28;
+
+__host__ __device__ inline int sk_m_for_k(int k) { return k < SK_MAX_M ? k : SK_MAX_M; }
+
+__device__ inline uint32_t mmer_hash32(uint64_t mmer) { return (uint32_t)(mix64(mmer + 0x51ED270B7F4A7C15ull) >> 32); }
+__device__ inline uint32_t bucket_hash22(uint64_t mmer) {
+    return (uint32_t)(mix64(mmer * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull) >> (64 - SK_BUCKET_BITS));
+}
+
+// minimizer-hash bucket of a single packed k-mer (pure function of the k-mer)
+__device__ inline uint32_t kmer_bucket22(uint64_t kmer, int k, int m) {
+    const int w = k - m + 1;
+    const uint64_t mmask = (1ull << (2 * m)) - 1;
+    uint32_t best = 0xFFFFFFFFu;
+    uint64_t best_mm = 0;
+    for (int i = 0; i < w; ++i) {
+        const uint64_t mm = (kmer >> (2 * (k - m - i))) & mmask;
+        const uint32_t hv = mmer_hash32(mm);
+        if (hv < best) { best = hv; best_mm = mm; }
+    }
+    return bucket_hash22(best_mm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: extraction.  One tile of TILE positions per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct SkLds {
+    TileLds t;
+    uint32_t hm[TILE + HALO];       // m-mer hash per position
+    uint16_t minp[TILE];            // minimizer position (tile-relative) per k-mer position, 0xFFFF = no k-mer
+    unsigned long long sbits[TILE / 64 + 1];  // record starts
+    unsigned long long vbits[TILE / 64 + 1];  // valid k-mer positions
+    uint32_t wpre[TILE / 64 + 1];   // exclusive prefix of popcount(sbits)
+    uint32_t nrec;
+    unsigned long long gbase;
+};
+
+template <class ST>
+__global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bases, uint64_t n_bytes,
+                                                    const uint32_t *__restrict__ startbits, int k, int m,
+                                                    uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t rec_cap,
+                                                    unsigned long long *scalars /* [0] err [1] N_k [2] N_e [3] n_rec */) {
+    __shared__ SkLds s;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
+    if (bad) atomicOr(&scalars[0], 1ull);
+    __syncthreads();
+    const int w = k - m + 1;
+    for (int j = threadIdx.x; j < TILE + HALO - 32; j += 256)
+        s.hm[j] = mmer_hash32(window32(s.t, j) >> (64 - 2 * m));
+    __syncthreads();
+
+    const uint32_t mid_mask = (k >= 2) ? ((1u << (k - 1)) - 1u) : 0u;
+    uint64_t n_k = 0, n_e = 0;
+    for (int j0 = 0; j0 < TILE; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        const uint64_t p = tile0 + j;
+        bool v = false;
+        uint32_t mp = 0xFFFFu;
+        if (p < n_bytes) {
+            const uint32_t sw = startwin32(s.t, j);
+            const uint32_t s0 = sw & 1u, sk = (sw >> k) & 1u;
+            v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0);
+            if (v) {
+                n_k += 1;
+                n_e += sk ^ 1u;
+                uint32_t best = s.hm[j];
+                mp = j;
+                for (int i = 1; i < w; ++i) {
+                    const uint32_t hv = s.hm[j + i];
+                    if (hv < best) { best = hv; mp = j + i; }
+                }
+            }
+        }
+        s.minp[j] = (uint16_t)mp;
+        const unsigned long long vb = __ballot(v);
+        if ((threadIdx.x & 63) == 0) s.vbits[j >> 6] = vb;
+    }
+    __syncthreads();
+    for (int j0 = 0; j0 < TILE; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        const uint32_t mp = s.minp[j];
+        const bool st = (mp != 0xFFFFu) && (j == 0 || s.minp[j - 1] != mp);
+        const unsigned long long sb = __ballot(st);
+        if ((threadIdx.x & 63) == 0) s.sbits[j >> 6] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive prefix of per-word record counts (128 words, one wave)
+        uint32_t a = __popcll(s.sbits[threadIdx.x]), b = __popcll(s.sbits[threadIdx.x + 64]);
+        uint32_t ia = a, ib = b;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+            if ((int)threadIdx.x >= d) { ia += oa; ib += ob; }
+        }
+        const uint32_t tot_a = __shfl(ia, 63, 64);
+        s.wpre[threadIdx.x] = ia - a;
+        s.wpre[threadIdx.x + 64] = tot_a + ib - b;
+        if (threadIdx.x == 63) {
+            const uint32_t n = tot_a + ib;
+            s.nrec = n;
+            s.gbase = n ? atomicAdd(&scalars[3], (unsigned long long)n) : 0ull;
+        }
+        if (threadIdx.x == 0) { s.sbits[TILE / 64] = 0; s.vbits[TILE / 64] = 0; }
+    }
+    __syncthreads();
+    const uint64_t gbase = s.gbase;
+    if (gbase + s.nrec > rec_cap) {
+        if (threadIdx.x == 0) atomicOr(&scalars[0], 4ull);  // record buffer too small: caller retries
+    } else {
+        for (int j0 = 0; j0 < TILE; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            const int wd = j >> 6, bt = j & 63;
+            const unsigned long long sb = s.sbits[wd];
+            if (!((sb >> bt) & 1ull)) continue;
+            // run length: up to the next record start or the first position without a k-mer
+            unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
+            unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
+            const int room = 63 - bt;  // positions after j inside this word
+            unsigned long long stop = nxt_s | nxt_i;
+            int len;
+            if (stop) {
+                len = 1 + (__ffsll((unsigned long long)stop) - 1);
+            } else {
+                const unsigned long long stop2 = s.sbits[wd + 1] | ~s.vbits[wd + 1];  // next word (sentinel word: all stop)
+                len = 1 + room + (__ffsll((unsigned long long)stop2) - 1);
+            }
+            if (j + len > TILE) len = TILE - j;
+            const uint64_t p = tile0 + j;
+            const uint32_t s0 = startwin32(s.t, j) & 1u;
+            const uint32_t sk_last = (startwin32(s.t, j + len - 1) >> k) & 1u;
+            const uint32_t has_succ = sk_last ^ 1u;
+            const int nb = k + len - 1 + (int)has_succ;  // bases carried by the record
+            uint64_t w0 = window32(s.t, j);
+            uint64_t hi = window32(s.t, j + 32);
+            if (nb < 32) { w0 &= ~0ull << (64 - 2 * nb); hi = 0; }
+            else if (nb == 32) hi = 0;
+            else hi &= ~0ull << (64 - 2 * (nb - 32));
+            const uint32_t mp = s.minp[j];
+            const uint32_t bh = bucket_hash22(window32(s.t, mp) >> (64 - 2 * m));
+            const uint64_t w1 = (hi & (~0ull << SK_META_BITS)) | ((uint64_t)bh << 6) | ((uint64_t)(len - 1) << 1) | has_succ;
+            const uint64_t o = gbase + s.wpre[wd] + __popcll(sb & ((1ull << bt) - 1));
+            rec_w0[o] = w0;
+            rec_w1[o] = w1;
+            rec_st[o] = (ST)((p << 1) | (s0 ^ 1u));
+        }
+    }
+    n_k = wave_sum_u64(n_k);
+    n_e = wave_sum_u64(n_e);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_k) atomicAdd(&scalars[1], (unsigned long long)n_k);
+        if (n_e) atomicAdd(&scalars[2], (unsigned long long)n_e);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2-K4: multisplit.  Records of `parents` (contiguous ranges) are split by a bit field of w1 into
+// nb children each; a workgroup owns one super-chunk (MS_SC records of one parent).
+// counts matrix: cmat[sc * nb + b]; offsets come from an exclusive scan in (parent, b, sc) order.
+// ------------------------------------------------------------------------------------------------
+constexpr int MS_CH = 4096;           // records sorted per LDS round
+constexpr int MS_SC = 8 * MS_CH;      // records per super-chunk
+constexpr int MS_MAX_NB = 512;
+
+struct MsParents {
+    const uint64_t *start;    // [n_parents]
+    const uint64_t *cnt;      // [n_parents]
+    const uint64_t *sc_pre;   // [n_parents + 1] super-chunks before parent i
+    uint32_t n_parents;
+};
+
+// which parent owns super-chunk g, and which super-chunk of that parent it is
+__device__ inline void ms_locate(const MsParents &P, uint64_t g, uint32_t *parent, uint64_t *sidx) {
+    uint32_t lo = 0, hi = P.n_parents;  // sc_pre[lo] <= g < sc_pre[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (P.sc_pre[mid] <= g) lo = mid; else hi = mid;
+    }
+    *parent = lo;
+    *sidx = g - P.sc_pre[lo];
+}
+
+__global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__restrict__ w1, int shift, int nb,
+                                                 uint32_t *cmat) {
+    __shared__ uint32_t hist[MS_MAX_NB];
+    uint32_t parent;
+    uint64_t sidx;
+    ms_locate(P, blockIdx.x, &parent, &sidx);
+    for (int b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
+    __syncthreads();
+    const uint64_t beg = P.start[parent] + sidx * MS_SC;
+    const uint64_t end = min(P.start[parent] + P.cnt[parent], beg + (uint64_t)MS_SC);
+    for (uint64_t i = beg + threadIdx.x; i < end; i += 256)
+        atomicAdd(&hist[(uint32_t)(w1[i] >> shift) & (uint32_t)(nb - 1)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += 256) cmat[(uint64_t)blockIdx.x * nb + b] = hist[b];
+}
+
+// logical scan order: parent-major, then child bucket, then super-chunk inside the parent
+struct MsLogical {
+    MsParents P;
+    const uint32_t *cmat;
+    int nb;
+    __device__ uint64_t operator()(uint64_t L) const {
+        // lbase[p] = nb * sc_pre[p]
+        uint32_t lo = 0, hi = P.n_parents;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)nb * P.sc_pre[mid] <= L) lo = mid; else hi = mid;
+        }
+        const uint64_t nsc = P.sc_pre[lo + 1] - P.sc_pre[lo];
+        const uint64_t r = L - (uint64_t)nb * P.sc_pre[lo];
+        const uint64_t b = r / nsc, sidx = r - b * nsc;
+        return cmat[(P.sc_pre[lo] + sidx) * nb + b];
+    }
+};
+
+// children descriptors: start/cnt of child (parent p, bucket b) = index p * nb + b
+__global__ __launch_bounds__(256) void k_ms_children(MsParents P, const uint64_t *__restrict__ offs, int nb,
+                                                     uint64_t total, uint64_t *c_start, uint64_t *c_cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_child = (uint64_t)P.n_parents * nb;
+    if (i >= n_child) return;
+    const uint32_t p = (uint32_t)(i / nb), b = (uint32_t)(i % nb);
+    const uint64_t nsc = P.sc_pre[p + 1] - P.sc_pre[p];
+    // first logical element of this child; children with no super-chunk (empty parent) are empty
+    const uint64_t L = (uint64_t)nb * P.sc_pre[p] + (uint64_t)b * nsc;
+    // next child in logical order starts at L + nsc
+    const uint64_t Ln = L + nsc;
+    const uint64_t total_L = (uint64_t)nb * P.sc_pre[P.n_parents];
+    const uint64_t a = (L < total_L) ? offs[L] : total;
+    const uint64_t e = (Ln < total_L) ? offs[Ln] : total;
+    c_start[i] = a;
+    c_cnt[i] = (nsc == 0) ? 0 : e - a;
+}
+
+template <class ST>
+struct MsLds {
+    uint64_t w0[MS_CH];
+    uint64_t w1[MS_CH];
+    ST st[MS_CH];
+    uint32_t hist[MS_MAX_NB];    // count in this chunk
+    uint32_t start[MS_MAX_NB];   // exclusive prefix inside the chunk
+    uint64_t run[MS_MAX_NB];     // global cursor of the super-chunk per child bucket
+};
+
+template <class ST, bool HAS_ST>
+__global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t *__restrict__ in_w0,
+                                                    const uint64_t *__restrict__ in_w1, const ST *__restrict__ in_st,
+                                                    int shift, int nb, const uint64_t *__restrict__ offs,
+                                                    uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ms_raw[];
+    MsLds<ST> &s = *reinterpret_cast<MsLds<ST> *>(ms_raw);
+    uint32_t parent;
+    uint64_t sidx;
+    ms_locate(P, blockIdx.x, &parent, &sidx);
+    const uint64_t nsc = P.sc_pre[parent + 1] - P.sc_pre[parent];
+    const uint64_t lbase = (uint64_t)nb * P.sc_pre[parent];
+    for (int b = threadIdx.x; b < nb; b += 256) s.run[b] = offs[lbase + (uint64_t)b * nsc + sidx];
+    const uint64_t beg = P.start[parent] + sidx * MS_SC;
+    const uint64_t end = min(P.start[parent] + P.cnt[parent], beg + (uint64_t)MS_SC);
+    for (uint64_t c0 = beg; c0 < end; c0 += MS_CH) {
+        const int n = (int)min((uint64_t)MS_CH, end - c0);
+        for (int b = threadIdx.x; b < nb; b += 256) s.hist[b] = 0;
+        __syncthreads();
+        uint64_t r0[MS_CH / 256], r1[MS_CH / 256];
+        ST rs[MS_CH / 256];
+        uint32_t rk[MS_CH / 256];
+#pragma unroll
+        for (int i = 0; i < MS_CH / 256; ++i) {
+            const int q = i * 256 + threadIdx.x;
+            if (q < n) {
+                r0[i] = in_w0[c0 + q];
+                r1[i] = in_w1[c0 + q];
+                if (HAS_ST) rs[i] = in_st[c0 + q];
+                rk[i] = atomicAdd(&s.hist[(uint32_t)(r1[i] >> shift) & (uint32_t)(nb - 1)], 1u);
+            }
+        }
+        __syncthreads();
+        {  // exclusive scan of hist (nb <= 512: two entries per thread)
+            const int b0 = threadIdx.x * 2;
+            const uint32_t a = b0 < nb ? s.hist[b0] : 0, b = b0 + 1 < nb ? s.hist[b0 + 1] : 0;
+            uint64_t tot;
+            const uint64_t ex = block_exscan_256((uint64_t)a + b, &tot);
+            if (b0 < nb) s.start[b0] = (uint32_t)ex;
+            if (b0 + 1 < nb) s.start[b0 + 1] = (uint32_t)ex + a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MS_CH / 256; ++i) {
+            const int q = i * 256 + threadIdx.x;
+            if (q < n) {
+                const uint32_t b = (uint32_t)(r1[i] >> shift) & (uint32_t)(nb - 1);
+                const uint32_t d = s.start[b] + rk[i];
+                s.w0[d] = r0[i];
+                s.w1[d] = r1[i];
+                if (HAS_ST) s.st[d] = rs[i];
+            }
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < n; q += 256) {
+            const uint64_t x1 = s.w1[q];
+            const uint32_t b = (uint32_t)(x1 >> shift) & (uint32_t)(nb - 1);
+            const uint64_t g = s.run[b] + (q - s.start[b]);
+            out_w0[g] = s.w0[q];
+            out_w1[g] = x1;
+            if (HAS_ST) out_st[g] = s.st[q];
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < nb; b += 256) s.run[b] += s.hist[b];
+        __syncthreads();
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K5: per-bucket counting in LDS.
+// ------------------------------------------------------------------------------------------------
+struct SkRange {            // one successfully counted (bucket, hash sub-range): consumed by k_q_answer
+    uint32_t bucket;
+    uint32_t mask, val;     // k-mers with (sub_hash & mask) == val
+    uint32_t node_cnt;
+    uint64_t node_base;
+};
+
+__device__ inline uint32_t sub_hash(uint64_t kmer) { return (uint32_t)(mix64(kmer ^ 0xA24BAED4963EE407ull) >> 40); }
+__device__ inline uint32_t slot_hash(uint64_t kmer) { return (uint32_t)(mix64(kmer * 0xD6E8FEB86659FD93ull) >> 32); }
+
+constexpr int CNT_QBUF = 1536;   // cross-bucket successor queries staged per workgroup
+constexpr int CNT_STACK = 24;    // pending hash sub-ranges of one bucket
+
+template <class ST, int CAP>
+struct CntLds {
+    unsigned long long keys[CAP];
+    uint32_t cnt[CAP * 4];
+    ST stamp[CAP];
+    uint16_t idx[CAP];
+    unsigned long long q_key[CNT_QBUF];
+    unsigned long long q_meta[CNT_QBUF];
+    uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
+    int stk_n;
+    uint32_t n_distinct, overflow, n_local, n_q;
+    unsigned long long gbase, qbase;
+};
+
+// k-mer i of a record: 32-base window starting at base i (first base in bits 63:62)
+__device__ inline uint64_t rec_window(uint64_t w0, uint64_t hi, int i) {
+    return i ? (w0 << (2 * i)) | (hi >> (64 - 2 * i)) : w0;
+}
+
+template <int CAP>
+__device__ inline int lds_find(const unsigned long long *keys, uint64_t key) {
+    uint32_t slot = slot_hash(key) & (CAP - 1);
+    for (int probe = 0; probe < CAP; ++probe) {
+        const unsigned long long cur = keys[slot];
+        if (cur == key) return (int)slot;
+        if (cur == EMPTY_KEY) return -1;
+        slot = (slot + 1) & (CAP - 1);
+    }
+    return -1;
+}
+
+struct SkCountOut {
+    uint64_t *keys, *stamps;
+    uint32_t *cnt;
+    uint8_t *flags, *order;
+    uint32_t *succ;
+    uint64_t node_cap;
+    uint64_t *q_key, *q_meta;
+    uint64_t q_cap;
+    SkRange *ranges;
+    uint64_t range_cap;
+    unsigned long long *scalars;  // [0] err [4] n_nodes [5] n_queries [6] n_ranges
+};
+
+template <class ST, int CAP>
+__global__ __launch_bounds__(256) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
+                                                  const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
+                                                  const ST *__restrict__ rec_st, int k, int m, int bucket_shift,
+                                                  SkCountOut out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char cnt_raw[];
+    CntLds<ST, CAP> &s = *reinterpret_cast<CntLds<ST, CAP> *>(cnt_raw);
+    const uint32_t bucket = blockIdx.x;
+    const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
+    if (r_n == 0) return;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    constexpr uint32_t LIMIT = (uint32_t)(CAP * 0.80);
+    if (threadIdx.x == 0) { s.stk_n = 1; s.stk_mask[0] = 0; s.stk_val[0] = 0; }
+    __syncthreads();
+    while (true) {
+        __syncthreads();
+        if (s.stk_n == 0) break;
+        const uint32_t cur_mask = s.stk_mask[s.stk_n - 1], cur_val = s.stk_val[s.stk_n - 1];
+        __syncthreads();
+        for (int i = threadIdx.x; i < CAP; i += 256) {
+            s.keys[i] = EMPTY_KEY;
+            s.stamp[i] = (ST)~(ST)0;
+            reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+        }
+        if (threadIdx.x == 0) { s.n_distinct = 0; s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
+        __syncthreads();
+        // ---- insert every k-mer of every record of the bucket
+        for (uint64_t r = threadIdx.x; r < r_n; r += 256) {
+            if (s.overflow) break;
+            const uint64_t w0 = rec_w0[r_beg + r], w1 = rec_w1[r_beg + r];
+            const uint64_t st0 = (uint64_t)rec_st[r_beg + r];
+            const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+            const int len = (int)((w1 >> 1) & 31) + 1;
+            const uint32_t hs = (uint32_t)(w1 & 1);
+            for (int i = 0; i < len; ++i) {
+                const uint64_t win = rec_window(w0, hi, i);
+                const uint64_t kmer = win >> (64 - 2 * k);
+                if (cur_mask && (sub_hash(kmer) & cur_mask) != cur_val) continue;
+                const bool has_succ = (i < len - 1) || hs;
+                const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
+                const uint64_t stamp = i ? ((st0 | 1ull) + 2ull * i) : st0;
+                uint32_t slot = slot_hash(kmer) & (CAP - 1);
+                bool ok = false;
+                for (int probe = 0; probe < CAP; ++probe) {
+                    unsigned long long cur = s.keys[slot];
+                    if (cur == EMPTY_KEY) {
+                        cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
+                        if (cur == EMPTY_KEY) {
+                            cur = kmer;
+                            if (atomicAdd(&s.n_distinct, 1u) >= LIMIT) s.overflow = 1;
+                        }
+                    }
+                    if (cur == kmer) { ok = true; break; }
+                    slot = (slot + 1) & (CAP - 1);
+                }
+                if (!ok) { s.overflow = 1; break; }
+                if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], 1u);
+                atomicMin(&s.stamp[slot], (ST)stamp);
+            }
+        }
+        __syncthreads();
+        if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
+            if (threadIdx.x == 0) {
+                const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
+                if (s.stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
+                    atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
+                } else {
+                    s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val; ++s.stk_n;
+                    s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val | bit; ++s.stk_n;
+                }
+            }
+            continue;
+        }
+        // ---- local node ids
+        for (int i = threadIdx.x; i < CAP; i += 256)
+            if (s.keys[i] != EMPTY_KEY) s.idx[i] = (uint16_t)atomicAdd(&s.n_local, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long base = atomicAdd(&out.scalars[4], (unsigned long long)s.n_local);
+            s.gbase = base;
+            if (base + s.n_local > out.node_cap) {
+                atomicOr(&out.scalars[0], 16ull);
+                s.overflow = 1;
+            } else {
+                const unsigned long long ri = atomicAdd(&out.scalars[6], 1ull);
+                if (ri < out.range_cap) {
+                    SkRange rg;
+                    rg.bucket = bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = s.n_local; rg.node_base = base;
+                    out.ranges[ri] = rg;
+                } else {
+                    atomicOr(&out.scalars[0], 32ull);
+                }
+            }
+        }
+        __syncthreads();
+        if (s.overflow) return;
+        const uint64_t gbase = s.gbase;
+        // ---- write nodes, resolve in-bucket successors, stage the others as queries
+        for (int i = threadIdx.x; i < CAP; i += 256) {
+            const unsigned long long key = s.keys[i];
+            if (key == EMPTY_KEY) continue;
+            const uint64_t node = gbase + s.idx[i];
+            const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
+            const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+            const uint64_t stamp = (uint64_t)s.stamp[i];
+            out.keys[node] = key;
+            out.stamps[node] = stamp;
+            reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
+            out.flags[node] = (uint8_t)(stamp & 1);
+            uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
+#pragma unroll
+            for (int a = 1; a < 4; ++a) {
+#pragma unroll
+                for (int b = a; b > 0; --b) {
+                    if (c[code[b]] > c[code[b - 1]]) { uint32_t t = code[b]; code[b] = code[b - 1]; code[b - 1] = t; }
+                }
+            }
+            out.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
+            uint32_t sc[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                sc[b] = NO_NODE;
+                if (!c[b]) continue;
+                const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
+                const int f = lds_find<CAP>(s.keys, skey);
+                if (f >= 0) {
+                    sc[b] = (uint32_t)(gbase + s.idx[f]);
+                } else {
+                    const unsigned long long meta = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
+                    const uint32_t qi = atomicAdd(&s.n_q, 1u);
+                    if (qi < CNT_QBUF) {
+                        s.q_key[qi] = skey;
+                        s.q_meta[qi] = meta;
+                    } else {  // staging full: append directly
+                        const unsigned long long g = atomicAdd(&out.scalars[5], 1ull);
+                        if (g < out.q_cap) { out.q_key[g] = skey; out.q_meta[g] = meta; }
+                        else atomicOr(&out.scalars[0], 64ull);
+                    }
+                }
+            }
+            reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+        }
+        __syncthreads();
+        const uint32_t nq = min(s.n_q, (uint32_t)CNT_QBUF);
+        if (threadIdx.x == 0 && nq) s.qbase = atomicAdd(&out.scalars[5], (unsigned long long)nq);
+        __syncthreads();
+        if (nq) {
+            const unsigned long long qb = s.qbase;
+            if (qb + nq > out.q_cap) {
+                if (threadIdx.x == 0) atomicOr(&out.scalars[0], 64ull);
+            } else {
+                for (uint32_t i = threadIdx.x; i < nq; i += 256) {
+                    out.q_key[qb + i] = s.q_key[i];
+                    out.q_meta[qb + i] = s.q_meta[i];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: answer the cross-bucket successor queries of one counted range
+// ------------------------------------------------------------------------------------------------
+template <int CAP>
+struct AnsLds {
+    unsigned long long keys[CAP];
+    uint16_t idx[CAP];
+};
+
+template <int CAP>
+__global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ q_start,
+                                                  const uint64_t *__restrict__ q_cnt, const uint64_t *__restrict__ q_key,
+                                                  const uint64_t *__restrict__ q_meta, const uint64_t *__restrict__ keys,
+                                                  uint32_t *succ, unsigned long long *scalars) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ans_raw[];
+    AnsLds<CAP> &s = *reinterpret_cast<AnsLds<CAP> *>(ans_raw);
+    const SkRange rg = ranges[blockIdx.x];
+    const uint64_t qn = q_cnt[rg.bucket];
+    if (qn == 0) return;
+    for (int i = threadIdx.x; i < CAP; i += 256) s.keys[i] = EMPTY_KEY;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < rg.node_cnt; i += 256) {
+        const unsigned long long key = keys[rg.node_base + i];
+        uint32_t slot = slot_hash(key) & (CAP - 1);
+        for (int probe = 0; probe < CAP; ++probe) {
+            const unsigned long long cur = atomicCAS(&s.keys[slot], EMPTY_KEY, key);
+            if (cur == EMPTY_KEY) { s.idx[slot] = (uint16_t)i; break; }
+            slot = (slot + 1) & (CAP - 1);
+        }
+    }
+    __syncthreads();
+    const uint64_t qb = q_start[rg.bucket];
+    for (uint64_t i = threadIdx.x; i < qn; i += 256) {
+        const uint64_t skey = q_key[qb + i];
+        if (rg.mask && (sub_hash(skey) & rg.mask) != rg.val) continue;
+        const int f = lds_find<CAP>(s.keys, skey);
+        if (f < 0) { atomicOr(&scalars[0], 128ull); continue; }  // every successor exists as a node
+        succ[q_meta[qb + i] & ((1ull << 40) - 1)] = (uint32_t)(rg.node_base + s.idx[f]);
+    }
+}
+
+}  // namespace dbgk

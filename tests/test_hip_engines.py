@@ -1,0 +1,109 @@
+"""Node table / successor parity of the two build engines and the C oracle (GPU, through the C ABI).
+
+engine 0: super-k-mer partitioned build (default); engine 1: single global hash table.
+Bucket geometries are forced so that the one- and two-level multisplit paths and the LDS
+overflow split (a bucket that does not fit the table) are all exercised at test sizes.
+"""
+import numpy as np
+import pytest
+
+import _dbg
+import synth
+from oracle import orc_c
+
+pytestmark = pytest.mark.gpu
+
+
+def table(g, k):
+    keys, stamps, counts, flags = g.export_nodes()
+    succ = g.export_succ()
+    o = np.argsort(stamps, kind="stable")
+    return keys[o], stamps[o], counts[o], flags[o], succ, keys
+
+
+def check_succ(keys_raw, counts_raw, succ, k):
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for code in range(4):
+        has = counts_raw[:, code] != 0
+        assert np.all(succ[~has, code] == _dbg.NO_NODE)
+        assert np.all(succ[has, code] != _dbg.NO_NODE), "unresolved successor"
+        want = ((keys_raw[has] << np.uint64(2)) | np.uint64(code)) & mask
+        assert np.array_equal(keys_raw[succ[has, code]], want)
+
+
+def build(reads2d, k, **opts):
+    g = _dbg.Graph()
+    for name, v in opts.items():
+        g.set_option(name, v)
+    L = reads2d.shape[1]
+    g.set_reads(reads2d.reshape(-1), np.arange(0, reads2d.size + 1, L, dtype=np.uint64))
+    g.build(k)
+    return g
+
+
+@pytest.mark.parametrize("k", [5, 13, 21, 31])
+@pytest.mark.parametrize("opts", [
+    dict(engine=1),
+    dict(engine=0),
+    dict(engine=0, bucket_bits=3),
+    dict(engine=0, bucket_bits=9),
+    dict(engine=0, bucket_bits=12, lds_slots=2048),
+    dict(engine=0, bucket_bits=18),
+    dict(engine=0, bucket_bits=1, lds_slots=2048),   # forces LDS overflow splits
+])
+def test_engine_matches_c_oracle(k, opts):
+    reads = synth.reads_ascii(7, 60000, 6000, 100, 0.01)
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64), k)
+    g = build(reads, k, **opts)
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == want["n_kmer_instances"]
+    assert sz["n_edge_instances"] == want["n_edge_instances"]
+    assert sz["n_nodes"] == want["n_nodes"]
+    keys, stamps, counts, flags, succ, keys_raw = table(g, k)
+    assert np.array_equal(keys, want["keys"])
+    assert np.array_equal(stamps, want["stamps"])
+    assert np.array_equal(counts, want["counts"])
+    assert np.array_equal(flags & 1, (want["stamps"] & np.uint64(1)).astype(np.uint8))
+    _, _, counts_raw, _ = g.export_nodes()
+    check_succ(keys_raw, counts_raw, succ, k)
+    rp, col, cnt = g.export_csr()
+    assert int(rp[-1]) == sz["n_edges"] == int((counts_raw != 0).sum())
+    assert np.array_equal(col, succ[counts_raw != 0]) and np.array_equal(cnt, counts_raw[counts_raw != 0])
+
+
+def test_ragged_reads_and_boundaries():
+    """Variable-length reads (including len <= k and empty) packed back to back."""
+    rng = np.random.default_rng(5)
+    genome = synth.reads_ascii(9, 5000, 1, 5000, 0.0)[0]
+    reads, lens = [], []
+    for _ in range(3000):
+        L = int(rng.integers(0, 90))
+        s = int(rng.integers(0, 5000 - L + 1))
+        reads.append(genome[s:s + L])
+        lens.append(L)
+    blob = np.concatenate(reads) if reads else np.zeros(0, np.uint8)
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=off[1:])
+    for k in (4, 17, 31):
+        want = orc_c.build(blob, off, k)
+        for opts in (dict(engine=1), dict(engine=0), dict(engine=0, bucket_bits=7)):
+            g = _dbg.Graph()
+            for name, v in opts.items():
+                g.set_option(name, v)
+            g.set_reads(blob, off)
+            g.build(k)
+            keys, stamps, counts, flags, succ, keys_raw = table(g, k)
+            assert np.array_equal(keys, want["keys"]) and np.array_equal(stamps, want["stamps"])
+            assert np.array_equal(counts, want["counts"])
+            check_succ(keys_raw, g.export_nodes()[2], succ, k)
+
+
+def test_rebuild_on_same_handle_reuses_buffers():
+    reads = synth.reads_ascii(3, 30000, 3000, 100, 0.01)
+    g = build(reads, 21)
+    a = table(g, 21)
+    g.build(31)
+    g.build(21)
+    b = table(g, 21)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
