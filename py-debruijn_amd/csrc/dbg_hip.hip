@@ -88,7 +88,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][2], ar_node[6], ar_misc[8];
+    Buf ar_rec[2][3], ar_q[2][2], ar_node[6], ar_misc[8], ar_csr[3], ar_scan;
     // branch k-mer lookup (pull-out reads)
     uint64_t *d_btab = nullptr;
     uint64_t btab_cap = 0;
@@ -224,8 +224,8 @@ template <class F, class OutT>
 static int exclusive_scan(dbg *h, uint64_t n, F f, OutT *out, uint64_t *h_total) {
     uint64_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nblk == 0) nblk = 1;
-    uint64_t *partial = nullptr;
-    CHK(dev_alloc(h, &partial, nblk + 1));
+    CHK(buf_ensure(h, h->ar_scan, (nblk + 1) * 8));
+    uint64_t *partial = (uint64_t *)h->ar_scan.p;
     uint64_t *d_total = partial + nblk;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<F>), dim3((unsigned)nblk), dim3(256), 0, h->stream, n, f, partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, h->stream, partial, nblk, d_total);
@@ -233,7 +233,6 @@ static int exclusive_scan(dbg *h, uint64_t n, F f, OutT *out, uint64_t *h_total)
                        partial, out);
     hipError_t e = hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(partial);
     if (e != hipSuccess) {
         h->err = std::string("exclusive_scan: ") + hipGetErrorString(e);
         return DBG_E_HIP;
@@ -245,13 +244,12 @@ template <class F>
 static int reduce_sum(dbg *h, uint64_t n, F f, uint64_t *h_total) {
     uint64_t nblk = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (nblk == 0) nblk = 1;
-    uint64_t *partial = nullptr;
-    CHK(dev_alloc(h, &partial, nblk + 1));
+    CHK(buf_ensure(h, h->ar_scan, (nblk + 1) * 8));
+    uint64_t *partial = (uint64_t *)h->ar_scan.p;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_reduce<F>), dim3((unsigned)nblk), dim3(256), 0, h->stream, n, f, partial);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, h->stream, partial, nblk, partial + nblk);
     hipError_t e = hipMemcpyAsync(h_total, partial + nblk, 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(partial);
     if (e != hipSuccess) {
         h->err = std::string("reduce_sum: ") + hipGetErrorString(e);
         return DBG_E_HIP;
@@ -843,7 +841,8 @@ static void free_build(dbg *h) {
     dev_free(h->d_btab);
     h->btab_cap = 0;
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
-    dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_rowptr); dev_free(h->d_col); dev_free(h->d_ecnt);
+    dev_free(h->d_order); dev_free(h->d_succ);
+    h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
     dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
     dev_free(h->d_ctg_seq);
@@ -892,6 +891,8 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &lvl : h->ar_q) for (auto &b : lvl) buf_free(b);
     for (auto &b : h->ar_node) buf_free(b);
     for (auto &b : h->ar_misc) buf_free(b);
+    for (auto &b : h->ar_csr) buf_free(b);
+    buf_free(h->ar_scan);
     dev_free(h->d_scalars);
     (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1000,13 +1001,16 @@ static int build_sk(dbg *h, int k, uint64_t node_capacity_hint);
 static int finish_graph(dbg *h) {
     {
         Timer t(h->stream);
-        CHK(dev_alloc(h, &h->d_rowptr, h->n_nodes + 1));
+        CHK(buf_ensure(h, h->ar_csr[0], (h->n_nodes + 1) * 8));
+        h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
         uint64_t total = 0;
         CHK(exclusive_scan(h, h->n_nodes, DegOf{h->d_cnt}, h->d_rowptr, &total));
         h->n_edges = total;
         HIPCHK(h, hipMemcpyAsync(h->d_rowptr + h->n_nodes, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
-        CHK(dev_alloc(h, &h->d_col, total));
-        CHK(dev_alloc(h, &h->d_ecnt, total));
+        CHK(buf_ensure(h, h->ar_csr[1], total * 4));
+        CHK(buf_ensure(h, h->ar_csr[2], total * 4));
+        h->d_col = (uint32_t *)h->ar_csr[1].p;
+        h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
         if (h->n_nodes) {
             hipLaunchKernelGGL(k_csr_fill, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                                h->d_rowptr, h->d_cnt, h->d_succ, h->d_col, h->d_ecnt);
@@ -1419,19 +1423,19 @@ struct CeilDiv {
     __device__ uint64_t operator()(uint64_t i) const { return (cnt[i] + d - 1) / d; }
 };
 
-// One multisplit level: parents (p_start/p_cnt, device) -> children (c_start/c_cnt, device,
-// n_parents * nb entries), records moved from in_* to out_*.
+// One multisplit level: segments (p_start/p_cnt, device) -> children (c_start/c_cnt, device,
+// n_groups * nb entries), records moved from in_* to out_*.
 template <class ST, bool HAS_ST>
-static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_cnt, uint32_t n_parents, uint64_t total,
-                            const uint64_t *in_w0, const uint64_t *in_w1, const ST *in_st, uint64_t *out_w0,
-                            uint64_t *out_w1, ST *out_st, int shift, int nb, uint64_t *c_start, uint64_t *c_cnt,
-                            dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs) {
-    CHK(buf_ensure(h, b_scpre, (uint64_t)(n_parents + 1) * 8));
+static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_cnt, uint32_t n_seg, bool one_group,
+                            uint64_t total, const uint64_t *in_w0, const uint64_t *in_w1, const ST *in_st,
+                            uint64_t *out_w0, uint64_t *out_w1, ST *out_st, int shift, int nb, uint64_t *c_start,
+                            uint64_t *c_cnt, dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs) {
+    CHK(buf_ensure(h, b_scpre, (uint64_t)(n_seg + 1) * 8));
     uint64_t *sc_pre = (uint64_t *)b_scpre.p;
     uint64_t nsc = 0;
-    CHK(exclusive_scan(h, n_parents, CeilDiv{p_cnt, (uint64_t)MS_SC}, sc_pre, &nsc));
-    HIPCHK(h, hipMemcpyAsync(sc_pre + n_parents, &nsc, 8, hipMemcpyHostToDevice, h->stream));
-    MsParents P{p_start, p_cnt, sc_pre, n_parents};
+    CHK(exclusive_scan(h, n_seg, CeilDiv{p_cnt, (uint64_t)MS_SC}, sc_pre, &nsc));
+    HIPCHK(h, hipMemcpyAsync(sc_pre + n_seg, &nsc, 8, hipMemcpyHostToDevice, h->stream));
+    MsParents P{p_start, p_cnt, sc_pre, n_seg, one_group ? 1u : 0u};
     const uint64_t n_log = nsc * (uint64_t)nb;
     CHK(buf_ensure(h, b_cmat, n_log * 4));
     CHK(buf_ensure(h, b_offs, n_log * 8));
@@ -1444,7 +1448,7 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
         CHK(exclusive_scan(h, n_log, MsLogical{P, cmat, nb}, offs, &tot));
         if (tot != total) { h->err = "multisplit: histogram total mismatch"; return DBG_E_HIP; }
     }
-    const uint64_t n_child = (uint64_t)n_parents * nb;
+    const uint64_t n_child = (uint64_t)(one_group ? 1 : n_seg) * nb;
     hipLaunchKernelGGL(k_ms_children, dim3(grid_for(n_child, 256)), dim3(256), 0, h->stream, P, offs, nb, total, c_start,
                        c_cnt);
     if (nsc) {
@@ -1458,51 +1462,37 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
     return DBG_OK;
 }
 
-// Two-level split of `total` records by the top (l1 + l2) bits of the 22-bit bucket hash that sits
-// at bit `field_lo` of w1.  On return the records are in set `*where` (0 or 1) of the ping-pong
-// buffers and final_start/final_cnt (2^(l1+l2) entries) describe the buckets.
+// Two-level split of the records in the given segments by the top (l1 + l2) bits of the 22-bit
+// bucket hash that sits at bit `field_lo` of w1.  Level 1 always runs (with l1 == 0 it only
+// compacts the segments into one range).  On return the records are in set `*where` of the
+// ping-pong buffers and final_start/final_cnt (2^(l1+l2) entries) describe the buckets.
 template <class ST, bool HAS_ST>
-static int multisplit_two_level(dbg *h, uint64_t total, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], int field_lo, int l1,
+static int multisplit_two_level(dbg *h, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
+                                uint64_t total, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], int field_lo, int l1,
                                 int l2, uint64_t *final_start, uint64_t *final_cnt, int *where) {
-    // level-0 parent: the whole array
-    CHK(buf_ensure(h, h->ar_misc[0], 16));
-    uint64_t root[2] = {0, total};
-    HIPCHK(h, hipMemcpyAsync(h->ar_misc[0].p, root, 16, hipMemcpyHostToDevice, h->stream));
-    const uint64_t *p_start = (const uint64_t *)h->ar_misc[0].p, *p_cnt = p_start + 1;
-    uint32_t n_parents = 1;
     int cur = 0;
     const int top = field_lo + SK_BUCKET_BITS;
-    if (l1 > 0) {
-        const int nb = 1 << l1;
-        uint64_t *cs, *cc;
-        if (l2 > 0) {
-            CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb * 16));
-            cs = (uint64_t *)h->ar_misc[1].p;
-            cc = cs + nb;
-        } else {
-            cs = final_start;
-            cc = final_cnt;
-        }
-        CHK((multisplit_level<ST, HAS_ST>(h, p_start, p_cnt, n_parents, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
-                                           w1[cur ^ 1], st[cur ^ 1], top - l1, nb, cs, cc, h->ar_misc[2], h->ar_misc[3],
-                                           h->ar_misc[4])));
-        cur ^= 1;
-        p_start = cs;
-        p_cnt = cc;
-        n_parents = nb;
+    const int nb1 = 1 << l1;
+    uint64_t *cs, *cc;
+    if (l2 > 0) {
+        CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+        cs = (uint64_t *)h->ar_misc[1].p;
+        cc = cs + nb1;
+    } else {
+        cs = final_start;
+        cc = final_cnt;
     }
+    CHK((multisplit_level<ST, HAS_ST>(h, seg_start, seg_cnt, n_seg, true, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
+                                       w1[cur ^ 1], st[cur ^ 1], top - l1, nb1, cs, cc, h->ar_misc[2], h->ar_misc[3],
+                                       h->ar_misc[4])));
+    cur ^= 1;
     if (l2 > 0) {
         const int nb = 1 << l2;
-        CHK((multisplit_level<ST, HAS_ST>(h, p_start, p_cnt, n_parents, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
+        CHK((multisplit_level<ST, HAS_ST>(h, cs, cc, (uint32_t)nb1, false, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
                                            w1[cur ^ 1], st[cur ^ 1], top - l1 - l2, nb, final_start, final_cnt,
                                            h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
         cur ^= 1;
     }
-    if (l1 == 0 && l2 == 0) {
-        HIPCHK(h, hipMemcpyAsync(final_start, root, 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(final_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // `root` lives on this stack frame
     *where = cur;
     return DBG_OK;
 }
@@ -1515,11 +1505,19 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     uint64_t sc[8] = {0};
     uint64_t *w0[2], *w1[2];
     ST *st[2];
-    // ---- K1: extraction
+    // ---- K1: extraction into one private segment per persistent workgroup
+    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 2048);
+    CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
+    uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg,
+             *seg_ne = seg_nk + n_wg;
+    std::vector<uint64_t> hseg((size_t)n_wg * 4);
+    uint64_t n_rec = 0;
     {
         Timer t(h->stream);
-        uint64_t rec_cap = (w == 1) ? h->n_bytes + 64 : h->n_bytes / 3 + tiles * 8 + 1024;
+        const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
+        uint64_t seg_cap = (w == 1) ? tiles_per_wg * TILE : tiles_per_wg * (TILE / 3 + 8) + 256;
         for (int attempt = 0; attempt < 2; ++attempt) {
+            const uint64_t rec_cap = seg_cap * n_wg;
             for (int set = 0; set < 2; ++set) {
                 CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
                 CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
@@ -1528,25 +1526,32 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
                 w1[set] = (uint64_t *)h->ar_rec[set][1].p;
                 st[set] = (ST *)h->ar_rec[set][2].p;
             }
+            for (uint32_t g = 0; g < n_wg; ++g) hseg[g] = (uint64_t)g * seg_cap;
+            HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
             if (tiles) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3((unsigned)tiles), dim3(256), 0, h->stream,
-                                   h->d_bases, h->n_bytes, h->d_startbits, k, m, w0[0], w1[0], st[0], rec_cap, sc_dev);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases,
+                                   h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk,
+                                   seg_ne, sc_dev);
                 HIPCHK(h, hipGetLastError());
             }
-            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
             if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
             if (!(sc[0] & 4)) break;
             if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
-            rec_cap = h->n_bytes + 64;
+            seg_cap = tiles_per_wg * TILE;  // one record per position: cannot overflow
         }
-        h->stats.ms_startbits += 0;
+        h->n_kmer_inst = h->n_edge_inst = 0;
+        for (uint32_t g = 0; g < n_wg; ++g) {
+            n_rec += hseg[n_wg + g];
+            h->n_kmer_inst += hseg[2 * n_wg + g];
+            h->n_edge_inst += hseg[3 * n_wg + g];
+        }
         h->stats.ms_table_init = t.stop();  // phase slot re-used: extraction time
     }
-    h->n_kmer_inst = sc[1];
-    h->n_edge_inst = sc[2];
-    const uint64_t n_rec = sc[3];
 
     // ---- bucket geometry
     int T = h->bucket_bits;
@@ -1563,7 +1568,8 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     int where = 0;
     {
         Timer t(h->stream);
-        CHK((multisplit_two_level<ST, true>(h, n_rec, w0, w1, st, 6, l1, l2, b_start, b_cnt, &where)));
+        CHK((multisplit_two_level<ST, true>(h, seg_start, seg_cnt, n_wg, n_rec, w0, w1, st, 6, l1, l2, b_start, b_cnt,
+                                            &where)));
         h->stats.ms_compact = t.stop();  // phase slot re-used: partition time
     }
 
@@ -1585,7 +1591,7 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     h->nodes_in_arena = true;
     uint64_t q_cap = n_rec + 1024;
     uint64_t *qk[2], *qm[2];
-    const uint64_t range_cap = n_buckets * 2 + 4096 + h->n_kmer_inst / (CAP / 4);
+    const uint64_t range_cap = n_buckets + 4096 + h->n_kmer_inst / (CAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1596,16 +1602,16 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
             qm[set] = (uint64_t *)h->ar_q[set][1].p;
         }
         Timer t(h->stream);
-        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-        HIPCHK(h, hipMemsetAsync(h->d_scalars + 4, 0, 24, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
         SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_succ, node_cap,
-                       qk[0], qm[0], q_cap, ranges, range_cap, sc_dev};
+                       qk[0], qm[0], q_cap, ranges, n_buckets, range_cap, sc_dev};
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n_rec) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)n_buckets), dim3(256), lds, h->stream, b_start, b_cnt, w0[where],
-                               w1[where], st[where], k, m, 0, out);
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_buckets), dim3(CNT_NT), lds, h->stream, b_start, b_cnt, w0[where],
+                               w1[where], st[where], k, m, out);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? 1 : 0;
@@ -1613,24 +1619,33 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         h->stats.ms_count = t.stop();
         // buckets that had to be split by hash sub-range turn in-bucket successors into queries:
         // the usual bound (one query per record) no longer holds, retry with the safe one
-        if ((sc[0] & 64) && attempt == 0) { q_cap = h->n_edge_inst + 1024; continue; }
+        if ((sc[0] & 64) && !(sc[0] & (8 | 16 | 32)) && attempt == 0) { q_cap = h->n_edge_inst + 1024; continue; }
         break;
     }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node capacity exceeded"; return DBG_E_CAPACITY; }
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
-    h->n_nodes = sc[4];
-    const uint64_t n_q = sc[5], n_ranges = sc[6];
+    h->n_nodes = sc[4] & 0xFFFFFFFFull;
+    const uint64_t n_q = sc[4] >> 32, n_ranges = n_buckets + sc[6];
 
     // ---- K6-K8: successors that live in another bucket
     {
         Timer t(h->stream);
         if (n_q) {
-            CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16));
+            CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 16));
             uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets;
+            uint64_t *q_seg = q_cnt + n_buckets;  // one input segment: [0, n_q)
+            const uint64_t root[2] = {0, n_q};
+            HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
             uint32_t *dummy[2] = {nullptr, nullptr};
             int qwhere = 0;
-            CHK((multisplit_two_level<uint32_t, false>(h, n_q, qk, qm, dummy, 40, l1, l2, q_start, q_cnt, &qwhere)));
+            if (T > 0) {
+                CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n_q, qk, qm, dummy, 40, l1, l2, q_start,
+                                                           q_cnt, &qwhere)));
+            } else {
+                HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
+                HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
+            }
             auto kern = k_q_answer<CAP>;
             const size_t lds = sizeof(AnsLds<CAP>);
             HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1648,7 +1663,8 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
 
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint) {
     const bool small = (h->n_bytes < (1ull << 31));
-    if (h->lds_slots == 2048)
-        return small ? build_sk_t<uint32_t, 2048>(h, k, node_capacity_hint) : build_sk_t<uint64_t, 2048>(h, k, node_capacity_hint);
-    return small ? build_sk_t<uint32_t, 4096>(h, k, node_capacity_hint) : build_sk_t<uint64_t, 4096>(h, k, node_capacity_hint);
+    // 64-bit stamps (inputs of 2 GiB and more) only fit the 160 KiB LDS with the 2048-slot table
+    if (!small) return build_sk_t<uint64_t, 2048>(h, k, node_capacity_hint);
+    if (h->lds_slots == 2048) return build_sk_t<uint32_t, 2048>(h, k, node_capacity_hint);
+    return build_sk_t<uint32_t, 4096>(h, k, node_capacity_hint);
 }

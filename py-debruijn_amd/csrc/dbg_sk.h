@@ -25,20 +25,24 @@ constexpr int SK_META_BITS = 28;
 
 __host__ __device__ inline int sk_m_for_k(int k) { return k < SK_MAX_M ? k : SK_MAX_M; }
 
-__device__ inline uint32_t mmer_hash32(uint64_t mmer) { return (uint32_t)(mix64(mmer + 0x51ED270B7F4A7C15ull) >> 32); }
-__device__ inline uint32_t bucket_hash22(uint64_t mmer) {
-    return (uint32_t)(mix64(mmer * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull) >> (64 - SK_BUCKET_BITS));
+__host__ __device__ inline uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
 }
+// m <= 13: an m-mer is at most 26 bits.  Minimizer order = 16-bit hash, ties to the leftmost.
+__device__ inline uint32_t mmer_hash16(uint32_t mmer) { return fmix32(mmer ^ 0x3C6EF372u) >> 16; }
+__device__ inline uint32_t bucket_hash22(uint32_t mmer) { return fmix32(mmer * 0x9E3779B1u + 0x7F4A7C15u) >> (32 - SK_BUCKET_BITS); }
 
 // minimizer-hash bucket of a single packed k-mer (pure function of the k-mer)
 __device__ inline uint32_t kmer_bucket22(uint64_t kmer, int k, int m) {
     const int w = k - m + 1;
-    const uint64_t mmask = (1ull << (2 * m)) - 1;
-    uint32_t best = 0xFFFFFFFFu;
-    uint64_t best_mm = 0;
+    const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
+    uint32_t best = 0xFFFFFFFFu, best_mm = 0;
     for (int i = 0; i < w; ++i) {
-        const uint64_t mm = (kmer >> (2 * (k - m - i))) & mmask;
-        const uint32_t hv = mmer_hash32(mm);
+        const uint32_t mm = (uint32_t)(kmer >> (2 * (k - m - i))) & mmask;
+        const uint32_t hv = mmer_hash16(mm);
         if (hv < best) { best = hv; best_mm = mm; }
     }
     return bucket_hash22(best_mm);
@@ -49,102 +53,108 @@ __device__ inline uint32_t kmer_bucket22(uint64_t kmer, int k, int m) {
 // ------------------------------------------------------------------------------------------------
 struct SkLds {
     TileLds t;
-    uint32_t hm[TILE + HALO];       // m-mer hash per position
-    uint16_t minp[TILE];            // minimizer position (tile-relative) per k-mer position, 0xFFFF = no k-mer
+    uint16_t hm[TILE + HALO];       // 16-bit m-mer hash per position
+    uint8_t minp[TILE];             // minimizer offset (0..w-1) from the k-mer position, 0xFF = no k-mer
     unsigned long long sbits[TILE / 64 + 1];  // record starts
     unsigned long long vbits[TILE / 64 + 1];  // valid k-mer positions
     uint32_t wpre[TILE / 64 + 1];   // exclusive prefix of popcount(sbits)
     uint32_t nrec;
-    unsigned long long gbase;
 };
 
+// Persistent workgroups: workgroup g owns the tiles [g*T/G, (g+1)*T/G) and writes its records to its
+// own segment [g*seg_cap, ...) of the record arrays -- no global atomics (a shared cursor would put
+// one same-address atomic per tile on the critical path, ~12 ns each, serialised chip-wide).
 template <class ST>
 __global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bases, uint64_t n_bytes,
                                                     const uint32_t *__restrict__ startbits, int k, int m,
-                                                    uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t rec_cap,
-                                                    unsigned long long *scalars /* [0] err [1] N_k [2] N_e [3] n_rec */) {
+                                                    uint64_t n_tiles, uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st,
+                                                    uint64_t seg_cap, uint64_t *seg_cnt, uint64_t *seg_nk,
+                                                    uint64_t *seg_ne, unsigned long long *scalars /* [0] err */) {
     __shared__ SkLds s;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
-    const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
-    if (bad) atomicOr(&scalars[0], 1ull);
-    __syncthreads();
+    __shared__ uint64_t red[8];
+    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
+    uint64_t cursor = 0;  // records written by this workgroup (uniform)
     const int w = k - m + 1;
-    for (int j = threadIdx.x; j < TILE + HALO - 32; j += 256)
-        s.hm[j] = mmer_hash32(window32(s.t, j) >> (64 - 2 * m));
-    __syncthreads();
-
     const uint32_t mid_mask = (k >= 2) ? ((1u << (k - 1)) - 1u) : 0u;
     uint64_t n_k = 0, n_e = 0;
-    for (int j0 = 0; j0 < TILE; j0 += 256) {
-        const int j = j0 + threadIdx.x;
-        const uint64_t p = tile0 + j;
-        bool v = false;
-        uint32_t mp = 0xFFFFu;
-        if (p < n_bytes) {
-            const uint32_t sw = startwin32(s.t, j);
-            const uint32_t s0 = sw & 1u, sk = (sw >> k) & 1u;
-            v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0);
-            if (v) {
-                n_k += 1;
-                n_e += sk ^ 1u;
-                uint32_t best = s.hm[j];
-                mp = j;
-                for (int i = 1; i < w; ++i) {
-                    const uint32_t hv = s.hm[j + i];
-                    if (hv < best) { best = hv; mp = j + i; }
+    bool overflow = false;
+    for (uint64_t tile = t_beg; tile < t_end; ++tile) {
+        const uint64_t tile0 = tile * TILE;
+        __syncthreads();  // LDS of the previous tile is free
+        const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
+        if (bad) atomicOr(&scalars[0], 1ull);
+        __syncthreads();
+        for (int j = threadIdx.x; j < TILE + HALO - 32; j += 256)
+            s.hm[j] = (uint16_t)mmer_hash16((uint32_t)(window32(s.t, j) >> (64 - 2 * m)));
+        __syncthreads();
+        for (int j0 = 0; j0 < TILE; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            const uint64_t p = tile0 + j;
+            bool v = false;
+            uint32_t mp = 0xFFu;
+            if (p < n_bytes) {
+                const uint32_t sw = startwin32(s.t, j);
+                const uint32_t s0 = sw & 1u, sk = (sw >> k) & 1u;
+                v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0);
+                if (v) {
+                    n_k += 1;
+                    n_e += sk ^ 1u;
+                    uint32_t best = s.hm[j];
+                    mp = 0;
+                    for (int i = 1; i < w; ++i) {
+                        const uint32_t hv = s.hm[j + i];
+                        if (hv < best) { best = hv; mp = i; }
+                    }
                 }
             }
+            s.minp[j] = (uint8_t)mp;
+            const unsigned long long vb = __ballot(v);
+            if ((threadIdx.x & 63) == 0) s.vbits[j >> 6] = vb;
         }
-        s.minp[j] = (uint16_t)mp;
-        const unsigned long long vb = __ballot(v);
-        if ((threadIdx.x & 63) == 0) s.vbits[j >> 6] = vb;
-    }
-    __syncthreads();
-    for (int j0 = 0; j0 < TILE; j0 += 256) {
-        const int j = j0 + threadIdx.x;
-        const uint32_t mp = s.minp[j];
-        const bool st = (mp != 0xFFFFu) && (j == 0 || s.minp[j - 1] != mp);
-        const unsigned long long sb = __ballot(st);
-        if ((threadIdx.x & 63) == 0) s.sbits[j >> 6] = sb;
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive prefix of per-word record counts (128 words, one wave)
-        uint32_t a = __popcll(s.sbits[threadIdx.x]), b = __popcll(s.sbits[threadIdx.x + 64]);
-        uint32_t ia = a, ib = b;
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
-            if ((int)threadIdx.x >= d) { ia += oa; ib += ob; }
+        __syncthreads();
+        for (int j0 = 0; j0 < TILE; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            const uint32_t mp = s.minp[j];
+            // same minimizer occurrence as the previous k-mer <=> offset one larger there
+            const bool st = (mp != 0xFFu) && (j == 0 || (uint32_t)s.minp[j - 1] != mp + 1);
+            const unsigned long long sb = __ballot(st);
+            if ((threadIdx.x & 63) == 0) s.sbits[j >> 6] = sb;
         }
-        const uint32_t tot_a = __shfl(ia, 63, 64);
-        s.wpre[threadIdx.x] = ia - a;
-        s.wpre[threadIdx.x + 64] = tot_a + ib - b;
-        if (threadIdx.x == 63) {
-            const uint32_t n = tot_a + ib;
-            s.nrec = n;
-            s.gbase = n ? atomicAdd(&scalars[3], (unsigned long long)n) : 0ull;
+        __syncthreads();
+        if (threadIdx.x < 64) {  // exclusive prefix of per-word record counts (128 words, one wave)
+            uint32_t a = __popcll(s.sbits[threadIdx.x]), b = __popcll(s.sbits[threadIdx.x + 64]);
+            uint32_t ia = a, ib = b;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+                if ((int)threadIdx.x >= d) { ia += oa; ib += ob; }
+            }
+            const uint32_t tot_a = __shfl(ia, 63, 64);
+            s.wpre[threadIdx.x] = ia - a;
+            s.wpre[threadIdx.x + 64] = tot_a + ib - b;
+            if (threadIdx.x == 63) s.nrec = tot_a + ib;
+            if (threadIdx.x == 0) { s.sbits[TILE / 64] = 0; s.vbits[TILE / 64] = 0; }
         }
-        if (threadIdx.x == 0) { s.sbits[TILE / 64] = 0; s.vbits[TILE / 64] = 0; }
-    }
-    __syncthreads();
-    const uint64_t gbase = s.gbase;
-    if (gbase + s.nrec > rec_cap) {
-        if (threadIdx.x == 0) atomicOr(&scalars[0], 4ull);  // record buffer too small: caller retries
-    } else {
+        __syncthreads();
+        const uint32_t nrec = s.nrec;
+        if (cursor + nrec > seg_cap) { overflow = true; break; }  // uniform: caller retries with a larger segment
+        const uint64_t gbase = seg0 + cursor;
+        cursor += nrec;
         for (int j0 = 0; j0 < TILE; j0 += 256) {
             const int j = j0 + threadIdx.x;
             const int wd = j >> 6, bt = j & 63;
             const unsigned long long sb = s.sbits[wd];
             if (!((sb >> bt) & 1ull)) continue;
             // run length: up to the next record start or the first position without a k-mer
-            unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
-            unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
+            const unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
+            const unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
             const int room = 63 - bt;  // positions after j inside this word
-            unsigned long long stop = nxt_s | nxt_i;
+            const unsigned long long stop = nxt_s | nxt_i;
             int len;
             if (stop) {
                 len = 1 + (__ffsll((unsigned long long)stop) - 1);
             } else {
-                const unsigned long long stop2 = s.sbits[wd + 1] | ~s.vbits[wd + 1];  // next word (sentinel word: all stop)
+                const unsigned long long stop2 = s.sbits[wd + 1] | ~s.vbits[wd + 1];  // sentinel word: all stop
                 len = 1 + room + (__ffsll((unsigned long long)stop2) - 1);
             }
             if (j + len > TILE) len = TILE - j;
@@ -158,8 +168,8 @@ __global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bas
             if (nb < 32) { w0 &= ~0ull << (64 - 2 * nb); hi = 0; }
             else if (nb == 32) hi = 0;
             else hi &= ~0ull << (64 - 2 * (nb - 32));
-            const uint32_t mp = s.minp[j];
-            const uint32_t bh = bucket_hash22(window32(s.t, mp) >> (64 - 2 * m));
+            const uint32_t mp = j + s.minp[j];
+            const uint32_t bh = bucket_hash22((uint32_t)(window32(s.t, mp) >> (64 - 2 * m)));
             const uint64_t w1 = (hi & (~0ull << SK_META_BITS)) | ((uint64_t)bh << 6) | ((uint64_t)(len - 1) << 1) | has_succ;
             const uint64_t o = gbase + s.wpre[wd] + __popcll(sb & ((1ull << bt) - 1));
             rec_w0[o] = w0;
@@ -167,11 +177,16 @@ __global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bas
             rec_st[o] = (ST)((p << 1) | (s0 ^ 1u));
         }
     }
+    if (overflow && threadIdx.x == 0) atomicOr(&scalars[0], 4ull);
     n_k = wave_sum_u64(n_k);
     n_e = wave_sum_u64(n_e);
-    if ((threadIdx.x & 63) == 0) {
-        if (n_k) atomicAdd(&scalars[1], (unsigned long long)n_k);
-        if (n_e) atomicAdd(&scalars[2], (unsigned long long)n_e);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = n_k; red[4 + (threadIdx.x >> 6)] = n_e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        seg_cnt[blockIdx.x] = cursor;
+        seg_nk[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        seg_ne[blockIdx.x] = red[4] + red[5] + red[6] + red[7];
     }
 }
 
@@ -184,48 +199,57 @@ constexpr int MS_CH = 4096;           // records sorted per LDS round
 constexpr int MS_SC = 8 * MS_CH;      // records per super-chunk
 constexpr int MS_MAX_NB = 512;
 
+// Input of one multisplit level: `n_seg` contiguous segments of the record arrays.  Either all
+// segments form ONE group (level 1: the per-workgroup output segments of k_sk_extract) or every
+// segment is its own group (level 2: the children of level 1).  A group is split into nb
+// children that are laid out contiguously, groups in order.
 struct MsParents {
-    const uint64_t *start;    // [n_parents]
-    const uint64_t *cnt;      // [n_parents]
-    const uint64_t *sc_pre;   // [n_parents + 1] super-chunks before parent i
-    uint32_t n_parents;
+    const uint64_t *start;    // [n_seg]
+    const uint64_t *cnt;      // [n_seg]
+    const uint64_t *sc_pre;   // [n_seg + 1] super-chunks before segment i
+    uint32_t n_seg;
+    uint32_t one_group;       // 1: all segments belong to one group
 };
 
-// which parent owns super-chunk g, and which super-chunk of that parent it is
-__device__ inline void ms_locate(const MsParents &P, uint64_t g, uint32_t *parent, uint64_t *sidx) {
-    uint32_t lo = 0, hi = P.n_parents;  // sc_pre[lo] <= g < sc_pre[hi]
+// which segment owns super-chunk g, and which super-chunk of that segment it is
+__device__ inline void ms_locate(const MsParents &P, uint64_t g, uint32_t *seg, uint64_t *sidx) {
+    uint32_t lo = 0, hi = P.n_seg;  // sc_pre[lo] <= g < sc_pre[hi]
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (P.sc_pre[mid] <= g) lo = mid; else hi = mid;
     }
-    *parent = lo;
+    *seg = lo;
     *sidx = g - P.sc_pre[lo];
 }
 
 __global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__restrict__ w1, int shift, int nb,
                                                  uint32_t *cmat) {
     __shared__ uint32_t hist[MS_MAX_NB];
-    uint32_t parent;
+    uint32_t seg;
     uint64_t sidx;
-    ms_locate(P, blockIdx.x, &parent, &sidx);
+    ms_locate(P, blockIdx.x, &seg, &sidx);
     for (int b = threadIdx.x; b < nb; b += 256) hist[b] = 0;
     __syncthreads();
-    const uint64_t beg = P.start[parent] + sidx * MS_SC;
-    const uint64_t end = min(P.start[parent] + P.cnt[parent], beg + (uint64_t)MS_SC);
+    const uint64_t beg = P.start[seg] + sidx * MS_SC;
+    const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
     for (uint64_t i = beg + threadIdx.x; i < end; i += 256)
         atomicAdd(&hist[(uint32_t)(w1[i] >> shift) & (uint32_t)(nb - 1)], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256) cmat[(uint64_t)blockIdx.x * nb + b] = hist[b];
 }
 
-// logical scan order: parent-major, then child bucket, then super-chunk inside the parent
+// logical scan order: group-major, then child bucket, then super-chunk inside the group
 struct MsLogical {
     MsParents P;
     const uint32_t *cmat;
     int nb;
     __device__ uint64_t operator()(uint64_t L) const {
-        // lbase[p] = nb * sc_pre[p]
-        uint32_t lo = 0, hi = P.n_parents;
+        if (P.one_group) {
+            const uint64_t nsc = P.sc_pre[P.n_seg];
+            const uint64_t b = L / nsc, sc = L - b * nsc;
+            return cmat[sc * nb + b];
+        }
+        uint32_t lo = 0, hi = P.n_seg;  // lbase[g] = nb * sc_pre[g]
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
             if ((uint64_t)nb * P.sc_pre[mid] <= L) lo = mid; else hi = mid;
@@ -237,19 +261,19 @@ struct MsLogical {
     }
 };
 
-// children descriptors: start/cnt of child (parent p, bucket b) = index p * nb + b
+// children descriptors: start/cnt of child (group g, bucket b) = index g * nb + b
 __global__ __launch_bounds__(256) void k_ms_children(MsParents P, const uint64_t *__restrict__ offs, int nb,
                                                      uint64_t total, uint64_t *c_start, uint64_t *c_cnt) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t n_child = (uint64_t)P.n_parents * nb;
+    const uint32_t n_groups = P.one_group ? 1u : P.n_seg;
+    const uint64_t n_child = (uint64_t)n_groups * nb;
     if (i >= n_child) return;
-    const uint32_t p = (uint32_t)(i / nb), b = (uint32_t)(i % nb);
-    const uint64_t nsc = P.sc_pre[p + 1] - P.sc_pre[p];
-    // first logical element of this child; children with no super-chunk (empty parent) are empty
-    const uint64_t L = (uint64_t)nb * P.sc_pre[p] + (uint64_t)b * nsc;
-    // next child in logical order starts at L + nsc
-    const uint64_t Ln = L + nsc;
-    const uint64_t total_L = (uint64_t)nb * P.sc_pre[P.n_parents];
+    const uint32_t g = (uint32_t)(i / nb), b = (uint32_t)(i % nb);
+    const uint64_t g_lo = P.one_group ? 0 : P.sc_pre[g], g_hi = P.one_group ? P.sc_pre[P.n_seg] : P.sc_pre[g + 1];
+    const uint64_t nsc = g_hi - g_lo;
+    const uint64_t L = (uint64_t)nb * g_lo + (uint64_t)b * nsc;  // first logical element of this child
+    const uint64_t Ln = L + nsc;                                   // ... of the next child
+    const uint64_t total_L = (uint64_t)nb * P.sc_pre[P.n_seg];
     const uint64_t a = (L < total_L) ? offs[L] : total;
     const uint64_t e = (Ln < total_L) ? offs[Ln] : total;
     c_start[i] = a;
@@ -273,14 +297,16 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
                                                     uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_raw[];
     MsLds<ST> &s = *reinterpret_cast<MsLds<ST> *>(ms_raw);
-    uint32_t parent;
+    uint32_t seg;
     uint64_t sidx;
-    ms_locate(P, blockIdx.x, &parent, &sidx);
-    const uint64_t nsc = P.sc_pre[parent + 1] - P.sc_pre[parent];
-    const uint64_t lbase = (uint64_t)nb * P.sc_pre[parent];
-    for (int b = threadIdx.x; b < nb; b += 256) s.run[b] = offs[lbase + (uint64_t)b * nsc + sidx];
-    const uint64_t beg = P.start[parent] + sidx * MS_SC;
-    const uint64_t end = min(P.start[parent] + P.cnt[parent], beg + (uint64_t)MS_SC);
+    ms_locate(P, blockIdx.x, &seg, &sidx);
+    // position of this super-chunk inside its group, and the group's extent in the logical order
+    const uint64_t g_lo = P.one_group ? 0 : P.sc_pre[seg], g_hi = P.one_group ? P.sc_pre[P.n_seg] : P.sc_pre[seg + 1];
+    const uint64_t nsc = g_hi - g_lo, gidx = (uint64_t)blockIdx.x - g_lo;
+    const uint64_t lbase = (uint64_t)nb * g_lo;
+    for (int b = threadIdx.x; b < nb; b += 256) s.run[b] = offs[lbase + (uint64_t)b * nsc + gidx];
+    const uint64_t beg = P.start[seg] + sidx * MS_SC;
+    const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
     for (uint64_t c0 = beg; c0 < end; c0 += MS_CH) {
         const int n = (int)min((uint64_t)MS_CH, end - c0);
         for (int b = threadIdx.x; b < nb; b += 256) s.hist[b] = 0;
@@ -345,23 +371,27 @@ struct SkRange {            // one successfully counted (bucket, hash sub-range)
     uint64_t node_base;
 };
 
-__device__ inline uint32_t sub_hash(uint64_t kmer) { return (uint32_t)(mix64(kmer ^ 0xA24BAED4963EE407ull) >> 40); }
-__device__ inline uint32_t slot_hash(uint64_t kmer) { return (uint32_t)(mix64(kmer * 0xD6E8FEB86659FD93ull) >> 32); }
+__device__ inline uint32_t fold32(uint64_t kmer) { return (uint32_t)kmer * 0x9E3779B1u ^ (uint32_t)(kmer >> 32) * 0x85EBCA77u; }
+__device__ inline uint32_t sub_hash(uint64_t kmer) { return fmix32(fold32(kmer) ^ 0x27D4EB2Fu); }
+__device__ inline uint32_t slot_hash(uint64_t kmer) { return fmix32(fold32(kmer)); }
 
 constexpr int CNT_QBUF = 1536;   // cross-bucket successor queries staged per workgroup
 constexpr int CNT_STACK = 24;    // pending hash sub-ranges of one bucket
+constexpr int CNT_NT = 1024;     // threads per bucket workgroup (one workgroup per CU: the table fills the LDS)
+constexpr int CNT_PROBE_LIMIT = 1024;
 
 template <class ST, int CAP>
 struct CntLds {
     unsigned long long keys[CAP];
     uint32_t cnt[CAP * 4];
     ST stamp[CAP];
-    uint16_t idx[CAP];
+    uint16_t idx[CAP];    // slot -> local node index
+    uint16_t list[CAP];   // local node index -> slot
     unsigned long long q_key[CNT_QBUF];
     unsigned long long q_meta[CNT_QBUF];
     uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
     int stk_n;
-    uint32_t n_distinct, overflow, n_local, n_q;
+    uint32_t overflow, n_local, n_q, fail;
     unsigned long long gbase, qbase;
 };
 
@@ -390,46 +420,60 @@ struct SkCountOut {
     uint64_t node_cap;
     uint64_t *q_key, *q_meta;
     uint64_t q_cap;
-    SkRange *ranges;
+    SkRange *ranges;        // [0, n_buckets): the unsplit range of each bucket; beyond: ranges of split buckets
+    uint64_t n_buckets;
     uint64_t range_cap;
-    unsigned long long *scalars;  // [0] err [4] n_nodes [5] n_queries [6] n_ranges
+    unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | queries (high 32) [6] extra ranges
 };
 
+// wave-aggregated LDS counter: returns this lane's index, adds popcount(active & pred) once per wave
+__device__ inline uint32_t wave_alloc(uint32_t *counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (!mask) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((unsigned long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+}
+
 template <class ST, int CAP>
-__global__ __launch_bounds__(256) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
-                                                  const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
-                                                  const ST *__restrict__ rec_st, int k, int m, int bucket_shift,
-                                                  SkCountOut out) {
+__global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
+                                                     const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
+                                                     const ST *__restrict__ rec_st, int k, int m, SkCountOut out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cnt_raw[];
     CntLds<ST, CAP> &s = *reinterpret_cast<CntLds<ST, CAP> *>(cnt_raw);
+    constexpr int NPT = CAP / CNT_NT;  // nodes per thread, upper bound
     const uint32_t bucket = blockIdx.x;
     const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
     if (r_n == 0) return;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    constexpr uint32_t LIMIT = (uint32_t)(CAP * 0.80);
-    if (threadIdx.x == 0) { s.stk_n = 1; s.stk_mask[0] = 0; s.stk_val[0] = 0; }
+    if (threadIdx.x == 0) { s.stk_n = 1; s.stk_mask[0] = 0; s.stk_val[0] = 0; s.fail = 0; }
     __syncthreads();
     while (true) {
         __syncthreads();
-        if (s.stk_n == 0) break;
+        if (s.stk_n == 0 || s.fail) break;
         const uint32_t cur_mask = s.stk_mask[s.stk_n - 1], cur_val = s.stk_val[s.stk_n - 1];
         __syncthreads();
-        for (int i = threadIdx.x; i < CAP; i += 256) {
+        for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
             s.keys[i] = EMPTY_KEY;
             s.stamp[i] = (ST)~(ST)0;
             reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
         }
-        if (threadIdx.x == 0) { s.n_distinct = 0; s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
+        if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
         __syncthreads();
-        // ---- insert every k-mer of every record of the bucket
-        for (uint64_t r = threadIdx.x; r < r_n; r += 256) {
-            if (s.overflow) break;
+        // ---- insert: four lanes share a record, lane part p takes k-mers p, p+4, ...
+        for (uint64_t rr = threadIdx.x; rr < r_n * 4; rr += CNT_NT) {
+            const uint64_t r = rr >> 2;
+            const int part = (int)(rr & 3);
             const uint64_t w0 = rec_w0[r_beg + r], w1 = rec_w1[r_beg + r];
             const uint64_t st0 = (uint64_t)rec_st[r_beg + r];
             const uint64_t hi = w1 & (~0ull << SK_META_BITS);
             const int len = (int)((w1 >> 1) & 31) + 1;
             const uint32_t hs = (uint32_t)(w1 & 1);
-            for (int i = 0; i < len; ++i) {
+            for (int i = part; i < len; i += 4) {
+                if (s.overflow) break;
                 const uint64_t win = rec_window(w0, hi, i);
                 const uint64_t kmer = win >> (64 - 2 * k);
                 if (cur_mask && (sub_hash(kmer) & cur_mask) != cur_val) continue;
@@ -438,14 +482,11 @@ __global__ __launch_bounds__(256) void k_sk_count(const uint64_t *__restrict__ b
                 const uint64_t stamp = i ? ((st0 | 1ull) + 2ull * i) : st0;
                 uint32_t slot = slot_hash(kmer) & (CAP - 1);
                 bool ok = false;
-                for (int probe = 0; probe < CAP; ++probe) {
+                for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
                     unsigned long long cur = s.keys[slot];
                     if (cur == EMPTY_KEY) {
                         cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
-                        if (cur == EMPTY_KEY) {
-                            cur = kmer;
-                            if (atomicAdd(&s.n_distinct, 1u) >= LIMIT) s.overflow = 1;
-                        }
+                        if (cur == EMPTY_KEY) cur = kmer;
                     }
                     if (cur == kmer) { ok = true; break; }
                     slot = (slot + 1) & (CAP - 1);
@@ -461,6 +502,7 @@ __global__ __launch_bounds__(256) void k_sk_count(const uint64_t *__restrict__ b
                 const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
                 if (s.stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
                     atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
+                    s.fail = 1;
                 } else {
                     s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val; ++s.stk_n;
                     s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val | bit; ++s.stk_n;
@@ -468,39 +510,88 @@ __global__ __launch_bounds__(256) void k_sk_count(const uint64_t *__restrict__ b
             }
             continue;
         }
-        // ---- local node ids
-        for (int i = threadIdx.x; i < CAP; i += 256)
-            if (s.keys[i] != EMPTY_KEY) s.idx[i] = (uint16_t)atomicAdd(&s.n_local, 1u);
+        // ---- dense list of occupied slots (one LDS atomic per wave)
+        for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
+            const bool occ = s.keys[i] != EMPTY_KEY;
+            const uint32_t li = wave_alloc(&s.n_local, occ);
+            if (occ) { s.idx[i] = (uint16_t)li; s.list[li] = (uint16_t)i; }
+        }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned long long base = atomicAdd(&out.scalars[4], (unsigned long long)s.n_local);
-            s.gbase = base;
-            if (base + s.n_local > out.node_cap) {
-                atomicOr(&out.scalars[0], 16ull);
-                s.overflow = 1;
-            } else {
-                const unsigned long long ri = atomicAdd(&out.scalars[6], 1ull);
-                if (ri < out.range_cap) {
-                    SkRange rg;
-                    rg.bucket = bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = s.n_local; rg.node_base = base;
-                    out.ranges[ri] = rg;
-                } else {
-                    atomicOr(&out.scalars[0], 32ull);
+        const uint32_t n_local = s.n_local;
+        // ---- successor lookups into registers; misses are staged as queries (slot index local for now)
+        unsigned long long nkey[NPT];
+        uint32_t nslot[NPT];
+        int nsucc[NPT][4];          // local node index, -1 none, -2 miss staged, -3-qi miss not staged
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const uint32_t li = threadIdx.x + u * CNT_NT;
+            nslot[u] = 0xFFFFFFFFu;
+            if (li < n_local) {
+                const uint32_t i = s.list[li];
+                nslot[u] = i;
+                nkey[u] = s.keys[i];
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                bool miss = false;
+                uint64_t skey = 0;
+                nsucc[u][b] = -1;
+                if (li < n_local && s.cnt[nslot[u] * 4 + b]) {
+                    skey = ((nkey[u] << 2) | (uint64_t)b) & kmask;
+                    const int f = lds_find<CAP>(s.keys, skey);
+                    if (f >= 0) nsucc[u][b] = (int)s.idx[f];
+                    else miss = true;
+                }
+                const uint32_t qi = wave_alloc(&s.n_q, miss);
+                if (miss) {
+                    if (qi < CNT_QBUF) {
+                        s.q_key[qi] = skey;
+                        s.q_meta[qi] = (unsigned long long)li * 4 + b;
+                        nsucc[u][b] = -2;
+                    } else {
+                        nsucc[u][b] = -3 - (int)qi;
+                    }
                 }
             }
         }
         __syncthreads();
-        if (s.overflow) return;
-        const uint64_t gbase = s.gbase;
-        // ---- write nodes, resolve in-bucket successors, stage the others as queries
-        for (int i = threadIdx.x; i < CAP; i += 256) {
-            const unsigned long long key = s.keys[i];
-            if (key == EMPTY_KEY) continue;
-            const uint64_t node = gbase + s.idx[i];
+        const uint32_t nq = s.n_q;
+        if (threadIdx.x == 0) {  // one packed reservation: nodes in the low half, queries in the high half
+            const unsigned long long got =
+                atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)nq << 32));
+            const unsigned long long base = got & 0xFFFFFFFFull, qb = got >> 32;
+            s.gbase = base;
+            s.qbase = qb;
+            if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
+            if (qb + nq > out.q_cap || qb + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+            uint64_t ri = bucket;
+            if (cur_mask) {
+                ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
+                if (ri >= out.range_cap) { atomicOr(&out.scalars[0], 32ull); s.fail = 1; }
+            }
+            if (!s.fail) {
+                SkRange rg;
+                rg.bucket = bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
+                out.ranges[ri] = rg;
+            }
+        }
+        // while the reservation is in flight: minimizer bucket of every staged query (dense, no divergence)
+        for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
+            s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
+        __syncthreads();
+        if (s.fail) break;
+        const uint64_t gbase = s.gbase, qbase = s.qbase;
+        // ---- write nodes: consecutive lanes -> consecutive nodes
+#pragma unroll
+        for (int u = 0; u < NPT; ++u) {
+            const uint32_t li = threadIdx.x + u * CNT_NT;
+            if (li >= n_local) continue;
+            const uint32_t i = nslot[u];
+            const uint64_t node = gbase + li;
             const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
             const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
             const uint64_t stamp = (uint64_t)s.stamp[i];
-            out.keys[node] = key;
+            out.keys[node] = nkey[u];
             out.stamps[node] = stamp;
             reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
             out.flags[node] = (uint8_t)(stamp & 1);
@@ -516,41 +607,20 @@ __global__ __launch_bounds__(256) void k_sk_count(const uint64_t *__restrict__ b
             uint32_t sc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                sc[b] = NO_NODE;
-                if (!c[b]) continue;
-                const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
-                const int f = lds_find<CAP>(s.keys, skey);
-                if (f >= 0) {
-                    sc[b] = (uint32_t)(gbase + s.idx[f]);
-                } else {
-                    const unsigned long long meta = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
-                    const uint32_t qi = atomicAdd(&s.n_q, 1u);
-                    if (qi < CNT_QBUF) {
-                        s.q_key[qi] = skey;
-                        s.q_meta[qi] = meta;
-                    } else {  // staging full: append directly
-                        const unsigned long long g = atomicAdd(&out.scalars[5], 1ull);
-                        if (g < out.q_cap) { out.q_key[g] = skey; out.q_meta[g] = meta; }
-                        else atomicOr(&out.scalars[0], 64ull);
-                    }
+                const int v = nsucc[u][b];
+                sc[b] = v >= 0 ? (uint32_t)(gbase + v) : NO_NODE;
+                if (v <= -3) {  // query that did not fit the staging buffer: write it straight out
+                    const uint64_t qi = (uint64_t)(-3 - v);
+                    const uint64_t skey = ((nkey[u] << 2) | (uint64_t)b) & kmask;
+                    out.q_key[qbase + qi] = skey;
+                    out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
                 }
             }
             reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
         }
-        __syncthreads();
-        const uint32_t nq = min(s.n_q, (uint32_t)CNT_QBUF);
-        if (threadIdx.x == 0 && nq) s.qbase = atomicAdd(&out.scalars[5], (unsigned long long)nq);
-        __syncthreads();
-        if (nq) {
-            const unsigned long long qb = s.qbase;
-            if (qb + nq > out.q_cap) {
-                if (threadIdx.x == 0) atomicOr(&out.scalars[0], 64ull);
-            } else {
-                for (uint32_t i = threadIdx.x; i < nq; i += 256) {
-                    out.q_key[qb + i] = s.q_key[i];
-                    out.q_meta[qb + i] = s.q_meta[i];
-                }
-            }
+        for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
+            out.q_key[qbase + i] = s.q_key[i];
+            out.q_meta[qbase + i] = s.q_meta[i] + gbase * 4;  // local slot index -> global
         }
     }
 }
@@ -572,6 +642,7 @@ __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ra
     extern __shared__ __attribute__((aligned(16))) unsigned char ans_raw[];
     AnsLds<CAP> &s = *reinterpret_cast<AnsLds<CAP> *>(ans_raw);
     const SkRange rg = ranges[blockIdx.x];
+    if (rg.node_cnt == 0) return;  // bucket that was empty or was split into sub-ranges
     const uint64_t qn = q_cnt[rg.bucket];
     if (qn == 0) return;
     for (int i = threadIdx.x; i < CAP; i += 256) s.keys[i] = EMPTY_KEY;
