@@ -54,6 +54,7 @@ struct dbg {
     uint32_t *d_cnt = nullptr;
     uint8_t *d_flags = nullptr;
     uint8_t *d_order = nullptr;  // successor codes ranked by (count desc, ascii asc), 2 bits each
+    uint8_t *d_deg = nullptr;    // distinct successors (pre-pruning outdegree) -- feeds the CSR row scan
     uint32_t *d_succ = nullptr;
     bool nodes_in_arena = false;  // node arrays borrowed from ar_node (super-k-mer engine)
     uint64_t *d_rowptr = nullptr;
@@ -88,7 +89,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][2], ar_node[6], ar_misc[8], ar_csr[3], ar_scan;
+    Buf ar_rec[2][3], ar_q[2][2], ar_node[7], ar_misc[8], ar_csr[3], ar_scan;
     // branch k-mer lookup (pull-out reads)
     uint64_t *d_btab = nullptr;
     uint64_t btab_cap = 0;
@@ -262,11 +263,8 @@ struct PopcWords {
     __device__ uint64_t operator()(uint64_t i) const { return __popc(w[i]); }
 };
 struct DegOf {
-    const uint32_t *cnt;
-    __device__ uint64_t operator()(uint64_t i) const {
-        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
-        return (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0);
-    }
+    const uint8_t *deg;
+    __device__ uint64_t operator()(uint64_t i) const { return deg[i]; }
 };
 struct U64At {
     const uint64_t *p;
@@ -424,7 +422,7 @@ __device__ inline uint32_t tab_find(const Slot *tab, uint64_t cap_mask, int hash
 // successor ids (4-way) + successor rank order byte
 __global__ __launch_bounds__(256) void k_succ(const Slot *tab, uint64_t cap_mask, int hash_shift, int k, uint64_t n_nodes,
                                               const uint64_t *keys, const uint32_t *cnt, uint32_t *succ,
-                                              uint8_t *order) {
+                                              uint8_t *order, uint8_t *deg) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -436,6 +434,7 @@ __global__ __launch_bounds__(256) void k_succ(const Slot *tab, uint64_t cap_mask
     for (int b = 0; b < 4; ++b)
         s[b] = c[b] ? tab_find(tab, cap_mask, hash_shift, ((key << 2) | (uint64_t)b) & kmask) : NO_NODE;
     reinterpret_cast<uint4 *>(succ)[i] = make_uint4(s[0], s[1], s[2], s[3]);
+    deg[i] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
     // rank codes by (count desc, ascii order asc): insertion sort of 4
     uint32_t code[4] = {0, 1, 3, 2};  // ascii order A, C, G, T as codes
 #pragma unroll
@@ -835,13 +834,13 @@ static void free_build(dbg *h) {
     dev_free(h->d_tab); dev_free(h->d_occ);
     if (h->nodes_in_arena) {
         h->d_keys = nullptr; h->d_stamps = nullptr; h->d_cnt = nullptr; h->d_flags = nullptr;
-        h->d_order = nullptr; h->d_succ = nullptr;
+        h->d_order = nullptr; h->d_succ = nullptr; h->d_deg = nullptr;
         h->nodes_in_arena = false;
     }
     dev_free(h->d_btab);
     h->btab_cap = 0;
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
-    dev_free(h->d_order); dev_free(h->d_succ);
+    dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_deg);
     h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
     dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
@@ -1004,7 +1003,7 @@ static int finish_graph(dbg *h) {
         CHK(buf_ensure(h, h->ar_csr[0], (h->n_nodes + 1) * 8));
         h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
         uint64_t total = 0;
-        CHK(exclusive_scan(h, h->n_nodes, DegOf{h->d_cnt}, h->d_rowptr, &total));
+        CHK(exclusive_scan(h, h->n_nodes, DegOf{h->d_deg}, h->d_rowptr, &total));
         h->n_edges = total;
         HIPCHK(h, hipMemcpyAsync(h->d_rowptr + h->n_nodes, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
         CHK(buf_ensure(h, h->ar_csr[1], total * 4));
@@ -1109,6 +1108,7 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
         CHK(dev_alloc(h, &h->d_flags, total));
         CHK(dev_alloc(h, &h->d_order, total));
         CHK(dev_alloc(h, &h->d_succ, total * 4));
+        CHK(dev_alloc(h, &h->d_deg, total));
         hipLaunchKernelGGL(k_gather, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, h->d_tab, h->d_occ,
                            word_rank, n_words, h->d_keys, h->d_stamps, h->d_cnt, h->d_flags);
         HIPCHK(h, hipGetLastError());
@@ -1119,7 +1119,7 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
         Timer t(h->stream);
         if (h->n_nodes) {
             hipLaunchKernelGGL(k_succ, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->d_tab, cap - 1,
-                               64 - lg, k, h->n_nodes, h->d_keys, h->d_cnt, h->d_succ, h->d_order);
+                               64 - lg, k, h->n_nodes, h->d_keys, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.ms_succ = t.stop();
@@ -1531,9 +1531,18 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
             HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
             if (tiles) {
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases,
-                                   h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk,
-                                   seg_ne, sc_dev);
+                if (m == SK_MAX_M && w == 19)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 19>), dim3(n_wg), dim3(256), 0, h->stream,
+                                       h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap,
+                                       seg_cnt, seg_nk, seg_ne, sc_dev);
+                else if (m == SK_MAX_M && w == 9)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 9>), dim3(n_wg), dim3(256), 0, h->stream,
+                                       h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap,
+                                       seg_cnt, seg_nk, seg_ne, sc_dev);
+                else
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream,
+                                       h->d_bases, h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap,
+                                       seg_cnt, seg_nk, seg_ne, sc_dev);
                 HIPCHK(h, hipGetLastError());
             }
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -1582,12 +1591,14 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     CHK(buf_ensure(h, h->ar_node[3], node_cap));
     CHK(buf_ensure(h, h->ar_node[4], node_cap));
     CHK(buf_ensure(h, h->ar_node[5], node_cap * 16));
+    CHK(buf_ensure(h, h->ar_node[6], node_cap));
     h->d_keys = (uint64_t *)h->ar_node[0].p;
     h->d_stamps = (uint64_t *)h->ar_node[1].p;
     h->d_cnt = (uint32_t *)h->ar_node[2].p;
     h->d_flags = (uint8_t *)h->ar_node[3].p;
     h->d_order = (uint8_t *)h->ar_node[4].p;
     h->d_succ = (uint32_t *)h->ar_node[5].p;
+    h->d_deg = (uint8_t *)h->ar_node[6].p;
     h->nodes_in_arena = true;
     uint64_t q_cap = n_rec + 1024;
     uint64_t *qk[2], *qm[2];
@@ -1604,7 +1615,7 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         Timer t(h->stream);
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
-        SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_succ, node_cap,
+        SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_deg, h->d_succ, node_cap,
                        qk[0], qm[0], q_cap, ranges, n_buckets, range_cap, sc_dev};
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);

@@ -58,6 +58,7 @@ struct SkLds {
     unsigned long long sbits[TILE / 64 + 1];  // record starts
     unsigned long long vbits[TILE / 64 + 1];  // valid k-mer positions
     uint32_t wpre[TILE / 64 + 1];   // exclusive prefix of popcount(sbits)
+    uint16_t list[TILE];            // record index -> start position (dense work list)
     uint32_t nrec;
 };
 
@@ -140,11 +141,16 @@ __global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bas
         if (cursor + nrec > seg_cap) { overflow = true; break; }  // uniform: caller retries with a larger segment
         const uint64_t gbase = seg0 + cursor;
         cursor += nrec;
-        for (int j0 = 0; j0 < TILE; j0 += 256) {
+        for (int j0 = 0; j0 < TILE; j0 += 256) {  // dense work list of record starts
             const int j = j0 + threadIdx.x;
+            const unsigned long long sb = s.sbits[j >> 6];
+            if ((sb >> (j & 63)) & 1ull) s.list[s.wpre[j >> 6] + __popcll(sb & ((1ull << (j & 63)) - 1))] = (uint16_t)j;
+        }
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < nrec; r += 256) {
+            const int j = s.list[r];
             const int wd = j >> 6, bt = j & 63;
             const unsigned long long sb = s.sbits[wd];
-            if (!((sb >> bt) & 1ull)) continue;
             // run length: up to the next record start or the first position without a k-mer
             const unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
             const unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
@@ -171,7 +177,175 @@ __global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bas
             const uint32_t mp = j + s.minp[j];
             const uint32_t bh = bucket_hash22((uint32_t)(window32(s.t, mp) >> (64 - 2 * m)));
             const uint64_t w1 = (hi & (~0ull << SK_META_BITS)) | ((uint64_t)bh << 6) | ((uint64_t)(len - 1) << 1) | has_succ;
-            const uint64_t o = gbase + s.wpre[wd] + __popcll(sb & ((1ull << bt) - 1));
+            const uint64_t o = gbase + r;
+            rec_w0[o] = w0;
+            rec_w1[o] = w1;
+            rec_st[o] = (ST)((p << 1) | (s0 ^ 1u));
+        }
+    }
+    if (overflow && threadIdx.x == 0) atomicOr(&scalars[0], 4ull);
+    n_k = wave_sum_u64(n_k);
+    n_e = wave_sum_u64(n_e);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = n_k; red[4 + (threadIdx.x >> 6)] = n_e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        seg_cnt[blockIdx.x] = cursor;
+        seg_nk[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        seg_ne[blockIdx.x] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+// Fast extraction for m = 13 and a compile-time window W = k - 12 (k = 31 -> W = 19).
+// Every lane owns 32 consecutive positions: it reads 64 bases and 64 read-start bits once, rolls
+// the 32 + W - 1 m-mer hashes it needs in registers and takes the sliding-window minimum with
+// the van Herk / Gil-Werman block scheme (about 4 min ops per position instead of W LDS reads).
+// Hash and leftmost tie-break are the same as in the generic kernel: packed = hash16 << 8 | offset.
+struct SkLdsW {
+    TileLds t;
+    uint8_t minp[TILE];
+    unsigned long long sbits[TILE / 64 + 1];
+    unsigned long long vbits[TILE / 64 + 1];
+    uint32_t wpre[TILE / 64 + 1];
+    uint16_t list[TILE];            // record index -> start position (dense work list)
+    uint8_t edge[256];
+    uint32_t nrec;
+};
+
+template <class ST, int W>
+__global__ __launch_bounds__(256) void k_sk_extract_w(const char *__restrict__ bases, uint64_t n_bytes,
+                                                      const uint32_t *__restrict__ startbits, uint64_t n_tiles,
+                                                      uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
+                                                      uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
+                                                      unsigned long long *scalars /* [0] err */) {
+    constexpr int M = SK_MAX_M, K = W + M - 1, NV = 32 + W - 1;
+    static_assert(TILE == 256 * 32, "one lane per 32 positions");
+    static_assert(K <= 31 && NV + M - 1 <= 64, "window must fit the two 32-base registers");
+    __shared__ SkLdsW s;
+    __shared__ uint64_t red[8];
+    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
+    uint64_t cursor = 0;
+    constexpr uint32_t mid_mask = (1u << (K - 1)) - 1u;
+    uint64_t n_k = 0, n_e = 0;
+    bool overflow = false;
+    const int j0 = threadIdx.x * 32;
+    for (uint64_t tile = t_beg; tile < t_end; ++tile) {
+        const uint64_t tile0 = tile * TILE;
+        __syncthreads();
+        const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
+        if (bad) atomicOr(&scalars[0], 1ull);
+        __syncthreads();
+        // ---- register phase
+        const uint64_t wa = window32(s.t, j0), wb = window32(s.t, j0 + 32);
+        uint32_t pv[NV], P[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const uint64_t win = (i == 0) ? wa : (i < 32) ? ((wa << (2 * i)) | (wb >> (64 - 2 * i))) : (i == 32) ? wb : (wb << (2 * (i - 32)));
+            pv[i] = (mmer_hash16((uint32_t)(win >> (64 - 2 * M))) << 8) | (uint32_t)i;
+            P[i] = (i % W == 0) ? pv[i] : min(P[i - 1], pv[i]);
+        }
+        const uint64_t sb64 = ((uint64_t)s.t.sb[(j0 >> 5) + 1] << 32) | s.t.sb[j0 >> 5];
+        uint32_t vmask = 0, skmask = 0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const uint32_t sw = (uint32_t)(sb64 >> q);
+            const uint32_t s0 = sw & 1u, sk = (sw >> K) & 1u;
+            const bool v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0) && (tile0 + j0 + q < n_bytes);
+            vmask |= (uint32_t)v << q;
+            skmask |= sk << q;
+        }
+        n_k += __popc(vmask);
+        n_e += __popc(vmask & ~skmask);
+        uint32_t off[32];
+        {
+            uint32_t S = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = NV - 1; i >= 0; --i) {
+                S = (i % W == W - 1 || i == NV - 1) ? pv[i] : min(S, pv[i]);
+                if (i < 32) {
+                    const uint32_t mn = (i % W == 0) ? P[i + W - 1] : min(S, P[i + W - 1]);
+                    off[i] = ((vmask >> i) & 1u) ? ((mn & 0xFFu) - (uint32_t)i) : 0xFFu;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 32; q += 4)
+            reinterpret_cast<uint32_t *>(s.minp)[(j0 + q) >> 2] = off[q] | (off[q + 1] << 8) | (off[q + 2] << 16) | (off[q + 3] << 24);
+        s.edge[threadIdx.x] = (uint8_t)off[31];
+        reinterpret_cast<uint32_t *>(s.vbits)[threadIdx.x] = vmask;
+        __syncthreads();
+        uint32_t smask = 0;
+        {
+            uint32_t prev = threadIdx.x ? (uint32_t)s.edge[threadIdx.x - 1] : 0xFFu;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                // new record unless the previous position holds a k-mer with the same minimizer occurrence
+                const bool st = (off[q] != 0xFFu) && (prev == 0xFFu || prev != off[q] + 1);
+                smask |= (uint32_t)st << q;
+                prev = off[q];
+            }
+            reinterpret_cast<uint32_t *>(s.sbits)[threadIdx.x] = smask;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            uint32_t a = __popcll(s.sbits[threadIdx.x]), b = __popcll(s.sbits[threadIdx.x + 64]);
+            uint32_t ia = a, ib = b;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+                if ((int)threadIdx.x >= d) { ia += oa; ib += ob; }
+            }
+            const uint32_t tot_a = __shfl(ia, 63, 64);
+            s.wpre[threadIdx.x] = ia - a;
+            s.wpre[threadIdx.x + 64] = tot_a + ib - b;
+            if (threadIdx.x == 63) s.nrec = tot_a + ib;
+            if (threadIdx.x == 0) { s.sbits[TILE / 64] = 0; s.vbits[TILE / 64] = 0; }
+        }
+        __syncthreads();
+        const uint32_t nrec = s.nrec;
+        if (cursor + nrec > seg_cap) { overflow = true; break; }
+        const uint64_t gbase = seg0 + cursor;
+        cursor += nrec;
+        {  // dense work list of record starts: this lane's 32 positions
+            uint32_t sm = smask;
+            uint32_t li = s.wpre[threadIdx.x >> 1] + ((threadIdx.x & 1) ? __popc((uint32_t)s.sbits[threadIdx.x >> 1]) : 0);
+            while (sm) {
+                const int q = __ffs(sm) - 1;
+                sm &= sm - 1;
+                s.list[li++] = (uint16_t)(j0 + q);
+            }
+        }
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < nrec; r += 256) {
+            const int j = s.list[r];
+            const int wd = j >> 6, bt = j & 63;
+            const unsigned long long sb = s.sbits[wd];
+            const unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
+            const unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
+            const int room = 63 - bt;
+            const unsigned long long stop = nxt_s | nxt_i;
+            int len;
+            if (stop) {
+                len = 1 + (__ffsll((unsigned long long)stop) - 1);
+            } else {
+                const unsigned long long stop2 = s.sbits[wd + 1] | ~s.vbits[wd + 1];
+                len = 1 + room + (__ffsll((unsigned long long)stop2) - 1);
+            }
+            if (j + len > TILE) len = TILE - j;
+            const uint64_t p = tile0 + j;
+            const uint32_t s0 = startwin32(s.t, j) & 1u;
+            const uint32_t sk_last = (startwin32(s.t, j + len - 1) >> K) & 1u;
+            const uint32_t has_succ = sk_last ^ 1u;
+            const int nb = K + len - 1 + (int)has_succ;
+            uint64_t w0 = window32(s.t, j);
+            uint64_t hi = window32(s.t, j + 32);
+            if (nb < 32) { w0 &= ~0ull << (64 - 2 * nb); hi = 0; }
+            else if (nb == 32) hi = 0;
+            else hi &= ~0ull << (64 - 2 * (nb - 32));
+            const uint32_t mp = j + s.minp[j];
+            const uint32_t bh = bucket_hash22((uint32_t)(window32(s.t, mp) >> (64 - 2 * M)));
+            const uint64_t w1 = (hi & (~0ull << SK_META_BITS)) | ((uint64_t)bh << 6) | ((uint64_t)(len - 1) << 1) | has_succ;
+            const uint64_t o = gbase + r;
             rec_w0[o] = w0;
             rec_w1[o] = w1;
             rec_st[o] = (ST)((p << 1) | (s0 ^ 1u));
@@ -415,7 +589,7 @@ __device__ inline int lds_find(const unsigned long long *keys, uint64_t key) {
 struct SkCountOut {
     uint64_t *keys, *stamps;
     uint32_t *cnt;
-    uint8_t *flags, *order;
+    uint8_t *flags, *order, *deg;
     uint32_t *succ;
     uint64_t node_cap;
     uint64_t *q_key, *q_meta;
@@ -595,6 +769,7 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
             out.stamps[node] = stamp;
             reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
             out.flags[node] = (uint8_t)(stamp & 1);
+            out.deg[node] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
             uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
 #pragma unroll
             for (int a = 1; a < 4; ++a) {
