@@ -82,6 +82,7 @@ struct dbg {
     int engine = 0;          // 0 = super-k-mer partitioned build, 1 = single global hash table
     int bucket_bits = 0;     // 0 = auto (super-k-mer engine)
     int lds_slots = 4096;    // LDS table slots per bucket workgroup (2048 or 4096)
+    int phase_limit = 0;     // ablation of k_sk_count (timing only; the build then fails on purpose)
 
     // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
     // so buffers survive across dbg_build calls on the same handle
@@ -1033,6 +1034,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "engine" && (value == 0 || value == 1)) { h->engine = (int)value; return DBG_OK; }
     if (n == "bucket_bits" && value >= 0 && value <= 18) { h->bucket_bits = (int)value; return DBG_OK; }
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
+    if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
 }
@@ -1622,12 +1624,13 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n_rec) {
             hipLaunchKernelGGL(kern, dim3((unsigned)n_buckets), dim3(CNT_NT), lds, h->stream, b_start, b_cnt, w0[where],
-                               w1[where], st[where], k, m, out);
+                               w1[where], st[where], k, m, out, h->phase_limit);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? 1 : 0;
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_count = t.stop();
+        if (h->phase_limit) { h->err = "ablation run (phase_limit set): timing only"; return DBG_E_ARG; }
         // buckets that had to be split by hash sub-range turn in-bucket successors into queries:
         // the usual bound (one query per record) no longer holds, retry with the safe one
         if ((sc[0] & 64) && !(sc[0] & (8 | 16 | 32)) && attempt == 0) { q_cap = h->n_edge_inst + 1024; continue; }

@@ -11,6 +11,7 @@
 // No global atomics per k-mer: they run at ~2-3e10/s chip-wide (memory-side), far below what
 // this path needs; all per-k-mer atomics are LDS atomics.
 #pragma once
+#include <cstddef>
 #include "dbg_device.h"
 
 namespace dbgk {
@@ -32,7 +33,8 @@ __host__ __device__ inline uint32_t fmix32(uint32_t x) {
     return x;
 }
 // m <= 13: an m-mer is at most 26 bits.  Minimizer order = 16-bit hash, ties to the leftmost.
-__device__ inline uint32_t mmer_hash16(uint32_t mmer) { return fmix32(mmer ^ 0x3C6EF372u) >> 16; }
+// one multiply: the minimizer order only has to look random, and this hash runs ~1.6x per base
+__device__ inline uint32_t mmer_hash16(uint32_t mmer) { return ((mmer ^ (mmer >> 9) ^ 0x3C6EF372u) * 0x9E3779B1u) >> 16; }
 __device__ inline uint32_t bucket_hash22(uint32_t mmer) { return fmix32(mmer * 0x9E3779B1u + 0x7F4A7C15u) >> (32 - SK_BUCKET_BITS); }
 
 // minimizer-hash bucket of a single packed k-mer (pure function of the k-mer)
@@ -547,9 +549,18 @@ struct SkRange {            // one successfully counted (bucket, hash sub-range)
 
 __device__ inline uint32_t fold32(uint64_t kmer) { return (uint32_t)kmer * 0x9E3779B1u ^ (uint32_t)(kmer >> 32) * 0x85EBCA77u; }
 __device__ inline uint32_t sub_hash(uint64_t kmer) { return fmix32(fold32(kmer) ^ 0x27D4EB2Fu); }
-__device__ inline uint32_t slot_hash(uint64_t kmer) { return fmix32(fold32(kmer)); }
+// LDS table slot: Fibonacci hashing of the folded key, top bits (one multiply per probe sequence)
+__device__ inline uint32_t slot_hash(uint64_t kmer) {
+    const uint32_t lo = (uint32_t)kmer, hi = (uint32_t)(kmer >> 32);
+    return (lo ^ (hi << 11) ^ (hi >> 7) ^ (lo >> 15)) * 0x9E3779B1u;
+}
+template <int CAP>
+__device__ inline uint32_t slot_of(uint64_t kmer) {
+    static_assert(CAP == 2048 || CAP == 4096, "table size");
+    return slot_hash(kmer) >> (CAP == 4096 ? 20 : 21);
+}
 
-constexpr int CNT_QBUF = 1536;   // cross-bucket successor queries staged per workgroup
+constexpr int CNT_QBUF = 1024;   // cross-bucket successor queries staged per workgroup; also the record staging depth
 constexpr int CNT_STACK = 24;    // pending hash sub-ranges of one bucket
 constexpr int CNT_NT = 1024;     // threads per bucket workgroup (one workgroup per CU: the table fills the LDS)
 constexpr int CNT_PROBE_LIMIT = 1024;
@@ -561,11 +572,12 @@ struct CntLds {
     ST stamp[CAP];
     uint16_t idx[CAP];    // slot -> local node index
     uint16_t list[CAP];   // local node index -> slot
-    unsigned long long q_key[CNT_QBUF];
-    unsigned long long q_meta[CNT_QBUF];
+    unsigned long long q_key[CNT_QBUF];   // insert phase: staged record w0; afterwards: query keys
+    unsigned long long q_meta[CNT_QBUF];  // insert phase: staged record w1; afterwards: query meta
+    ST st_stage[CNT_QBUF];                // insert phase: staged record stamps
     uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
     int stk_n;
-    uint32_t overflow, n_local, n_q, fail;
+    uint32_t overflow, n_local, n_q, fail, n_flat;
     unsigned long long gbase, qbase;
 };
 
@@ -576,7 +588,7 @@ __device__ inline uint64_t rec_window(uint64_t w0, uint64_t hi, int i) {
 
 template <int CAP>
 __device__ inline int lds_find(const unsigned long long *keys, uint64_t key) {
-    uint32_t slot = slot_hash(key) & (CAP - 1);
+    uint32_t slot = slot_of<CAP>(key);
     for (int probe = 0; probe < CAP; ++probe) {
         const unsigned long long cur = keys[slot];
         if (cur == key) return (int)slot;
@@ -612,10 +624,28 @@ __device__ inline uint32_t wave_alloc(uint32_t *counter, bool pred) {
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
 }
 
+// same for n items per lane: returns the index of the lane's first item
+__device__ inline uint32_t wave_alloc_n(uint32_t *counter, uint32_t n) {
+    const int lane = threadIdx.x & 63;
+    uint32_t inc = n;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    const uint32_t total = __shfl(inc, 63, 64);
+    if (!total) return 0;
+    uint32_t base = 0;
+    if (lane == 63) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + inc - n;
+}
+
 template <class ST, int CAP>
 __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
-                                                     const ST *__restrict__ rec_st, int k, int m, SkCountOut out) {
+                                                     const ST *__restrict__ rec_st, int k, int m, SkCountOut out,
+                                                     int phase_limit /* ablation only: 0 = run everything */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char cnt_raw[];
     CntLds<ST, CAP> &s = *reinterpret_cast<CntLds<ST, CAP> *>(cnt_raw);
     constexpr int NPT = CAP / CNT_NT;  // nodes per thread, upper bound
@@ -637,24 +667,52 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
         }
         if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
         __syncthreads();
-        // ---- insert: four lanes share a record, lane part p takes k-mers p, p+4, ...
-        for (uint64_t rr = threadIdx.x; rr < r_n * 4; rr += CNT_NT) {
-            const uint64_t r = rr >> 2;
-            const int part = (int)(rr & 3);
-            const uint64_t w0 = rec_w0[r_beg + r], w1 = rec_w1[r_beg + r];
-            const uint64_t st0 = (uint64_t)rec_st[r_beg + r];
-            const uint64_t hi = w1 & (~0ull << SK_META_BITS);
-            const int len = (int)((w1 >> 1) & 31) + 1;
-            const uint32_t hs = (uint32_t)(w1 & 1);
-            for (int i = part; i < len; i += 4) {
-                if (s.overflow) break;
+        // ---- insert: records are staged in LDS with one bulk load (no global latency inside the
+        //      k-mer loop).  Work items are "quads" (record, 4 consecutive k-mers), listed densely so
+        //      that every group of 4 lanes has a quad: lane utilisation ~80 % whatever the lengths.
+        uint16_t *flat = s.idx;  // idx[] and list[] are adjacent and unused until the table is final
+        using LdsT = CntLds<ST, CAP>;
+        static_assert(offsetof(LdsT, list) == offsetof(LdsT, idx) + sizeof(uint16_t) * CAP, "layout");
+        static_assert(CNT_QBUF * 5 <= 2 * CAP || CAP == 2048, "quad list must fit idx+list");
+        constexpr uint32_t STAGE = (CNT_QBUF * 5 <= 2 * CAP) ? CNT_QBUF : (2 * CAP) / 5;
+        for (uint64_t c0 = 0; c0 < r_n; c0 += STAGE) {
+            const uint32_t n_st = (uint32_t)min((uint64_t)STAGE, r_n - c0);
+            if (c0) __syncthreads();
+            if (threadIdx.x == 0) s.n_flat = 0;
+            for (uint32_t r = threadIdx.x; r < n_st; r += CNT_NT) {
+                s.q_key[r] = rec_w0[r_beg + c0 + r];
+                s.q_meta[r] = rec_w1[r_beg + c0 + r];
+                s.st_stage[r] = rec_st[r_beg + c0 + r];
+            }
+            __syncthreads();
+            if (phase_limit == 1) return;  // clear + stage
+            if (s.overflow) break;  // uniform: read after the barrier
+            {  // quad list (STAGE <= CNT_NT: one record per thread)
+                const uint32_t r = threadIdx.x;
+                uint32_t nquad = 0;
+                if (r < n_st) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
+                uint32_t base = wave_alloc_n(&s.n_flat, nquad);
+                for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
+            }
+            __syncthreads();
+            const uint32_t n_flat = s.n_flat;
+            for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += CNT_NT / 4) {
+                const uint32_t e = flat[f];
+                const uint32_t r = e >> 3;
+                const int i = (int)((e & 7) * 4 + (threadIdx.x & 3));
+                const uint64_t w0 = s.q_key[r], w1 = s.q_meta[r];
+                const int len = (int)((w1 >> 1) & 31) + 1;
+                if (i >= len) continue;
+                const ST st0 = s.st_stage[r];
+                const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+                const uint32_t hs = (uint32_t)(w1 & 1);
                 const uint64_t win = rec_window(w0, hi, i);
                 const uint64_t kmer = win >> (64 - 2 * k);
                 if (cur_mask && (sub_hash(kmer) & cur_mask) != cur_val) continue;
                 const bool has_succ = (i < len - 1) || hs;
                 const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
-                const uint64_t stamp = i ? ((st0 | 1ull) + 2ull * i) : st0;
-                uint32_t slot = slot_hash(kmer) & (CAP - 1);
+                const ST stamp = i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0;
+                uint32_t slot = slot_of<CAP>(kmer);
                 bool ok = false;
                 for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
                     unsigned long long cur = s.keys[slot];
@@ -665,12 +723,13 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                     if (cur == kmer) { ok = true; break; }
                     slot = (slot + 1) & (CAP - 1);
                 }
-                if (!ok) { s.overflow = 1; break; }
+                if (!ok) { s.overflow = 1; continue; }
                 if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], 1u);
-                atomicMin(&s.stamp[slot], (ST)stamp);
+                atomicMin(&s.stamp[slot], stamp);
             }
         }
         __syncthreads();
+        if (phase_limit == 2) return;  // clear + stage + insert
         if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
             if (threadIdx.x == 0) {
                 const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
@@ -691,44 +750,52 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
             if (occ) { s.idx[i] = (uint16_t)li; s.list[li] = (uint16_t)i; }
         }
         __syncthreads();
+        if (phase_limit == 3) return;  // + dense list
         const uint32_t n_local = s.n_local;
-        // ---- successor lookups into registers; misses are staged as queries (slot index local for now)
-        unsigned long long nkey[NPT];
-        uint32_t nslot[NPT];
-        int nsucc[NPT][4];          // local node index, -1 none, -2 miss staged, -3-qi miss not staged
+        // ---- successor lookups into registers; misses are staged as queries (slot index local for now).
+        //      Per node only the bases that occur are looked up (usually one): the wave loops
+        //      max-popcount times instead of four.  Result per base, 16 bits: local node index,
+        //      0xFFFF none, 0xFFFE miss staged, 0x8000 | (qi - CNT_QBUF) miss that did not fit the staging.
+        unsigned long long nsucc[NPT];
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
+            nsucc[u] = ~0ull;
+            if ((uint32_t)(u * CNT_NT) >= n_local) continue;  // uniform over the workgroup
             const uint32_t li = threadIdx.x + u * CNT_NT;
-            nslot[u] = 0xFFFFFFFFu;
+            unsigned long long key = 0;
+            uint32_t nz = 0;
             if (li < n_local) {
-                const uint32_t i = s.list[li];
-                nslot[u] = i;
-                nkey[u] = s.keys[i];
+                const uint32_t sl = s.list[li];
+                key = s.keys[sl];
+                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[sl];
+                nz = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
             }
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                bool miss = false;
-                uint64_t skey = 0;
-                nsucc[u][b] = -1;
-                if (li < n_local && s.cnt[nslot[u] * 4 + b]) {
-                    skey = ((nkey[u] << 2) | (uint64_t)b) & kmask;
-                    const int f = lds_find<CAP>(s.keys, skey);
-                    if (f >= 0) nsucc[u][b] = (int)s.idx[f];
-                    else miss = true;
+            uint32_t missmask = 0;
+            while (nz) {
+                const uint32_t b = __ffs(nz) - 1;
+                nz &= nz - 1;
+                const int f = lds_find<CAP>(s.keys, ((key << 2) | (uint64_t)b) & kmask);
+                if (f >= 0) nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)s.idx[f] << (16 * b));
+                else missmask |= 1u << b;
+            }
+            uint32_t qi = wave_alloc_n(&s.n_q, (uint32_t)__popc(missmask));
+            while (missmask) {
+                const uint32_t b = __ffs(missmask) - 1;
+                missmask &= missmask - 1;
+                unsigned long long code;
+                if (qi < CNT_QBUF) {
+                    s.q_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
+                    s.q_meta[qi] = (unsigned long long)li * 4 + b;
+                    code = 0xFFFEull;
+                } else {
+                    code = 0x8000ull | (qi - CNT_QBUF);
                 }
-                const uint32_t qi = wave_alloc(&s.n_q, miss);
-                if (miss) {
-                    if (qi < CNT_QBUF) {
-                        s.q_key[qi] = skey;
-                        s.q_meta[qi] = (unsigned long long)li * 4 + b;
-                        nsucc[u][b] = -2;
-                    } else {
-                        nsucc[u][b] = -3 - (int)qi;
-                    }
-                }
+                nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | (code << (16 * b));
+                ++qi;
             }
         }
         __syncthreads();
+        if (phase_limit == 4) return;  // + successor lookups
         const uint32_t nq = s.n_q;
         if (threadIdx.x == 0) {  // one packed reservation: nodes in the low half, queries in the high half
             const unsigned long long got =
@@ -753,19 +820,22 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
         for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
             s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
         __syncthreads();
+        if (phase_limit == 5) return;  // + reservation + query buckets
         if (s.fail) break;
         const uint64_t gbase = s.gbase, qbase = s.qbase;
         // ---- write nodes: consecutive lanes -> consecutive nodes
 #pragma unroll
         for (int u = 0; u < NPT; ++u) {
+            if ((uint32_t)(u * CNT_NT) >= n_local) break;
             const uint32_t li = threadIdx.x + u * CNT_NT;
             if (li >= n_local) continue;
-            const uint32_t i = nslot[u];
+            const uint32_t i = s.list[li];
+            const unsigned long long key = s.keys[i];
             const uint64_t node = gbase + li;
             const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
             const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
             const uint64_t stamp = (uint64_t)s.stamp[i];
-            out.keys[node] = nkey[u];
+            out.keys[node] = key;
             out.stamps[node] = stamp;
             reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
             out.flags[node] = (uint8_t)(stamp & 1);
@@ -782,11 +852,11 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
             uint32_t sc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const int v = nsucc[u][b];
-                sc[b] = v >= 0 ? (uint32_t)(gbase + v) : NO_NODE;
-                if (v <= -3) {  // query that did not fit the staging buffer: write it straight out
-                    const uint64_t qi = (uint64_t)(-3 - v);
-                    const uint64_t skey = ((nkey[u] << 2) | (uint64_t)b) & kmask;
+                const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
+                sc[b] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
+                if (v >= 0x8000u && v < 0xFFFEu) {  // query that did not fit the staging buffer: write it straight out
+                    const uint64_t qi = (uint64_t)(v & 0x7FFFu) + CNT_QBUF;
+                    const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
                     out.q_key[qbase + qi] = skey;
                     out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
                 }
@@ -824,7 +894,7 @@ __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ra
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < rg.node_cnt; i += 256) {
         const unsigned long long key = keys[rg.node_base + i];
-        uint32_t slot = slot_hash(key) & (CAP - 1);
+        uint32_t slot = slot_of<CAP>(key);
         for (int probe = 0; probe < CAP; ++probe) {
             const unsigned long long cur = atomicCAS(&s.keys[slot], EMPTY_KEY, key);
             if (cur == EMPTY_KEY) { s.idx[slot] = (uint16_t)i; break; }

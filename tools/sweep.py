@@ -17,7 +17,11 @@ for cfg in configs:
         g.set_option(k, v)
     g.synth_reads(1, int(reads * 150 / 30), reads, 150, err)
     for _ in range(2):
-        g.build(31)
+        try:
+            g.build(31)
+        except _dbg.DbgError as e:
+            if "ablation" not in str(e):
+                raise
     st = g.stats()
     sz = g.sizes()
     print(json.dumps({"cfg": cfg, "extract": round(st["ms_table_init"], 2), "partition": round(st["ms_compact"], 2),
