@@ -90,7 +90,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][2], ar_node[7], ar_misc[8], ar_csr[3], ar_scan;
+    Buf ar_rec[2][3], ar_q[2][2], ar_node[7], ar_misc[9], ar_csr[3], ar_scan;
     // branch k-mer lookup (pull-out reads)
     uint64_t *d_btab = nullptr;
     uint64_t btab_cap = 0;
@@ -1564,25 +1564,58 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         h->stats.ms_table_init = t.stop();  // phase slot re-used: extraction time
     }
 
-    // ---- bucket geometry
+    // ---- bucket geometry.  Level 1 takes up to 9 bits of the bucket hash; the remaining bits are
+    //      chosen after level 1 from a distinct-k-mer estimate on one level-1 bucket (auto mode).
+    constexpr double TARGET_DISTINCT = CAP * 0.27;  // mean distinct k-mers per final bucket (table ~27 % full)
     int T = h->bucket_bits;
-    if (T == 0) {
-        const double want = (double)h->n_kmer_inst * 0.4 / (CAP * 0.375);
+    const bool auto_T = (T == 0);
+    if (auto_T) {  // provisional: assume 40 % of the instances are distinct
+        const double want = (double)h->n_kmer_inst * 0.4 / TARGET_DISTINCT;
         while (T < 18 && (double)(1ull << T) < want) ++T;
     }
-    const int l1 = (T + 1) / 2, l2 = T - l1;
+    int l1 = T < 9 ? T : 9, l2 = T - l1;
+    const int nb1 = 1 << l1;
+    CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+    uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
+    int where = 0;
+    const int top = 6 + SK_BUCKET_BITS;
+    Timer t_part(h->stream);
+    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_wg, true, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+                                    top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+    where = 1;
+    if (auto_T && l1 == 9 && n_rec) {  // refine T from a sample
+        const uint64_t inst_bucket = h->n_kmer_inst / nb1 * 2 + 1024;
+        uint64_t set_cap = 1024;
+        while (set_cap < inst_bucket * 2) set_cap <<= 1;
+        CHK(buf_ensure(h, h->ar_misc[8], set_cap * 8));
+        HIPCHK(h, hipMemsetAsync(h->ar_misc[8].p, 0xFF, set_cap * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_scalars + 40, 0, 16, h->stream));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_estimate_distinct<ST>), dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt,
+                           0u, w0[1], w1[1], k, (unsigned long long *)h->ar_misc[8].p, set_cap - 1,
+                           (unsigned long long *)(h->d_scalars + 40));
+        uint64_t est[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(est, h->d_scalars + 40, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (est[0]) {
+            const double distinct = (double)h->n_kmer_inst * (double)est[1] / (double)est[0];
+            T = 9;
+            while (T < 18 && (double)(1ull << T) < distinct / TARGET_DISTINCT) ++T;
+            l2 = T - l1;
+        }
+    }
     const uint64_t n_buckets = 1ull << T;
-
-    // ---- K2-K4: two-level multisplit of the records
     CHK(buf_ensure(h, h->ar_misc[5], n_buckets * 16));
     uint64_t *b_start = (uint64_t *)h->ar_misc[5].p, *b_cnt = b_start + n_buckets;
-    int where = 0;
-    {
-        Timer t(h->stream);
-        CHK((multisplit_two_level<ST, true>(h, seg_start, seg_cnt, n_wg, n_rec, w0, w1, st, 6, l1, l2, b_start, b_cnt,
-                                            &where)));
-        h->stats.ms_compact = t.stop();  // phase slot re-used: partition time
+    if (l2 > 0) {
+        CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, false, n_rec, w0[1], w1[1], st[1], w0[0], w1[0],
+                                        st[0], top - l1 - l2, 1 << l2, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3],
+                                        h->ar_misc[4])));
+        where = 0;
+    } else {
+        HIPCHK(h, hipMemcpyAsync(b_start, c1_start, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(b_cnt, c1_cnt, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
     }
+    h->stats.ms_compact = t_part.stop();  // phase slot re-used: partition time
 
     // ---- K5: per-bucket counting
     uint64_t node_cap = node_capacity_hint ? node_capacity_hint : h->n_kmer_inst;

@@ -538,6 +538,46 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
 
 
 // ------------------------------------------------------------------------------------------------
+// Distinct-k-mer estimate: the k-mers of ONE level-1 bucket (1/nb1 of the data) go through a small
+// global hash set; distinct / instances of that sample sizes the final bucket count.
+// ------------------------------------------------------------------------------------------------
+template <class ST>
+__global__ __launch_bounds__(256) void k_estimate_distinct(const uint64_t *__restrict__ b_start,
+                                                           const uint64_t *__restrict__ b_cnt, uint32_t bucket,
+                                                           const uint64_t *__restrict__ rec_w0,
+                                                           const uint64_t *__restrict__ rec_w1, int k,
+                                                           unsigned long long *set, uint64_t set_mask,
+                                                           unsigned long long *out /* [0] instances [1] distinct */) {
+    const uint64_t beg = b_start[bucket], n = b_cnt[bucket];
+    uint64_t inst = 0, fresh = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t w0 = rec_w0[beg + r], w1 = rec_w1[beg + r];
+        const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+        const int len = (int)((w1 >> 1) & 31) + 1;
+        for (int i = 0; i < len; ++i) {
+            const uint64_t kmer = (i ? (w0 << (2 * i)) | (hi >> (64 - 2 * i)) : w0) >> (64 - 2 * k);
+            ++inst;
+            uint64_t slot = mix64(kmer) & set_mask;
+            for (uint64_t probe = 0; probe <= set_mask; ++probe) {
+                unsigned long long cur = set[slot];
+                if (cur == EMPTY_KEY) {
+                    cur = atomicCAS(&set[slot], EMPTY_KEY, (unsigned long long)kmer);
+                    if (cur == EMPTY_KEY) { ++fresh; break; }
+                }
+                if (cur == kmer) break;
+                slot = (slot + 1) & set_mask;
+            }
+        }
+    }
+    inst = wave_sum_u64(inst);
+    fresh = wave_sum_u64(fresh);
+    if ((threadIdx.x & 63) == 0) {
+        if (inst) atomicAdd(&out[0], (unsigned long long)inst);
+        if (fresh) atomicAdd(&out[1], (unsigned long long)fresh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5: per-bucket counting in LDS.
 // ------------------------------------------------------------------------------------------------
 struct SkRange {            // one successfully counted (bucket, hash sub-range): consumed by k_q_answer
