@@ -124,7 +124,7 @@ def main():
 
     if rank == 0:
         phases = {key: round(sum(p[key] for p in ms_phases) / len(ms_phases), 3)
-                  for key in ("ms_table_init", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total")}
+                  for key in ("ms_extract", "ms_partition", "ms_count", "ms_succ", "ms_csr", "ms_build_total")}
         out = {
             "metric": "k-mers/s hashed+graph-built at k=31", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -137,10 +137,11 @@ def main():
                        "parallelism": "single table" if world == 1 else f"hash-prefix shard x{world} (RCCL alltoallv)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_count", "ms_per_launch": mean_count_ms,
+                         "kernel": "k_sk_count", "ms_per_launch": mean_count_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_kmer": b_alg(L, k)},
             "phases_ms": phases,
-            "graph": {"n_nodes": sz["n_nodes"], "n_edges": sz["n_edges"], "table_capacity": sz["table_capacity"]},
+            "graph": {"n_nodes": sz["n_nodes"], "n_edges": sz["n_edges"], "n_records": st["n_records"],
+                      "n_buckets": st["n_buckets"], "n_cross_bucket_successors": st["n_queries"]},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed, genome_len, L, k, args.err,

@@ -77,9 +77,9 @@ typedef struct dbg_sizes {
 typedef struct dbg_stats {
     /* device time of each phase of the last call, milliseconds (HIP events on the handle's stream) */
     double ms_startbits;  /* read-start bitmap */
-    double ms_table_init; /* hash table clear */
+    double ms_table_init; /* engine 1: hash table clear */
     double ms_count;      /* encode + hash insert + edge counters (dominant kernel) */
-    double ms_compact;    /* occupied slots -> node arrays */
+    double ms_compact;    /* engine 1: occupied slots -> node arrays */
     double ms_succ;       /* successor lookup -> 4-way adjacency */
     double ms_csr;        /* degree scan + CSR fill */
     double ms_build_total;
@@ -88,7 +88,12 @@ typedef struct dbg_stats {
     double ms_pull_reads;
     double ms_walk;
     double ms_h2d;        /* dbg_set_reads copy */
+    double ms_extract;    /* engine 0: reads -> super-k-mer records (k_sk_extract) */
+    double ms_partition;  /* engine 0: two-level multisplit of the records */
     uint64_t count_launches; /* launches of the dominant kernel in the last dbg_build */
+    uint64_t n_records;      /* engine 0: super-k-mer records */
+    uint64_t n_buckets;      /* engine 0: final buckets */
+    uint64_t n_queries;      /* engine 0: successors resolved across buckets */
 } dbg_stats_t;
 
 /* ---- lifetime ---------------------------------------------------------- */

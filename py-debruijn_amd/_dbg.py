@@ -41,7 +41,8 @@ class Sizes(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "ms_startbits", "ms_table_init", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total", "ms_prune",
-        "ms_tips", "ms_pull_reads", "ms_walk", "ms_h2d")] + [("count_launches", C.c_uint64)]
+        "ms_tips", "ms_pull_reads", "ms_walk", "ms_h2d", "ms_extract", "ms_partition")] + [
+        (n, C.c_uint64) for n in ("count_launches", "n_records", "n_buckets", "n_queries")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1561,7 +1561,8 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
             h->n_kmer_inst += hseg[2 * n_wg + g];
             h->n_edge_inst += hseg[3 * n_wg + g];
         }
-        h->stats.ms_table_init = t.stop();  // phase slot re-used: extraction time
+        h->stats.ms_extract = t.stop();
+        h->stats.n_records = n_rec;
     }
 
     // ---- bucket geometry.  Level 1 takes up to 9 bits of the bucket hash; the remaining bits are
@@ -1615,7 +1616,8 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         HIPCHK(h, hipMemcpyAsync(b_start, c1_start, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(b_cnt, c1_cnt, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
     }
-    h->stats.ms_compact = t_part.stop();  // phase slot re-used: partition time
+    h->stats.ms_partition = t_part.stop();
+    h->stats.n_buckets = n_buckets;
 
     // ---- K5: per-bucket counting
     uint64_t node_cap = node_capacity_hint ? node_capacity_hint : h->n_kmer_inst;
@@ -1674,6 +1676,7 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
     h->n_nodes = sc[4] & 0xFFFFFFFFull;
     const uint64_t n_q = sc[4] >> 32, n_ranges = n_buckets + sc[6];
+    h->stats.n_queries = n_q;
 
     // ---- K6-K8: successors that live in another bucket
     {

@@ -1,0 +1,73 @@
+"""Parity at sizes the Python oracle cannot reach: against the C oracle at 1M reads, and through
+size-independent properties at the full BASELINE.json configs[1] size (10M x 150 bp, k = 31)."""
+import numpy as np
+import pytest
+
+import _dbg
+import synth
+from oracle import orc_c
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_million_reads_vs_c_oracle():
+    n, L, k = 1_000_000, 150, 31
+    reads = synth.reads_ascii(1, 5_000_000, n, L, 0.01)
+    off = np.arange(0, reads.size + 1, L, dtype=np.uint64)
+    want = orc_c.build(reads.reshape(-1), off, k)
+    g = _dbg.Graph()
+    g.synth_reads(1, 5_000_000, n, L, 0.01)              # device twin of the generator
+    assert g.reads_checksum() == synth.checksum(reads)
+    g.build(k)
+    keys, stamps, counts, flags = g.export_nodes()
+    o = np.argsort(stamps, kind="stable")
+    assert g.sizes()["n_nodes"] == want["n_nodes"]
+    assert np.array_equal(keys[o], want["keys"])
+    assert np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(counts[o], want["counts"])
+    succ = g.export_succ()
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for code in range(4):
+        has = counts[:, code] != 0
+        assert np.array_equal(keys[succ[has, code]], ((keys[has] << np.uint64(2)) | np.uint64(code)) & mask)
+
+
+@pytest.mark.parametrize("err", [0.0, 0.01])
+def test_full_size_invariants(err):
+    """10M x 150 bp, k = 31: properties that hold whatever the size."""
+    n, L, k, G = 10_000_000, 150, 31, 50_000_000
+    g = _dbg.Graph()
+    g.synth_reads(1, G, n, L, err)
+    g.build(k)
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == n * (L - k + 1)
+    assert sz["n_edge_instances"] == n * (L - k)
+    keys, stamps, counts, flags = g.export_nodes()
+    assert int(counts.sum(dtype=np.uint64)) == sz["n_edge_instances"]        # every (k+1)-mer instance counted once
+    assert sz["n_edges"] == int((counts != 0).sum())
+    assert np.unique(keys).size == keys.size                                  # nodes are distinct k-mers
+    assert np.unique(stamps).size == stamps.size                              # first occurrences are distinct positions
+    pos = stamps >> np.uint64(1)
+    assert np.array_equal((stamps & np.uint64(1)) == 0, pos % np.uint64(L) == 0)  # indegree 0 <=> read position 0
+    assert sz["n_starts"] == int(((stamps & np.uint64(1)) == 0).sum())
+    # the first occurrence really holds the k-mer: re-encode it from the reads on the host
+    reads, _ = g.copy_reads()
+    idx = np.linspace(0, keys.size - 1, 20000).astype(np.int64)
+    code = ((reads[(pos[idx][:, None] + np.arange(k, dtype=np.uint64)[None, :]).astype(np.int64)] >> 1) & 3).astype(np.uint64)
+    shifts = (2 * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
+    assert np.array_equal((code << shifts[None, :]).sum(axis=1, dtype=np.uint64), keys[idx])
+    if err == 0.0:
+        # an error-free read set holds exactly the genome's k-mers that the reads cover
+        assert sz["n_nodes"] <= G - k + 1
+    # successor ids are consistent with the shifted key (all edges)
+    succ = g.export_succ()
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for c in range(4):
+        has = counts[:, c] != 0
+        assert np.array_equal(keys[succ[has, c]], ((keys[has] << np.uint64(2)) | np.uint64(c)) & mask)
+    # building again on the same handle gives the same table (order may differ)
+    g.build(k)
+    keys2, stamps2, counts2, _ = g.export_nodes()
+    a, b = np.argsort(keys), np.argsort(keys2)
+    assert np.array_equal(keys[a], keys2[b]) and np.array_equal(stamps[a], stamps2[b])
+    assert np.array_equal(counts[a], counts2[b])

@@ -24,7 +24,8 @@ for cfg in configs:
                 raise
     st = g.stats()
     sz = g.sizes()
-    print(json.dumps({"cfg": cfg, "extract": round(st["ms_table_init"], 2), "partition": round(st["ms_compact"], 2),
+    print(json.dumps({"cfg": cfg, "extract": round(st["ms_extract"], 2), "partition": round(st["ms_partition"], 2),
                       "count": round(st["ms_count"], 2), "succ": round(st["ms_succ"], 2), "csr": round(st["ms_csr"], 2),
-                      "total": round(st["ms_build_total"], 2), "n_nodes": sz["n_nodes"]}), flush=True)
+                      "total": round(st["ms_build_total"], 2), "n_nodes": sz["n_nodes"], "buckets": st["n_buckets"],
+                      "records": st["n_records"], "queries": st["n_queries"]}), flush=True)
     g.close()
