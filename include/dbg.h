@@ -159,6 +159,28 @@ int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint64_t *score
 int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const void **d_stamps,
                      const void **d_flags, const void **d_succ);
 
+/* ---- multi-GPU: hash-prefix sharding (no reference counterpart: the reference is one process).
+ *      One handle per rank; the caller moves the buffers between ranks (RCCL all-to-all).  Owner
+ *      shard of a k-mer = top log2(n_shards) bits of its minimizer bucket hash; n_shards in {1,2,4,8}.
+ *      After dbg_shard_apply the handle holds the shard's nodes; successor ids are
+ *      (owner shard << 29) | node id on that shard; stamps are global ((byte offset in the
+ *      rank-major concatenation of all reads) << 1 | pos != 0). */
+/* step 1: this rank's reads -> super-k-mer records grouped by owner (device arrays: w0, w1 uint64,
+ * st uint32); send_counts[n_shards] records go to each owner, contiguous and in owner order */
+int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
+                      const void **d_st);
+/* step 2: records received from rank r are recv_counts[r] consecutive entries (rank order);
+ * stamp_base[r] = bytes of reads held by ranks < r.  Builds the shard's node table.  Successor
+ * k-mers owned by other shards: device array *d_q_keys (uint64), group of owner d at
+ * [q_starts[d], q_starts[d] + q_counts[d]) */
+int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w0, const void *d_w1, const void *d_st32,
+                    const uint64_t *recv_counts, const uint64_t *stamp_base, uint64_t *q_starts, uint64_t *q_counts,
+                    const void **d_q_keys);
+/* step 3: node ids (uint32, device) of n successor k-mers other ranks asked this shard about */
+int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void *d_answers);
+/* step 4: d_answers (uint32, device) laid out like *d_q_keys of step 2; completes successors + CSR */
+int dbg_shard_apply(dbg_t *h, const void *d_answers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ SYMBOLS = (
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs", "dbg_device_views",
+    "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
 )
 
 
@@ -98,6 +99,10 @@ def load_library():
         "dbg_export_pull_reads": (C.c_int, [H, vp]),
         "dbg_export_contigs": (C.c_int, [H, vp, vp, vp, vp, vp]),
         "dbg_device_views": (C.c_int, [H] + [C.POINTER(vp)] * 5),
+        "dbg_shard_extract": (C.c_int, [H, C.c_int, C.c_int, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
+        "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
+        "dbg_shard_apply": (C.c_int, [H, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -126,7 +131,8 @@ class Graph:
     def __init__(self, device=None):
         self._lib = load_library()
         self._h = C.c_void_p()
-        rc = self._lib.dbg_create(default_device() if device is None else int(device), C.byref(self._h))
+        self._device_index = default_device() if device is None else int(device)
+        rc = self._lib.dbg_create(self._device_index, C.byref(self._h))
         if rc != DBG_OK:
             self._h = None
             raise DbgError(rc, "dbg_create failed: no usable MI355X visible (the device path has no CPU fallback)")
@@ -254,6 +260,63 @@ class Graph:
         seq = np.empty(n, dtype=np.uint32)
         self._chk(self._lib.dbg_export_contigs(self._h, _ptr(off), _ptr(chars), _ptr(score), _ptr(stamp), _ptr(seq)))
         return off, chars, score, stamp, seq
+
+
+    # ---- multi-GPU sharding (buffers are torch tensors on this handle's device; see multi_gpu.py)
+    def shard_extract(self, k, n_shards):
+        """-> (send_counts list, (w0, w1, st) tensors viewing library memory, grouped by owner)."""
+        counts = (C.c_uint64 * n_shards)()
+        p0, p1, p2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self._lib.dbg_shard_extract(self._h, int(k), int(n_shards), counts, C.byref(p0), C.byref(p1),
+                                              C.byref(p2)))
+        counts = [int(c) for c in counts]
+        n = sum(counts)
+        dev = self.sizes_device()
+        return counts, (device_tensor(p0.value, n, "int64", dev), device_tensor(p1.value, n, "int64", dev),
+                        device_tensor(p2.value, n, "int32", dev))
+
+    def sizes_device(self):
+        return getattr(self, "_device_index", default_device())
+
+    def shard_build(self, k, n_shards, my_shard, w0, w1, st, recv_counts, stamp_base):
+        """Received records (torch tensors) -> (q_starts, q_counts, query key tensor grouped by owner)."""
+        rc = (C.c_uint64 * n_shards)(*[int(x) for x in recv_counts])
+        sb = (C.c_uint64 * n_shards)(*[int(x) for x in stamp_base])
+        qs, qc = (C.c_uint64 * n_shards)(), (C.c_uint64 * n_shards)()
+        pk = C.c_void_p()
+        self._keep = [w0, w1, st]
+        self._chk(self._lib.dbg_shard_build(self._h, int(k), int(n_shards), int(my_shard), C.c_void_p(w0.data_ptr()),
+                                            C.c_void_p(w1.data_ptr()), C.c_void_p(st.data_ptr()), rc, sb, qs, qc,
+                                            C.byref(pk)))
+        self._keep = []
+        qs, qc = [int(x) for x in qs], [int(x) for x in qc]
+        total = max([a + b for a, b in zip(qs, qc)] + [0])
+        return qs, qc, device_tensor(pk.value, total, "int64", self.sizes_device())
+
+    def shard_answer(self, keys):
+        import torch
+        ans = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
+        self._chk(self._lib.dbg_shard_answer(self._h, C.c_void_p(keys.data_ptr()), keys.numel(),
+                                             C.c_void_p(ans.data_ptr())))
+        return ans
+
+    def shard_apply(self, answers):
+        self._chk(self._lib.dbg_shard_apply(self._h, C.c_void_p(answers.data_ptr()) if answers.numel() else None))
+
+
+class _DevView:
+    """Zero-copy torch view of library-owned device memory (``__cuda_array_interface__``)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def device_tensor(ptr, n, dtype, device_index):
+    import torch
+    tdtype = {"int64": torch.int64, "int32": torch.int32}[dtype]
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=tdtype, device=f"cuda:{device_index}")
+    return torch.as_tensor(_DevView(ptr, n, {"int64": "<i8", "int32": "<i4"}[dtype]), device=f"cuda:{device_index}")
 
 
 # ---- 2-bit key <-> str helpers (host side of the boundary) -------------------------------

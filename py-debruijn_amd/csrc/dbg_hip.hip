@@ -90,13 +90,25 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][2], ar_node[7], ar_misc[9], ar_csr[3], ar_scan;
+    Buf ar_rec[2][3], ar_q[2][2], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4];
+    int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
+    uint64_t sk_n_ranges = 0;
+    void *shard_state = nullptr;  // ShardState (multi-GPU builds)
     // branch k-mer lookup (pull-out reads)
     uint64_t *d_btab = nullptr;
     uint64_t btab_cap = 0;
 
     dbg_stats_t stats{};
 };
+
+// What a sharded build leaves behind for the exchange of successors owned by other ranks.
+struct ShardState {
+    int n_shards = 0, my_shard = 0, shard_bits = 0, k = 0;
+    std::vector<uint64_t> q_start, q_cnt;   // remote queries grouped by owner (own group: count 0)
+    uint64_t n_remote = 0;
+    uint64_t n_kmer_inst_local = 0;          // k-mer instances of the reads this rank extracted
+};
+static ShardState &shard_of(dbg *h);
 
 static int buf_ensure(dbg *h, dbg::Buf &b, uint64_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -892,8 +904,10 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_node) buf_free(b);
     for (auto &b : h->ar_misc) buf_free(b);
     for (auto &b : h->ar_csr) buf_free(b);
+    for (auto &b : h->ar_shard) buf_free(b);
     buf_free(h->ar_scan);
     dev_free(h->d_scalars);
+    delete (ShardState *)h->shard_state;
     (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1499,81 +1513,99 @@ static int multisplit_two_level(dbg *h, const uint64_t *seg_start, const uint64_
     return DBG_OK;
 }
 
-template <class ST, int CAP>
-static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
+// ---- stage 1: K1 extraction into one private segment per persistent workgroup (arena set 0)
+template <class ST>
+static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], uint64_t **seg_start_out,
+                      uint64_t **seg_cnt_out, uint32_t *n_seg_out, uint64_t *n_rec_out) {
     const int m = sk_m_for_k(k), w = k - m + 1;
     unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
     const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
     uint64_t sc[8] = {0};
-    uint64_t *w0[2], *w1[2];
-    ST *st[2];
-    // ---- K1: extraction into one private segment per persistent workgroup
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 2048);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
     uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg,
              *seg_ne = seg_nk + n_wg;
     std::vector<uint64_t> hseg((size_t)n_wg * 4);
     uint64_t n_rec = 0;
-    {
-        Timer t(h->stream);
-        const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
-        uint64_t seg_cap = (w == 1) ? tiles_per_wg * TILE : tiles_per_wg * (TILE / 3 + 8) + 256;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const uint64_t rec_cap = seg_cap * n_wg;
-            for (int set = 0; set < 2; ++set) {
-                CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
-                CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
-                CHK(buf_ensure(h, h->ar_rec[set][2], rec_cap * sizeof(ST)));
-                w0[set] = (uint64_t *)h->ar_rec[set][0].p;
-                w1[set] = (uint64_t *)h->ar_rec[set][1].p;
-                st[set] = (ST *)h->ar_rec[set][2].p;
-            }
-            for (uint32_t g = 0; g < n_wg; ++g) hseg[g] = (uint64_t)g * seg_cap;
-            HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
-            HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
-            if (tiles) {
-                if (m == SK_MAX_M && w == 19)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 19>), dim3(n_wg), dim3(256), 0, h->stream,
-                                       h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap,
-                                       seg_cnt, seg_nk, seg_ne, sc_dev);
-                else if (m == SK_MAX_M && w == 9)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 9>), dim3(n_wg), dim3(256), 0, h->stream,
-                                       h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap,
-                                       seg_cnt, seg_nk, seg_ne, sc_dev);
-                else
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream,
-                                       h->d_bases, h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap,
-                                       seg_cnt, seg_nk, seg_ne, sc_dev);
-                HIPCHK(h, hipGetLastError());
-            }
-            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
-            if (!(sc[0] & 4)) break;
-            if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
-            seg_cap = tiles_per_wg * TILE;  // one record per position: cannot overflow
+    Timer t(h->stream);
+    const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
+    uint64_t seg_cap = (w == 1) ? tiles_per_wg * TILE : tiles_per_wg * (TILE / 3 + 8) + 256;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint64_t rec_cap = seg_cap * n_wg;
+        for (int set = 0; set < 2; ++set) {
+            CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
+            CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
+            CHK(buf_ensure(h, h->ar_rec[set][2], rec_cap * sizeof(ST)));
+            w0[set] = (uint64_t *)h->ar_rec[set][0].p;
+            w1[set] = (uint64_t *)h->ar_rec[set][1].p;
+            st[set] = (ST *)h->ar_rec[set][2].p;
         }
-        h->n_kmer_inst = h->n_edge_inst = 0;
-        for (uint32_t g = 0; g < n_wg; ++g) {
-            n_rec += hseg[n_wg + g];
-            h->n_kmer_inst += hseg[2 * n_wg + g];
-            h->n_edge_inst += hseg[3 * n_wg + g];
+        for (uint32_t g = 0; g < n_wg; ++g) hseg[g] = (uint64_t)g * seg_cap;
+        HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+        if (tiles) {
+            if (m == SK_MAX_M && w == 19)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 19>), dim3(n_wg), dim3(256), 0, h->stream,
+                                   h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt,
+                                   seg_nk, seg_ne, sc_dev);
+            else if (m == SK_MAX_M && w == 9)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 9>), dim3(n_wg), dim3(256), 0, h->stream,
+                                   h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt,
+                                   seg_nk, seg_ne, sc_dev);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases,
+                                   h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk,
+                                   seg_ne, sc_dev);
+            HIPCHK(h, hipGetLastError());
         }
-        h->stats.ms_extract = t.stop();
-        h->stats.n_records = n_rec;
+        HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
+        if (!(sc[0] & 4)) break;
+        if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
+        seg_cap = tiles_per_wg * TILE;  // one record per position: cannot overflow
     }
+    h->n_kmer_inst = h->n_edge_inst = 0;
+    for (uint32_t g = 0; g < n_wg; ++g) {
+        n_rec += hseg[n_wg + g];
+        h->n_kmer_inst += hseg[2 * n_wg + g];
+        h->n_edge_inst += hseg[3 * n_wg + g];
+    }
+    h->stats.ms_extract = t.stop();
+    h->stats.n_records = n_rec;
+    *seg_start_out = seg_start;
+    *seg_cnt_out = seg_cnt;
+    *n_seg_out = n_wg;
+    *n_rec_out = n_rec;
+    return DBG_OK;
+}
 
+
+// ---- stages 2..: records given as segments of (in_w0, in_w1, in_st) -> node arrays + successors.
+// The ping-pong sets w0/w1/st (arena) must hold n_rec records; n_inst bounds the distinct k-mers.
+// shard_bits > 0: only buckets whose top shard_bits equal my_shard hold records (the caller made
+// sure); successors owned by other shards are left as remote queries in ar_shard[0..1].
+template <class ST, int CAP>
+static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
+                                  uint64_t n_rec, uint64_t n_inst, uint64_t n_edge_inst, const uint64_t *in_w0,
+                                  const uint64_t *in_w1, const ST *in_st, uint64_t *w0[2], uint64_t *w1[2], ST *st[2],
+                                  uint64_t node_capacity_hint, int shard_bits, int my_shard) {
+    const int m = sk_m_for_k(k);
+    unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
+    uint64_t sc[8] = {0};
     // ---- bucket geometry.  Level 1 takes up to 9 bits of the bucket hash; the remaining bits are
     //      chosen after level 1 from a distinct-k-mer estimate on one level-1 bucket (auto mode).
     constexpr double TARGET_DISTINCT = CAP * 0.27;  // mean distinct k-mers per final bucket (table ~27 % full)
+    const double own = shard_bits ? (double)(1 << shard_bits) : 1.0;  // buckets are spread over `own` shards
     int T = h->bucket_bits;
     const bool auto_T = (T == 0);
     if (auto_T) {  // provisional: assume 40 % of the instances are distinct
-        const double want = (double)h->n_kmer_inst * 0.4 / TARGET_DISTINCT;
+        const double want = (double)n_inst * own * 0.4 / TARGET_DISTINCT;
         while (T < 18 && (double)(1ull << T) < want) ++T;
     }
+    if (T < shard_bits) T = shard_bits;
     int l1 = T < 9 ? T : 9, l2 = T - l1;
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
@@ -1581,24 +1613,25 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     int where = 0;
     const int top = 6 + SK_BUCKET_BITS;
     Timer t_part(h->stream);
-    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_wg, true, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, true, n_rec, in_w0, in_w1, in_st, w0[1], w1[1], st[1],
                                     top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
     where = 1;
-    if (auto_T && l1 == 9 && n_rec) {  // refine T from a sample
-        const uint64_t inst_bucket = h->n_kmer_inst / nb1 * 2 + 1024;
+    if (auto_T && l1 == 9 && n_rec) {  // refine T from a sample: the first level-1 bucket this shard owns
+        const uint32_t probe_bucket = shard_bits ? (uint32_t)my_shard << (9 - shard_bits) : 0u;
+        const uint64_t inst_bucket = (uint64_t)((double)n_inst * own / nb1) * 2 + 1024;
         uint64_t set_cap = 1024;
         while (set_cap < inst_bucket * 2) set_cap <<= 1;
         CHK(buf_ensure(h, h->ar_misc[8], set_cap * 8));
         HIPCHK(h, hipMemsetAsync(h->ar_misc[8].p, 0xFF, set_cap * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_scalars + 40, 0, 16, h->stream));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_estimate_distinct<ST>), dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt,
-                           0u, w0[1], w1[1], k, (unsigned long long *)h->ar_misc[8].p, set_cap - 1,
+                           probe_bucket, w0[1], w1[1], k, (unsigned long long *)h->ar_misc[8].p, set_cap - 1,
                            (unsigned long long *)(h->d_scalars + 40));
         uint64_t est[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(est, h->d_scalars + 40, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (est[0]) {
-            const double distinct = (double)h->n_kmer_inst * (double)est[1] / (double)est[0];
+            const double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
             T = 9;
             while (T < 18 && (double)(1ull << T) < distinct / TARGET_DISTINCT) ++T;
             l2 = T - l1;
@@ -1620,8 +1653,9 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     h->stats.n_buckets = n_buckets;
 
     // ---- K5: per-bucket counting
-    uint64_t node_cap = node_capacity_hint ? node_capacity_hint : h->n_kmer_inst;
-    if (node_cap > 0xFFFFFFF0ull) node_cap = 0xFFFFFFF0ull;
+    uint64_t node_cap = node_capacity_hint ? node_capacity_hint : n_inst;
+    const uint64_t id_limit = shard_bits ? ((1ull << 29) - 16) : 0xFFFFFFF0ull;  // sharded ids carry the owner in bits 31:29
+    if (node_cap > id_limit) node_cap = id_limit;
     CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
     CHK(buf_ensure(h, h->ar_node[1], node_cap * 8));
     CHK(buf_ensure(h, h->ar_node[2], node_cap * 16));
@@ -1639,7 +1673,7 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
     h->nodes_in_arena = true;
     uint64_t q_cap = n_rec + 1024;
     uint64_t *qk[2], *qm[2];
-    const uint64_t range_cap = n_buckets + 4096 + h->n_kmer_inst / (CAP / 4);
+    const uint64_t range_cap = n_buckets + 4096 + n_inst / (CAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1668,29 +1702,58 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         if (h->phase_limit) { h->err = "ablation run (phase_limit set): timing only"; return DBG_E_ARG; }
         // buckets that had to be split by hash sub-range turn in-bucket successors into queries:
         // the usual bound (one query per record) no longer holds, retry with the safe one
-        if ((sc[0] & 64) && !(sc[0] & (8 | 16 | 32)) && attempt == 0) { q_cap = h->n_edge_inst + 1024; continue; }
+        if ((sc[0] & 64) && !(sc[0] & (8 | 16 | 32)) && attempt == 0) { q_cap = n_edge_inst + 1024; continue; }
         break;
     }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node capacity exceeded"; return DBG_E_CAPACITY; }
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
     h->n_nodes = sc[4] & 0xFFFFFFFFull;
-    const uint64_t n_q = sc[4] >> 32, n_ranges = n_buckets + sc[6];
+    uint64_t n_q = sc[4] >> 32;
+    const uint64_t n_ranges = n_buckets + sc[6];
     h->stats.n_queries = n_q;
 
-    // ---- K6-K8: successors that live in another bucket
+    // ---- K6-K8: successors that live in another bucket (of this shard: answered here; of another
+    //      shard: grouped by owner and parked for the exchange)
     {
         Timer t(h->stream);
-        if (n_q) {
-            CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 16));
-            uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets;
-            uint64_t *q_seg = q_cnt + n_buckets;  // one input segment: [0, n_q)
-            const uint64_t root[2] = {0, n_q};
+        CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 64 * 16 + 16));
+        uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets;
+        uint64_t *q_seg = q_cnt + n_buckets;  // [0..1]: one input segment; [2..]: per-owner children
+        uint64_t root[2] = {0, n_q};
+        int qset = 0;
+        uint32_t *dummy[2] = {nullptr, nullptr};
+        if (shard_bits && n_q) {  // group by owner shard = top shard_bits of the bucket hash
+            const int nsh = 1 << shard_bits;
             HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
-            uint32_t *dummy[2] = {nullptr, nullptr};
+            uint64_t *o_start = q_seg + 2, *o_cnt = o_start + nsh;
+            CHK((multisplit_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, true, n_q, qk[0], qm[0], dummy[0], qk[1], qm[1],
+                                                   dummy[1], 40 + SK_BUCKET_BITS - shard_bits, nsh, o_start, o_cnt,
+                                                   h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+            ShardState &sh = shard_of(h);
+            sh.q_start.assign(nsh, 0);
+            sh.q_cnt.assign(nsh, 0);
+            HIPCHK(h, hipMemcpyAsync(sh.q_start.data(), o_start, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(sh.q_cnt.data(), o_cnt, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            // park everything (keys + metas, grouped by owner) before the local group is shuffled further
+            CHK(buf_ensure(h, h->ar_shard[0], n_q * 8));
+            CHK(buf_ensure(h, h->ar_shard[1], n_q * 8));
+            HIPCHK(h, hipMemcpyAsync(h->ar_shard[0].p, qk[1], n_q * 8, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->ar_shard[1].p, qm[1], n_q * 8, hipMemcpyDeviceToDevice, h->stream));
+            root[0] = sh.q_start[my_shard];
+            root[1] = sh.q_cnt[my_shard];
+            sh.n_remote = n_q - root[1];
+            sh.q_cnt[my_shard] = 0;  // what is left in the lists is remote
+            n_q = root[1];
+            qset = 1;
+        }
+        if (n_q) {
+            HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
+            uint64_t *qk2[2] = {qk[qset], qk[qset ^ 1]}, *qm2[2] = {qm[qset], qm[qset ^ 1]};
             int qwhere = 0;
             if (T > 0) {
-                CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n_q, qk, qm, dummy, 40, l1, l2, q_start,
+                CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n_q, qk2, qm2, dummy, 40, l1, l2, q_start,
                                                            q_cnt, &qwhere)));
             } else {
                 HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
@@ -1700,7 +1763,7 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
             const size_t lds = sizeof(AnsLds<CAP>);
             HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt,
-                               qk[qwhere], qm[qwhere], h->d_keys, h->d_succ, sc_dev);
+                               qk2[qwhere], qm2[qwhere], h->d_keys, h->d_succ, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1708,13 +1771,253 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
         }
         h->stats.ms_succ = t.stop();
     }
+    // geometry the answer stage of a sharded build needs again
+    h->sk_T = T; h->sk_l1 = l1; h->sk_l2 = l2; h->sk_n_ranges = n_ranges; h->sk_cap = CAP;
     return DBG_OK;
+}
+
+template <class ST, int CAP>
+static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
+    uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
+    ST *st[2];
+    uint32_t n_seg = 0;
+    CHK(sk_extract<ST>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    return sk_count_from_segments<ST, CAP>(h, k, seg_start, seg_cnt, n_seg, n_rec, h->n_kmer_inst, h->n_edge_inst, w0[0],
+                                           w1[0], st[0], w0, w1, st, node_capacity_hint, 0, 0);
 }
 
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint) {
     const bool small = (h->n_bytes < (1ull << 31));
-    // 64-bit stamps (inputs of 2 GiB and more) only fit the 160 KiB LDS with the 2048-slot table
-    if (!small) return build_sk_t<uint64_t, 2048>(h, k, node_capacity_hint);
+    // 64-bit stamps (inputs of 2 GiB and more, or a sharded build) use the smaller record staging
+    if (!small) return build_sk_t<uint64_t, 4096>(h, k, node_capacity_hint);
     if (h->lds_slots == 2048) return build_sk_t<uint32_t, 2048>(h, k, node_capacity_hint);
     return build_sk_t<uint32_t, 4096>(h, k, node_capacity_hint);
+}
+
+// ==========================================================================================
+// multi-GPU: hash-prefix sharding of the super-k-mer records.
+// One handle per rank.  The caller (py-debruijn_amd/multi_gpu.py) moves the buffers between
+// ranks with RCCL all-to-all; nothing here talks to another device.
+//   dbg_shard_extract : reads of this rank -> records grouped by owner shard (top bits of the
+//                       minimizer bucket hash), counts per owner
+//   dbg_shard_build   : records received from all ranks (32-bit rank-local stamps are rebased to
+//                       global 64-bit ones) -> node table of the buckets this shard owns;
+//                       successors owned by other shards come back as queries grouped by owner
+//   dbg_shard_answer  : node ids for the successor k-mers other ranks asked about
+//   dbg_shard_apply   : answers -> successor arrays; node ids become (owner << 29) | local id
+// ==========================================================================================
+static ShardState &shard_of(dbg *h) {
+    if (!h->shard_state) h->shard_state = new ShardState();
+    return *(ShardState *)h->shard_state;
+}
+
+__global__ __launch_bounds__(256) void k_stamp_globalize(const uint32_t *__restrict__ st32, uint64_t n, uint64_t base2,
+                                                         uint64_t *st64) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st64[i] = base2 + st32[i];  // ((base + p) << 1) | flag == (base << 1) + ((p << 1) | flag)
+}
+
+struct RecLen {
+    const uint64_t *w1;
+    __device__ uint64_t operator()(uint64_t i) const { return ((w1[i] >> 1) & 31) + 1; }
+};
+struct RecEdges {
+    const uint64_t *w1;
+    __device__ uint64_t operator()(uint64_t i) const { return ((w1[i] >> 1) & 31) + (w1[i] & 1); }
+};
+
+__global__ __launch_bounds__(256) void k_q_prepare(const uint64_t *__restrict__ keys, uint64_t n, int k, int m,
+                                                   uint64_t *meta) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) meta[i] = ((uint64_t)kmer_bucket22(keys[i], k, m) << 40) | i;
+}
+
+__global__ __launch_bounds__(256) void k_tag_local(uint32_t *succ, uint64_t n, uint32_t tag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && succ[i] != NO_NODE) succ[i] |= tag;
+}
+
+__global__ __launch_bounds__(256) void k_apply_remote(const uint64_t *__restrict__ meta, const uint32_t *__restrict__ ans,
+                                                      uint64_t n, uint32_t tag, uint32_t *succ,
+                                                      unsigned long long *scalars) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = ans[i];
+    if (a == NO_NODE || a >= (1u << 29)) { atomicOr(&scalars[0], 256ull); return; }
+    succ[meta[i] & ((1ull << 40) - 1)] = tag | a;
+}
+
+static int shard_args_ok(dbg *h, int k, int n_shards) {
+    if (!h) return DBG_E_ARG;
+    if (k < 1 || k > 31) { h->err = "k must be in 1..31"; return DBG_E_ARG; }
+    if (n_shards < 1 || n_shards > 8 || (n_shards & (n_shards - 1))) {
+        h->err = "n_shards must be 1, 2, 4 or 8 (owner = top bits of the bucket hash; node ids keep 29 bits)";
+        return DBG_E_ARG;
+    }
+    if (h->engine != 0) { h->err = "sharded builds use the super-k-mer engine"; return DBG_E_ARG; }
+    return DBG_OK;
+}
+
+extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0,
+                                 const void **d_w1, const void **d_st) {
+    CHK(shard_args_ok(h, k, n_shards));
+    if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
+    if (h->n_bytes >= (1ull << 31)) { h->err = "a shard's reads must stay below 2 GiB (32-bit local stamps)"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    free_build(h);
+    h->stats = dbg_stats_t{};
+    uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
+    uint32_t *st[2];
+    uint32_t n_seg = 0;
+    CHK(sk_extract<uint32_t>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    // group by the 9 top bits of the bucket hash: owners are contiguous ranges of those 512 groups
+    const int nb1 = 512;
+    CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+    uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
+    Timer t(h->stream);
+    CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, true, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
+                                          st[1], 6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2],
+                                          h->ar_misc[3], h->ar_misc[4])));
+    std::vector<uint64_t> cnt(nb1);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
+    h->stats.ms_partition = t.stop();
+    for (int d = 0; d < n_shards; ++d) {
+        send_counts[d] = 0;
+        for (int b = d * nb1 / n_shards; b < (d + 1) * nb1 / n_shards; ++b) send_counts[d] += cnt[b];
+    }
+    *d_w0 = w0[1];
+    *d_w1 = w1[1];
+    *d_st = st[1];
+    ShardState &sh = shard_of(h);
+    sh.n_shards = n_shards;
+    sh.k = k;
+    sh.n_kmer_inst_local = h->n_kmer_inst;
+    return DBG_OK;
+}
+
+extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w0, const void *d_w1,
+                               const void *d_st32, const uint64_t *recv_counts, const uint64_t *stamp_base,
+                               uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys) {
+    CHK(shard_args_ok(h, k, n_shards));
+    if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !q_starts || !q_counts || !d_q_keys)
+        return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    int shard_bits = 0;
+    while ((1 << shard_bits) < n_shards) ++shard_bits;
+    uint64_t n_rec = 0;
+    std::vector<uint64_t> seg((size_t)n_shards * 2);
+    for (int r = 0; r < n_shards; ++r) { seg[r] = n_rec; seg[n_shards + r] = recv_counts[r]; n_rec += recv_counts[r]; }
+    CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_shards * 16));
+    uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_shards;
+    HIPCHK(h, hipMemcpyAsync(seg_start, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, h->stream));
+    // arena sets for 64-bit stamps; the rebased stamps of the received records go to ar_shard[2]
+    uint64_t *w0[2], *w1[2], *st[2];
+    for (int set = 0; set < 2; ++set) {
+        CHK(buf_ensure(h, h->ar_rec[set][0], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_rec[set][1], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_rec[set][2], (n_rec + 16) * 8));
+        w0[set] = (uint64_t *)h->ar_rec[set][0].p;
+        w1[set] = (uint64_t *)h->ar_rec[set][1].p;
+        st[set] = (uint64_t *)h->ar_rec[set][2].p;
+    }
+    CHK(buf_ensure(h, h->ar_shard[2], (n_rec + 16) * 8));
+    uint64_t *st64 = (uint64_t *)h->ar_shard[2].p;
+    for (int r = 0; r < n_shards; ++r) {
+        if (!recv_counts[r]) continue;
+        hipLaunchKernelGGL(k_stamp_globalize, dim3(grid_for(recv_counts[r], 256)), dim3(256), 0, h->stream,
+                           (const uint32_t *)d_st32 + seg[r], recv_counts[r], stamp_base[r] << 1, st64 + seg[r]);
+    }
+    HIPCHK(h, hipGetLastError());
+    uint64_t n_inst = 0, n_edge = 0;
+    CHK(reduce_sum(h, n_rec, RecLen{(const uint64_t *)d_w1}, &n_inst));
+    CHK(reduce_sum(h, n_rec, RecEdges{(const uint64_t *)d_w1}, &n_edge));
+    h->k = k;
+    h->stats.n_records = n_rec;
+    Timer t_total(h->stream);
+    ShardState &sh = shard_of(h);
+    sh.n_shards = n_shards; sh.my_shard = my_shard; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
+    sh.q_start.assign(n_shards, 0);
+    sh.q_cnt.assign(n_shards, 0);
+    int rc = sk_count_from_segments<uint64_t, 4096>(h, k, seg_start, seg_cnt, (uint32_t)n_shards, n_rec, n_inst, n_edge,
+                                                    (const uint64_t *)d_w0, (const uint64_t *)d_w1, st64, w0, w1, st, 0,
+                                                    shard_bits, my_shard);
+    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+    // the instance counters describe this shard's nodes from here on
+    h->n_kmer_inst = n_inst;
+    h->n_edge_inst = n_edge;
+    for (int d = 0; d < n_shards; ++d) { q_starts[d] = sh.q_start[d]; q_counts[d] = sh.q_cnt[d]; }
+    *d_q_keys = h->ar_shard[0].p;
+    h->stats.ms_build_total = t_total.stop();
+    return DBG_OK;
+}
+
+extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void *d_answers) {
+    if (!h || !h->k || (n && (!d_q_keys || !d_answers))) return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!n) return DBG_OK;
+    unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
+    const int k = h->k, m = sk_m_for_k(k);
+    uint64_t *qk[2], *qm[2];
+    for (int set = 0; set < 2; ++set) {
+        CHK(buf_ensure(h, h->ar_q[set][0], (n + 16) * 8));
+        CHK(buf_ensure(h, h->ar_q[set][1], (n + 16) * 8));
+        qk[set] = (uint64_t *)h->ar_q[set][0].p;
+        qm[set] = (uint64_t *)h->ar_q[set][1].p;
+    }
+    HIPCHK(h, hipMemcpyAsync(qk[0], d_q_keys, n * 8, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_q_prepare, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, qk[0], n, k, m, qm[0]);
+    HIPCHK(h, hipMemsetAsync(d_answers, 0xFF, n * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+    const uint64_t n_buckets = 1ull << h->sk_T;
+    CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 64 * 16 + 16));
+    uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets, *q_seg = q_cnt + n_buckets;
+    const uint64_t root[2] = {0, n};
+    HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
+    uint32_t *dummy[2] = {nullptr, nullptr};
+    int qwhere = 0;
+    if (h->sk_T > 0) {
+        CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n, qk, qm, dummy, 40, h->sk_l1, h->sk_l2, q_start,
+                                                   q_cnt, &qwhere)));
+    } else {
+        HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
+    }
+    const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;
+    auto kern = k_q_answer<4096>;
+    const size_t lds = sizeof(AnsLds<4096>);
+    HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)h->sk_n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt, qk[qwhere],
+                       qm[qwhere], h->d_keys, (uint32_t *)d_answers, sc_dev);
+    HIPCHK(h, hipGetLastError());
+    uint64_t sc0 = 0;
+    HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sc0 & 128) { h->err = "a queried successor k-mer is not a node of this shard"; return DBG_E_HIP; }
+    return DBG_OK;
+}
+
+extern "C" int dbg_shard_apply(dbg_t *h, const void *d_answers) {
+    if (!h || !h->k || !h->shard_state) return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    ShardState &sh = shard_of(h);
+    Timer t(h->stream);
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+    if (h->n_nodes)
+        hipLaunchKernelGGL(k_tag_local, dim3(grid_for(h->n_nodes * 4, 256)), dim3(256), 0, h->stream, h->d_succ,
+                           h->n_nodes * 4, (uint32_t)sh.my_shard << 29);
+    const uint64_t *meta = (const uint64_t *)h->ar_shard[1].p;
+    for (int d = 0; d < sh.n_shards; ++d) {
+        if (d == sh.my_shard || !sh.q_cnt[d]) continue;
+        if (!d_answers) { h->err = "answers missing"; return DBG_E_ARG; }
+        hipLaunchKernelGGL(k_apply_remote, dim3(grid_for(sh.q_cnt[d], 256)), dim3(256), 0, h->stream, meta + sh.q_start[d],
+                           (const uint32_t *)d_answers + sh.q_start[d], sh.q_cnt[d], (uint32_t)d << 29, h->d_succ,
+                           (unsigned long long *)h->d_scalars);
+    }
+    HIPCHK(h, hipGetLastError());
+    uint64_t sc0 = 0;
+    HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sc0 & 256) { h->err = "a remote successor came back unresolved"; return DBG_E_HIP; }
+    h->stats.ms_succ += t.stop();
+    return finish_graph(h);
 }

@@ -600,13 +600,19 @@ __device__ inline uint32_t slot_of(uint64_t kmer) {
     return slot_hash(kmer) >> (CAP == 4096 ? 20 : 21);
 }
 
-constexpr int CNT_QBUF = 1024;   // cross-bucket successor queries staged per workgroup; also the record staging depth
+// cross-bucket successor queries staged per workgroup; also the record staging depth.  With 64-bit
+// stamps the 4096-slot table leaves room for 512 only.
+template <class ST, int CAP>
+struct CntCfg {
+    static constexpr int QBUF = (sizeof(ST) == 8 && CAP == 4096) ? 512 : 1024;
+};
 constexpr int CNT_STACK = 24;    // pending hash sub-ranges of one bucket
 constexpr int CNT_NT = 1024;     // threads per bucket workgroup (one workgroup per CU: the table fills the LDS)
 constexpr int CNT_PROBE_LIMIT = 1024;
 
 template <class ST, int CAP>
 struct CntLds {
+    static constexpr int CNT_QBUF = CntCfg<ST, CAP>::QBUF;
     unsigned long long keys[CAP];
     uint32_t cnt[CAP * 4];
     ST stamp[CAP];
@@ -689,6 +695,7 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char cnt_raw[];
     CntLds<ST, CAP> &s = *reinterpret_cast<CntLds<ST, CAP> *>(cnt_raw);
     constexpr int NPT = CAP / CNT_NT;  // nodes per thread, upper bound
+    constexpr int CNT_QBUF = CntCfg<ST, CAP>::QBUF;
     const uint32_t bucket = blockIdx.x;
     const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
     if (r_n == 0) return;

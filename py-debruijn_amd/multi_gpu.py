@@ -1,0 +1,97 @@
+"""Hash-prefix sharded graph build across the GPUs of one node.
+
+One process per GPU (``torch.distributed``; backend ``nccl`` == RCCL over xGMI).  The path has
+real exchange steps, so there are collectives -- but only all-to-alls, which use every xGMI
+link of a rank at once (a ring collective would be bound by one link):
+
+  1. every rank cuts ITS reads into super-k-mer records and groups them by owner shard
+     (owner = top bits of the minimizer bucket hash, so a k-mer and its 4 successor counters
+     live on exactly one rank)                                        -- dbg_shard_extract
+  2. all-to-all of the records (3 arrays: 2 x uint64 + uint32 stamp)  -- RCCL
+  3. every rank builds the node table of its buckets; successors owned by another shard come
+     back as (successor k-mer) queries grouped by owner               -- dbg_shard_build
+  4. all-to-all of the queries, owners look the k-mers up             -- dbg_shard_answer
+  5. all-to-all of the answers (uint32 node ids) back                 -- dbg_shard_apply
+
+After step 5 every rank holds its shard: node ids are (owner << 29) | local id, stamps are global.
+The graph object may be an ``_dbg.Graph`` or anything with the same four shard_* methods
+(the CPU test uses a numpy stand-in), and the process group may be gloo (tensors are staged
+through the host) or nccl.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def _is_gloo(dist):
+    return dist.get_backend() == "gloo"
+
+
+def exchange_counts(dist, counts, device):
+    """counts[d] = items this rank sends to d  ->  items this rank receives from every rank."""
+    w = dist.get_world_size()
+    send = torch.tensor(counts, dtype=torch.int64, device="cpu" if _is_gloo(dist) else device)
+    recv = torch.empty(w, dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(recv, send)
+    return [int(x) for x in recv.tolist()]
+
+
+def alltoallv(dist, tensor, send_counts, recv_counts):
+    """Variable all-to-all of a 1-D tensor laid out contiguously in destination order
+    (all_to_all_single with split sizes; staged through the host for gloo)."""
+    n_out = sum(recv_counts)
+    if _is_gloo(dist):
+        out = torch.empty(n_out, dtype=tensor.dtype)
+        dist.all_to_all_single(out, tensor.cpu().contiguous(), list(recv_counts), list(send_counts))
+        return out.to(tensor.device)
+    out = torch.empty(n_out, dtype=tensor.dtype, device=tensor.device)
+    dist.all_to_all_single(out, tensor.contiguous(), list(recv_counts), list(send_counts))
+    return out
+
+
+def stamp_bases(dist, n_bytes, device):
+    """Byte offset of every rank's reads in the rank-major concatenation of all reads."""
+    w = dist.get_world_size()
+    mine = torch.tensor([n_bytes], dtype=torch.int64, device="cpu" if _is_gloo(dist) else device)
+    allb = [torch.empty(1, dtype=torch.int64, device=mine.device) for _ in range(w)]
+    dist.all_gather(allb, mine)
+    bases, acc = [], 0
+    for t in allb:
+        bases.append(acc)
+        acc += int(t.item())
+    return bases
+
+
+def sharded_build(g, k, dist):
+    """Runs steps 1-5 on graph handle ``g`` (reads already set on every rank).  Returns ``g``."""
+    w, me = dist.get_world_size(), dist.get_rank()
+    send_counts, (w0, w1, st) = g.shard_extract(k, w)
+    device = w0.device
+    recv_counts = exchange_counts(dist, send_counts, device)
+    r_w0 = alltoallv(dist, w0, send_counts, recv_counts)
+    r_w1 = alltoallv(dist, w1, send_counts, recv_counts)
+    r_st = alltoallv(dist, st, send_counts, recv_counts)
+    bases = stamp_bases(dist, g.sizes()["n_bytes"], device)
+    if not _is_gloo(dist) and device.type == "cuda":
+        torch.cuda.synchronize(device)  # the library works on its own stream
+    q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases)
+
+    # successors owned by other shards: keys out, node ids back.  The library lists the queries
+    # grouped by owner with its own group in between: pack the remote groups for the wire.
+    q_recv = exchange_counts(dist, q_counts, device)
+    groups = [q_keys[s:s + c] for s, c in zip(q_starts, q_counts)]
+    packed = torch.cat(groups) if groups else q_keys[:0]
+    keys_in = alltoallv(dist, packed, q_counts, q_recv)
+    if not _is_gloo(dist) and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    answers_out = g.shard_answer(keys_in)
+    back = alltoallv(dist, answers_out, q_recv, q_counts)
+    answers = torch.empty(q_keys.numel(), dtype=torch.int32, device=device)
+    off = 0
+    for s, c in zip(q_starts, q_counts):
+        answers[s:s + c] = back[off:off + c]
+        off += c
+    if not _is_gloo(dist) and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    g.shard_apply(answers)
+    return g

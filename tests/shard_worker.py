@@ -1,0 +1,138 @@
+"""One rank of a sharded build (launched by test_multi_gpu.py; test infrastructure).
+
+mode "fake": the device library is replaced by NumpyShardGraph below, a tiny numpy model of the
+four shard_* steps, so that multi_gpu.py's exchange logic runs on CPU under gloo.
+mode "gpu": the real _dbg.Graph on cuda:0 (both ranks share the one GPU of the test box; gloo).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "py-debruijn_amd"))
+import multi_gpu  # noqa: E402
+import synth  # noqa: E402
+
+M64 = (1 << 64) - 1
+
+
+def mix(x):
+    x &= M64
+    x ^= x >> 30; x = (x * 0xBF58476D1CE4E5B9) & M64
+    x ^= x >> 27; x = (x * 0x94D049BB133111EB) & M64
+    x ^= x >> 31
+    return x
+
+
+def as_i64(vals):
+    return torch.from_numpy(np.array(vals, dtype=np.uint64).view(np.int64).copy())
+
+
+class NumpyShardGraph:
+    """Model of dbg_shard_* with one record per k-mer occurrence (format is opaque to multi_gpu.py)."""
+
+    def __init__(self, reads, k):
+        self.reads, self.k = reads, k
+        self.mask = (1 << (2 * k)) - 1
+
+    def sizes(self):
+        return {"n_bytes": sum(len(r) for r in self.reads)}
+
+    def owner(self, key, n):
+        bits = n.bit_length() - 1
+        return (mix(key) >> (64 - bits)) if bits else 0
+
+    def shard_extract(self, k, n):
+        recs, off = [], 0
+        for r in self.reads:
+            codes = [(ord(c) >> 1) & 3 for c in r]
+            if len(r) > k:
+                for p in range(len(r) - k + 1):
+                    key = 0
+                    for c in codes[p:p + k]:
+                        key = (key << 2) | c
+                    succ = codes[p + k] if p + k < len(r) else 4
+                    recs.append((self.owner(key, n), key, succ, ((off + p) << 1) | (p != 0)))
+            off += len(r)
+        recs.sort(key=lambda t: t[0])
+        counts = [sum(1 for t in recs if t[0] == d) for d in range(n)]
+        return counts, (as_i64([t[1] for t in recs]), as_i64([t[2] for t in recs]),
+                        torch.tensor([t[3] for t in recs], dtype=torch.int32))
+
+    def shard_build(self, k, n, me, w0, w1, st, recv_counts, bases):
+        keys = w0.numpy().view(np.uint64)
+        succ = w1.numpy().view(np.uint64)
+        stl = st.numpy().view(np.uint32)
+        table, seg = {}, 0
+        for r, c in enumerate(recv_counts):
+            for i in range(seg, seg + c):
+                ent = table.setdefault(int(keys[i]), [[0, 0, 0, 0], None])
+                if int(succ[i]) < 4:
+                    ent[0][int(succ[i])] += 1
+                stamp = (bases[r] << 1) + int(stl[i])
+                ent[1] = stamp if ent[1] is None else min(ent[1], stamp)
+            seg += c
+        self.node_keys = sorted(table)
+        self.ids = {key: i for i, key in enumerate(self.node_keys)}
+        self.counts = np.array([table[key][0] for key in self.node_keys], dtype=np.uint32).reshape(-1, 4)
+        self.stamps = np.array([table[key][1] for key in self.node_keys], dtype=np.uint64)
+        self.succ = np.full((len(self.node_keys), 4), 0xFFFFFFFF, dtype=np.uint32)
+        self.me, self.n = me, n
+        groups = [[] for _ in range(n)]
+        for i, key in enumerate(self.node_keys):
+            for code in range(4):
+                if self.counts[i, code]:
+                    sk = ((key << 2) | code) & self.mask
+                    d = self.owner(sk, n)
+                    if d == me:
+                        self.succ[i, code] = (me << 29) | self.ids[sk]
+                    else:
+                        groups[d].append((sk, i * 4 + code))
+        self.q_slots = [slot for gquery in groups for _, slot in gquery]
+        self.q_owner = [d for d, gquery in enumerate(groups) for _ in gquery]
+        q_counts = [len(gq) for gq in groups]
+        q_starts = [sum(q_counts[:d]) for d in range(n)]
+        return q_starts, q_counts, as_i64([sk for gq in groups for sk, _ in gq])
+
+    def shard_answer(self, keys):
+        return torch.tensor([self.ids[int(x)] for x in keys.numpy().view(np.uint64)], dtype=torch.int32)
+
+    def shard_apply(self, answers):
+        flat = self.succ.reshape(-1)
+        for slot, d, a in zip(self.q_slots, self.q_owner, answers.tolist()):
+            flat[slot] = (d << 29) | a
+
+    def export(self):
+        return np.array(self.node_keys, dtype=np.uint64), self.stamps, self.counts, self.succ
+
+
+def main():
+    mode, out_dir, k, n_reads, read_len = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    per = n_reads // world
+    reads = synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01, first_read=rank * per)
+    if mode == "fake":
+        g = NumpyShardGraph([row.tobytes().decode() for row in reads], k)
+        multi_gpu.sharded_build(g, k, dist)
+        keys, stamps, counts, succ = g.export()
+    else:
+        import _dbg
+        g = _dbg.Graph(device=0)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
+        multi_gpu.sharded_build(g, k, dist)
+        keys, stamps, counts, _ = g.export_nodes()
+        succ = g.export_succ()
+        rp, col, cnt = g.export_csr()
+        assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, stamps=stamps, counts=counts, succ=succ)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""Sharded (multi-rank) build: union of the shards == the single-rank oracle result.
+
+CPU (gloo, world_size 2 and 4): multi_gpu.py's exchange logic around a numpy model of the device steps.
+GPU (-m gpu): the real library, two ranks sharing the test box's single GPU over gloo.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+from oracle import orc_c
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_ranks(mode, world, tmp_path, k, n_reads, read_len):
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), mode, str(tmp_path), str(k),
+                                       str(n_reads), str(read_len)], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    return [np.load(os.path.join(tmp_path, f"rank{r}.npz")) for r in range(world)]
+
+
+def check(shards, world, k, n_reads, read_len):
+    per = n_reads // world
+    reads = np.concatenate([synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01,
+                                              first_read=r * per) for r in range(world)])
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
+    keys = np.concatenate([s["keys"] for s in shards])
+    stamps = np.concatenate([s["stamps"] for s in shards])
+    counts = np.concatenate([s["counts"] for s in shards])
+    assert keys.size == want["n_nodes"], "every k-mer is owned by exactly one shard"
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"])
+    assert np.array_equal(stamps[o], want["stamps"])       # global first-occurrence stamps
+    assert np.array_equal(counts[o], want["counts"])
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for r, s in enumerate(shards):                           # successors: (owner << 29) | id on the owner
+        for code in range(4):
+            has = s["counts"][:, code] != 0
+            ref = s["succ"][has, code]
+            assert np.all(ref != 0xFFFFFFFF)
+            owner, idx = ref >> 29, ref & ((1 << 29) - 1)
+            got = np.empty(ref.size, dtype=np.uint64)
+            for d in range(world):
+                sel = owner == d
+                got[sel] = shards[d]["keys"][idx[sel]]
+            assert np.array_equal(got, ((s["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+            assert np.all(s["succ"][~has, code] == 0xFFFFFFFF)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_exchange_logic_on_cpu_gloo(world, tmp_path):
+    shards = run_ranks("fake", world, tmp_path, 9, 64, 40)
+    check(shards, world, 9, 64, 40)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_reads,read_len", [(21, 4000, 100), (31, 20000, 150), (5, 400, 30)])
+def test_two_ranks_on_one_gpu(k, n_reads, read_len, tmp_path):
+    shards = run_ranks("gpu", 2, tmp_path, k, n_reads, read_len)
+    check(shards, 2, k, n_reads, read_len)
