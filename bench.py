@@ -27,6 +27,20 @@ def b_alg(read_len, k):
     return read_len / (read_len - k + 1) + 8 + 8
 
 
+def pmc_traffic(kernel="k_sk_count"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (collected in its own
+    rocprofv3 --pmc passes, FETCH_SIZE x2 per the gfx950 correction); None when the profile is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    try:
+        with open(path) as fh:
+            for row in json.load(fh):
+                if kernel in row["kernel"]:
+                    return (row["hbm_read_GB_corrected_x2"] + row["hbm_write_GB"]) * 1e9
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def cpu_baseline(seed, genome_len, read_len, k, err, sample_reads):
     """oracle/dbg_oracle.c (single-threaded port of the reference's algorithm) on a bounded sample."""
     import numpy as np
@@ -74,9 +88,16 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # BENCH_BACKEND=gloo BENCH_SAME_GPU=1: rehearsal of the N>1 path on a one-GPU box (not a measurement)
+        backend = os.environ.get("BENCH_BACKEND", "nccl")
+        if os.environ.get("BENCH_SAME_GPU", "") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        import multi_gpu  # hash-prefix sharded build (RCCL alltoallv)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+        import multi_gpu  # hash-prefix sharded build (RCCL all-to-all)
 
     L, k = args.read_len, args.k
     n_total = args.reads * world
@@ -109,7 +130,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -136,7 +157,8 @@ def main():
                        "k": k, "reads_per_gpu": args.reads, "read_len": L, "err_rate": args.err,
                        "parallelism": "single table" if world == 1 else f"hash-prefix shard x{world} (RCCL alltoallv)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic() if (world == 1 and args.reads == 10_000_000 and args.err == 0.01) else None,
                          "kernel": "k_sk_count", "ms_per_launch": mean_count_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_kmer": b_alg(L, k)},
             "phases_ms": phases,
