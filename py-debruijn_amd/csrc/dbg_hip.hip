@@ -1692,8 +1692,11 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n_rec) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)n_buckets), dim3(CNT_NT), lds, h->stream, b_start, b_cnt, w0[where],
-                               w1[where], st[where], k, m, out, h->phase_limit);
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);  // persistent: one per CU
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(CNT_NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
+                               st[where], k, m, n_buckets, out, h->phase_limit);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? 1 : 0;

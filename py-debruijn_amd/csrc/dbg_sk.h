@@ -690,230 +690,272 @@ __device__ inline uint32_t wave_alloc_n(uint32_t *counter, uint32_t n) {
 template <class ST, int CAP>
 __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
-                                                     const ST *__restrict__ rec_st, int k, int m, SkCountOut out,
-                                                     int phase_limit /* ablation only: 0 = run everything */) {
+                                                     const ST *__restrict__ rec_st, int k, int m, uint64_t n_buckets,
+                                                     SkCountOut out, int phase_limit /* ablation only: 0 = run everything */) {
+    // Persistent: one workgroup per CU walks buckets blockIdx.x, blockIdx.x + gridDim.x, ...  The table
+    // stays in LDS across buckets: the node write clears exactly the slots it reads (a third of the
+    // table), and the next bucket's records are prefetched into registers while this bucket is in
+    // its lookup / reservation / write phases.
     extern __shared__ __attribute__((aligned(16))) unsigned char cnt_raw[];
     CntLds<ST, CAP> &s = *reinterpret_cast<CntLds<ST, CAP> *>(cnt_raw);
+    using LdsT = CntLds<ST, CAP>;
     constexpr int NPT = CAP / CNT_NT;  // nodes per thread, upper bound
     constexpr int CNT_QBUF = CntCfg<ST, CAP>::QBUF;
-    const uint32_t bucket = blockIdx.x;
-    const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
-    if (r_n == 0) return;
+    static_assert(offsetof(LdsT, list) == offsetof(LdsT, idx) + sizeof(uint16_t) * CAP, "layout");
+    static_assert(CNT_QBUF * 5 <= 2 * CAP || CAP == 2048, "quad list must fit idx+list");
+    constexpr uint32_t STAGE = (CNT_QBUF * 5 <= 2 * CAP) ? CNT_QBUF : (2 * CAP) / 5;
+    static_assert(STAGE <= CNT_NT, "one staged record per thread");
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    if (threadIdx.x == 0) { s.stk_n = 1; s.stk_mask[0] = 0; s.stk_val[0] = 0; s.fail = 0; }
-    __syncthreads();
-    while (true) {
-        __syncthreads();
-        if (s.stk_n == 0 || s.fail) break;
-        const uint32_t cur_mask = s.stk_mask[s.stk_n - 1], cur_val = s.stk_val[s.stk_n - 1];
-        __syncthreads();
-        for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
-            s.keys[i] = EMPTY_KEY;
-            s.stamp[i] = (ST)~(ST)0;
-            reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+    uint16_t *flat = s.idx;  // idx[] and list[] are adjacent and unused until the table is final
+
+    bool clean = false;  // uniform: every slot of the table is EMPTY / zero / max
+    uint64_t pf_w0 = 0, pf_w1 = 0;
+    ST pf_st = 0;
+    auto prefetch = [&](uint64_t bucket) {
+        if (bucket < n_buckets) {
+            const uint64_t beg = b_start[bucket], n = b_cnt[bucket];
+            if (threadIdx.x < min(n, (uint64_t)STAGE)) {
+                pf_w0 = rec_w0[beg + threadIdx.x];
+                pf_w1 = rec_w1[beg + threadIdx.x];
+                pf_st = rec_st[beg + threadIdx.x];
+            }
         }
-        if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
+    };
+    if (threadIdx.x == 0) s.fail = 0;
+    prefetch(blockIdx.x);
+
+    for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
+        const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
+        if (r_n == 0) { prefetch(bucket + gridDim.x); continue; }
+        bool have_prefetch = true;  // registers hold the first STAGE records of this bucket
+        bool skip_rest = false;     // ablation exit
         __syncthreads();
-        // ---- insert: records are staged in LDS with one bulk load (no global latency inside the
-        //      k-mer loop).  Work items are "quads" (record, 4 consecutive k-mers), listed densely so
-        //      that every group of 4 lanes has a quad: lane utilisation ~80 % whatever the lengths.
-        uint16_t *flat = s.idx;  // idx[] and list[] are adjacent and unused until the table is final
-        using LdsT = CntLds<ST, CAP>;
-        static_assert(offsetof(LdsT, list) == offsetof(LdsT, idx) + sizeof(uint16_t) * CAP, "layout");
-        static_assert(CNT_QBUF * 5 <= 2 * CAP || CAP == 2048, "quad list must fit idx+list");
-        constexpr uint32_t STAGE = (CNT_QBUF * 5 <= 2 * CAP) ? CNT_QBUF : (2 * CAP) / 5;
-        for (uint64_t c0 = 0; c0 < r_n; c0 += STAGE) {
-            const uint32_t n_st = (uint32_t)min((uint64_t)STAGE, r_n - c0);
-            if (c0) __syncthreads();
-            if (threadIdx.x == 0) s.n_flat = 0;
-            for (uint32_t r = threadIdx.x; r < n_st; r += CNT_NT) {
-                s.q_key[r] = rec_w0[r_beg + c0 + r];
-                s.q_meta[r] = rec_w1[r_beg + c0 + r];
-                s.st_stage[r] = rec_st[r_beg + c0 + r];
-            }
+        if (threadIdx.x == 0) { s.stk_n = 1; s.stk_mask[0] = 0; s.stk_val[0] = 0; }
+        while (true) {
             __syncthreads();
-            if (phase_limit == 1) return;  // clear + stage
-            if (s.overflow) break;  // uniform: read after the barrier
-            {  // quad list (STAGE <= CNT_NT: one record per thread)
-                const uint32_t r = threadIdx.x;
-                uint32_t nquad = 0;
-                if (r < n_st) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
-                uint32_t base = wave_alloc_n(&s.n_flat, nquad);
-                for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
-            }
+            if (s.stk_n == 0 || s.fail) break;
+            const uint32_t cur_mask = s.stk_mask[s.stk_n - 1], cur_val = s.stk_val[s.stk_n - 1];
             __syncthreads();
-            const uint32_t n_flat = s.n_flat;
-            for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += CNT_NT / 4) {
-                const uint32_t e = flat[f];
-                const uint32_t r = e >> 3;
-                const int i = (int)((e & 7) * 4 + (threadIdx.x & 3));
-                const uint64_t w0 = s.q_key[r], w1 = s.q_meta[r];
-                const int len = (int)((w1 >> 1) & 31) + 1;
-                if (i >= len) continue;
-                const ST st0 = s.st_stage[r];
-                const uint64_t hi = w1 & (~0ull << SK_META_BITS);
-                const uint32_t hs = (uint32_t)(w1 & 1);
-                const uint64_t win = rec_window(w0, hi, i);
-                const uint64_t kmer = win >> (64 - 2 * k);
-                if (cur_mask && (sub_hash(kmer) & cur_mask) != cur_val) continue;
-                const bool has_succ = (i < len - 1) || hs;
-                const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
-                const ST stamp = i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0;
-                uint32_t slot = slot_of<CAP>(kmer);
-                bool ok = false;
-                for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
-                    unsigned long long cur = s.keys[slot];
-                    if (cur == EMPTY_KEY) {
-                        cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
-                        if (cur == EMPTY_KEY) cur = kmer;
+            if (!clean) {
+                for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
+                    s.keys[i] = EMPTY_KEY;
+                    s.stamp[i] = (ST)~(ST)0;
+                    reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            clean = false;
+            if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
+            // ---- insert: records are staged in LDS (first chunk: from the prefetch registers), work
+            //      items are "quads" (record, 4 consecutive k-mers) listed densely, 4 lanes per quad
+            for (uint64_t c0 = 0; c0 < r_n; c0 += STAGE) {
+                const uint32_t n_st = (uint32_t)min((uint64_t)STAGE, r_n - c0);
+                if (c0) __syncthreads();
+                if (threadIdx.x == 0) s.n_flat = 0;
+                if (c0 == 0 && have_prefetch) {
+                    if (threadIdx.x < n_st) { s.q_key[threadIdx.x] = pf_w0; s.q_meta[threadIdx.x] = pf_w1; s.st_stage[threadIdx.x] = pf_st; }
+                } else {
+                    for (uint32_t r = threadIdx.x; r < n_st; r += CNT_NT) {
+                        s.q_key[r] = rec_w0[r_beg + c0 + r];
+                        s.q_meta[r] = rec_w1[r_beg + c0 + r];
+                        s.st_stage[r] = rec_st[r_beg + c0 + r];
                     }
-                    if (cur == kmer) { ok = true; break; }
-                    slot = (slot + 1) & (CAP - 1);
                 }
-                if (!ok) { s.overflow = 1; continue; }
-                if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], 1u);
-                atomicMin(&s.stamp[slot], stamp);
+                __syncthreads();
+                if (phase_limit == 1) { skip_rest = true; break; }  // clear + stage
+                if (s.overflow) break;  // uniform: read after the barrier
+                {  // quad list (STAGE <= CNT_NT: one record per thread)
+                    const uint32_t r = threadIdx.x;
+                    uint32_t nquad = 0;
+                    if (r < n_st) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
+                    const uint32_t base = wave_alloc_n(&s.n_flat, nquad);
+                    for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
+                }
+                __syncthreads();
+                const uint32_t n_flat = s.n_flat;
+                for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += CNT_NT / 4) {
+                    const uint32_t e = flat[f];
+                    const uint32_t r = e >> 3;
+                    const int i = (int)((e & 7) * 4 + (threadIdx.x & 3));
+                    const uint64_t w0 = s.q_key[r], w1 = s.q_meta[r];
+                    const int len = (int)((w1 >> 1) & 31) + 1;
+                    if (i >= len) continue;
+                    const ST st0 = s.st_stage[r];
+                    const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+                    const uint32_t hs = (uint32_t)(w1 & 1);
+                    const uint64_t win = rec_window(w0, hi, i);
+                    const uint64_t kmer = win >> (64 - 2 * k);
+                    if (cur_mask && (sub_hash(kmer) & cur_mask) != cur_val) continue;
+                    const bool has_succ = (i < len - 1) || hs;
+                    const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
+                    const ST stamp = i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0;
+                    uint32_t slot = slot_of<CAP>(kmer);
+                    bool ok = false;
+                    for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
+                        unsigned long long cur = s.keys[slot];
+                        if (cur == EMPTY_KEY) {
+                            cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
+                            if (cur == EMPTY_KEY) cur = kmer;
+                        }
+                        if (cur == kmer) { ok = true; break; }
+                        slot = (slot + 1) & (CAP - 1);
+                    }
+                    if (!ok) { s.overflow = 1; continue; }
+                    if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], 1u);
+                    atomicMin(&s.stamp[slot], stamp);
+                }
             }
+            if (skip_rest) break;
+            __syncthreads();
+            if (have_prefetch) {  // the registers are free: fetch the next bucket's records under the rest of this one
+                have_prefetch = false;
+                prefetch(bucket + gridDim.x);
+            }
+            if (phase_limit == 2) { skip_rest = true; break; }  // + insert
+            if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
+                if (threadIdx.x == 0) {
+                    const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
+                    if (s.stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
+                        atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
+                        s.fail = 1;
+                    } else {
+                        s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val; ++s.stk_n;
+                        s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val | bit; ++s.stk_n;
+                    }
+                }
+                continue;
+            }
+            // ---- dense list of occupied slots (one LDS atomic per wave)
+            for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
+                const bool occ = s.keys[i] != EMPTY_KEY;
+                const uint32_t li = wave_alloc(&s.n_local, occ);
+                if (occ) { s.idx[i] = (uint16_t)li; s.list[li] = (uint16_t)i; }
+            }
+            __syncthreads();
+            if (phase_limit == 3) { skip_rest = true; break; }  // + dense list
+            const uint32_t n_local = s.n_local;
+            // ---- successor lookups into registers; misses are staged as queries (slot index local for now).
+            //      Per node only the bases that occur are looked up (usually one): the wave loops
+            //      max-popcount times instead of four.  Result per base, 16 bits: local node index,
+            //      0xFFFF none, 0xFFFE miss staged, 0x8000 | (qi - CNT_QBUF) miss that did not fit the staging.
+            unsigned long long nsucc[NPT];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                nsucc[u] = ~0ull;
+                if ((uint32_t)(u * CNT_NT) >= n_local) continue;  // uniform over the workgroup
+                const uint32_t li = threadIdx.x + u * CNT_NT;
+                unsigned long long key = 0;
+                uint32_t nz = 0;
+                if (li < n_local) {
+                    const uint32_t sl = s.list[li];
+                    key = s.keys[sl];
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[sl];
+                    nz = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
+                }
+                uint32_t missmask = 0;
+                while (nz) {
+                    const uint32_t b = __ffs(nz) - 1;
+                    nz &= nz - 1;
+                    const int f = lds_find<CAP>(s.keys, ((key << 2) | (uint64_t)b) & kmask);
+                    if (f >= 0) nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)s.idx[f] << (16 * b));
+                    else missmask |= 1u << b;
+                }
+                uint32_t qi = wave_alloc_n(&s.n_q, (uint32_t)__popc(missmask));
+                while (missmask) {
+                    const uint32_t b = __ffs(missmask) - 1;
+                    missmask &= missmask - 1;
+                    unsigned long long code;
+                    if (qi < CNT_QBUF) {
+                        s.q_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
+                        s.q_meta[qi] = (unsigned long long)li * 4 + b;
+                        code = 0xFFFEull;
+                    } else {
+                        code = 0x8000ull | (qi - CNT_QBUF);
+                    }
+                    nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | (code << (16 * b));
+                    ++qi;
+                }
+            }
+            __syncthreads();
+            if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
+            const uint32_t nq = s.n_q;
+            if (threadIdx.x == 0) {  // one packed reservation: nodes in the low half, queries in the high half
+                const unsigned long long got =
+                    atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)nq << 32));
+                const unsigned long long base = got & 0xFFFFFFFFull, qb = got >> 32;
+                s.gbase = base;
+                s.qbase = qb;
+                if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
+                if (qb + nq > out.q_cap || qb + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+                uint64_t ri = bucket;
+                if (cur_mask) {
+                    ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
+                    if (ri >= out.range_cap) { atomicOr(&out.scalars[0], 32ull); s.fail = 1; }
+                }
+                if (!s.fail) {
+                    SkRange rg;
+                    rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
+                    out.ranges[ri] = rg;
+                }
+            }
+            // while the reservation is in flight: minimizer bucket of every staged query (dense, no divergence)
+            for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
+                s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
+            __syncthreads();
+            if (phase_limit == 5) { skip_rest = true; break; }  // + reservation + query buckets
+            if (s.fail) break;
+            const uint64_t gbase = s.gbase, qbase = s.qbase;
+            // ---- write nodes: consecutive lanes -> consecutive nodes; every slot read is cleared for the next bucket
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                if ((uint32_t)(u * CNT_NT) >= n_local) break;
+                const uint32_t li = threadIdx.x + u * CNT_NT;
+                if (li >= n_local) continue;
+                const uint32_t i = s.list[li];
+                const unsigned long long key = s.keys[i];
+                const uint64_t node = gbase + li;
+                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
+                const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+                const uint64_t stamp = (uint64_t)s.stamp[i];
+                s.keys[i] = EMPTY_KEY;
+                s.stamp[i] = (ST)~(ST)0;
+                reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+                out.keys[node] = key;
+                out.stamps[node] = stamp;
+                reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
+                out.flags[node] = (uint8_t)(stamp & 1);
+                out.deg[node] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
+                uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
+#pragma unroll
+                for (int a = 1; a < 4; ++a) {
+#pragma unroll
+                    for (int b = a; b > 0; --b) {
+                        if (c[code[b]] > c[code[b - 1]]) { uint32_t t = code[b]; code[b] = code[b - 1]; code[b - 1] = t; }
+                    }
+                }
+                out.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
+                uint32_t sc[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
+                    sc[b] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
+                    if (v >= 0x8000u && v < 0xFFFEu) {  // query that did not fit the staging buffer: write it straight out
+                        const uint64_t qi = (uint64_t)(v & 0x7FFFu) + CNT_QBUF;
+                        const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
+                        out.q_key[qbase + qi] = skey;
+                        out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
+                    }
+                }
+                reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+            }
+            for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
+                out.q_key[qbase + i] = s.q_key[i];
+                out.q_meta[qbase + i] = s.q_meta[i] + gbase * 4;  // local slot index -> global
+            }
+            clean = true;  // every occupied slot was reset above (uniform: all waves pass here)
         }
         __syncthreads();
-        if (phase_limit == 2) return;  // clear + stage + insert
-        if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
-            if (threadIdx.x == 0) {
-                const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
-                if (s.stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
-                    atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
-                    s.fail = 1;
-                } else {
-                    s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val; ++s.stk_n;
-                    s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val | bit; ++s.stk_n;
-                }
-            }
-            continue;
-        }
-        // ---- dense list of occupied slots (one LDS atomic per wave)
-        for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
-            const bool occ = s.keys[i] != EMPTY_KEY;
-            const uint32_t li = wave_alloc(&s.n_local, occ);
-            if (occ) { s.idx[i] = (uint16_t)li; s.list[li] = (uint16_t)i; }
-        }
-        __syncthreads();
-        if (phase_limit == 3) return;  // + dense list
-        const uint32_t n_local = s.n_local;
-        // ---- successor lookups into registers; misses are staged as queries (slot index local for now).
-        //      Per node only the bases that occur are looked up (usually one): the wave loops
-        //      max-popcount times instead of four.  Result per base, 16 bits: local node index,
-        //      0xFFFF none, 0xFFFE miss staged, 0x8000 | (qi - CNT_QBUF) miss that did not fit the staging.
-        unsigned long long nsucc[NPT];
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            nsucc[u] = ~0ull;
-            if ((uint32_t)(u * CNT_NT) >= n_local) continue;  // uniform over the workgroup
-            const uint32_t li = threadIdx.x + u * CNT_NT;
-            unsigned long long key = 0;
-            uint32_t nz = 0;
-            if (li < n_local) {
-                const uint32_t sl = s.list[li];
-                key = s.keys[sl];
-                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[sl];
-                nz = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
-            }
-            uint32_t missmask = 0;
-            while (nz) {
-                const uint32_t b = __ffs(nz) - 1;
-                nz &= nz - 1;
-                const int f = lds_find<CAP>(s.keys, ((key << 2) | (uint64_t)b) & kmask);
-                if (f >= 0) nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)s.idx[f] << (16 * b));
-                else missmask |= 1u << b;
-            }
-            uint32_t qi = wave_alloc_n(&s.n_q, (uint32_t)__popc(missmask));
-            while (missmask) {
-                const uint32_t b = __ffs(missmask) - 1;
-                missmask &= missmask - 1;
-                unsigned long long code;
-                if (qi < CNT_QBUF) {
-                    s.q_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
-                    s.q_meta[qi] = (unsigned long long)li * 4 + b;
-                    code = 0xFFFEull;
-                } else {
-                    code = 0x8000ull | (qi - CNT_QBUF);
-                }
-                nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | (code << (16 * b));
-                ++qi;
-            }
-        }
-        __syncthreads();
-        if (phase_limit == 4) return;  // + successor lookups
-        const uint32_t nq = s.n_q;
-        if (threadIdx.x == 0) {  // one packed reservation: nodes in the low half, queries in the high half
-            const unsigned long long got =
-                atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)nq << 32));
-            const unsigned long long base = got & 0xFFFFFFFFull, qb = got >> 32;
-            s.gbase = base;
-            s.qbase = qb;
-            if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
-            if (qb + nq > out.q_cap || qb + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
-            uint64_t ri = bucket;
-            if (cur_mask) {
-                ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
-                if (ri >= out.range_cap) { atomicOr(&out.scalars[0], 32ull); s.fail = 1; }
-            }
-            if (!s.fail) {
-                SkRange rg;
-                rg.bucket = bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
-                out.ranges[ri] = rg;
-            }
-        }
-        // while the reservation is in flight: minimizer bucket of every staged query (dense, no divergence)
-        for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
-            s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
-        __syncthreads();
-        if (phase_limit == 5) return;  // + reservation + query buckets
-        if (s.fail) break;
-        const uint64_t gbase = s.gbase, qbase = s.qbase;
-        // ---- write nodes: consecutive lanes -> consecutive nodes
-#pragma unroll
-        for (int u = 0; u < NPT; ++u) {
-            if ((uint32_t)(u * CNT_NT) >= n_local) break;
-            const uint32_t li = threadIdx.x + u * CNT_NT;
-            if (li >= n_local) continue;
-            const uint32_t i = s.list[li];
-            const unsigned long long key = s.keys[i];
-            const uint64_t node = gbase + li;
-            const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
-            const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-            const uint64_t stamp = (uint64_t)s.stamp[i];
-            out.keys[node] = key;
-            out.stamps[node] = stamp;
-            reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
-            out.flags[node] = (uint8_t)(stamp & 1);
-            out.deg[node] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
-            uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
-#pragma unroll
-            for (int a = 1; a < 4; ++a) {
-#pragma unroll
-                for (int b = a; b > 0; --b) {
-                    if (c[code[b]] > c[code[b - 1]]) { uint32_t t = code[b]; code[b] = code[b - 1]; code[b - 1] = t; }
-                }
-            }
-            out.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
-            uint32_t sc[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
-                sc[b] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
-                if (v >= 0x8000u && v < 0xFFFEu) {  // query that did not fit the staging buffer: write it straight out
-                    const uint64_t qi = (uint64_t)(v & 0x7FFFu) + CNT_QBUF;
-                    const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
-                    out.q_key[qbase + qi] = skey;
-                    out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
-                }
-            }
-            reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
-        }
-        for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
-            out.q_key[qbase + i] = s.q_key[i];
-            out.q_meta[qbase + i] = s.q_meta[i] + gbase * 4;  // local slot index -> global
-        }
+        if (s.fail) return;
+        if (skip_rest) { clean = false; if (have_prefetch) prefetch(bucket + gridDim.x); }
     }
 }
 
