@@ -57,6 +57,7 @@ struct dbg {
     uint8_t *d_deg = nullptr;    // distinct successors (pre-pruning outdegree) -- feeds the CSR row scan
     uint32_t *d_succ = nullptr;
     bool nodes_in_arena = false;  // node arrays borrowed from ar_node (super-k-mer engine)
+    bool csr_built = false;       // rowptr/col/ecnt already written by k_sk_count
     uint64_t *d_rowptr = nullptr;
     uint32_t *d_col = nullptr, *d_ecnt = nullptr;
 
@@ -90,7 +91,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][2], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -855,6 +856,7 @@ static void free_build(dbg *h) {
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
     dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_deg);
     h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
+    h->csr_built = false;
     dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
     dev_free(h->d_ctg_seq);
@@ -1013,7 +1015,7 @@ extern "C" int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets) {
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint);
 // CSR over distinct edges + start count; shared by both engines
 static int finish_graph(dbg *h) {
-    {
+    if (!h->csr_built) {
         Timer t(h->stream);
         CHK(buf_ensure(h, h->ar_csr[0], (h->n_nodes + 1) * 8));
         h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
@@ -1662,17 +1664,24 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     CHK(buf_ensure(h, h->ar_node[3], node_cap));
     CHK(buf_ensure(h, h->ar_node[4], node_cap));
     CHK(buf_ensure(h, h->ar_node[5], node_cap * 16));
-    CHK(buf_ensure(h, h->ar_node[6], node_cap));
     h->d_keys = (uint64_t *)h->ar_node[0].p;
     h->d_stamps = (uint64_t *)h->ar_node[1].p;
     h->d_cnt = (uint32_t *)h->ar_node[2].p;
     h->d_flags = (uint8_t *)h->ar_node[3].p;
     h->d_order = (uint8_t *)h->ar_node[4].p;
     h->d_succ = (uint32_t *)h->ar_node[5].p;
-    h->d_deg = (uint8_t *)h->ar_node[6].p;
     h->nodes_in_arena = true;
+    uint64_t edge_cap = n_edge_inst + 16;
+    if (edge_cap > 0xFFFFFFF0ull) edge_cap = 0xFFFFFFF0ull;
+    CHK(buf_ensure(h, h->ar_csr[0], (node_cap + 1) * 8));
+    CHK(buf_ensure(h, h->ar_csr[1], edge_cap * 4));
+    CHK(buf_ensure(h, h->ar_csr[2], edge_cap * 4));
+    h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
+    h->d_col = (uint32_t *)h->ar_csr[1].p;
+    h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
     uint64_t q_cap = n_rec + 1024;
     uint64_t *qk[2], *qm[2];
+    uint32_t *qc[2];
     const uint64_t range_cap = n_buckets + 4096 + n_inst / (CAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
@@ -1680,14 +1689,17 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         for (int set = 0; set < 2; ++set) {
             CHK(buf_ensure(h, h->ar_q[set][0], q_cap * 8));
             CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
+            CHK(buf_ensure(h, h->ar_q[set][2], q_cap * 4));
             qk[set] = (uint64_t *)h->ar_q[set][0].p;
             qm[set] = (uint64_t *)h->ar_q[set][1].p;
+            qc[set] = (uint32_t *)h->ar_q[set][2].p;
         }
         Timer t(h->stream);
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
-        SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_deg, h->d_succ, node_cap,
-                       qk[0], qm[0], q_cap, ranges, n_buckets, range_cap, sc_dev};
+        SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_succ, node_cap,
+                       h->d_rowptr, h->d_col, h->d_ecnt, edge_cap, qk[0], qm[0], qc[0], q_cap,
+                       ranges, n_buckets, range_cap, sc_dev};
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1709,10 +1721,13 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         break;
     }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
-    if (sc[0] & 16) { h->err = "node capacity exceeded"; return DBG_E_CAPACITY; }
+    if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
     h->n_nodes = sc[4] & 0xFFFFFFFFull;
-    uint64_t n_q = sc[4] >> 32;
+    h->n_edges = sc[4] >> 32;
+    HIPCHK(h, hipMemcpyAsync(h->d_rowptr + h->n_nodes, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
+    h->csr_built = true;
+    uint64_t n_q = sc[5];
     const uint64_t n_ranges = n_buckets + sc[6];
     h->stats.n_queries = n_q;
 
@@ -1725,25 +1740,26 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         uint64_t *q_seg = q_cnt + n_buckets;  // [0..1]: one input segment; [2..]: per-owner children
         uint64_t root[2] = {0, n_q};
         int qset = 0;
-        uint32_t *dummy[2] = {nullptr, nullptr};
         if (shard_bits && n_q) {  // group by owner shard = top shard_bits of the bucket hash
             const int nsh = 1 << shard_bits;
             HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
             uint64_t *o_start = q_seg + 2, *o_cnt = o_start + nsh;
-            CHK((multisplit_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, true, n_q, qk[0], qm[0], dummy[0], qk[1], qm[1],
-                                                   dummy[1], 40 + SK_BUCKET_BITS - shard_bits, nsh, o_start, o_cnt,
-                                                   h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+            CHK((multisplit_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, true, n_q, qk[0], qm[0], qc[0], qk[1], qm[1], qc[1],
+                                                  40 + SK_BUCKET_BITS - shard_bits, nsh, o_start, o_cnt, h->ar_misc[2],
+                                                  h->ar_misc[3], h->ar_misc[4])));
             ShardState &sh = shard_of(h);
             sh.q_start.assign(nsh, 0);
             sh.q_cnt.assign(nsh, 0);
             HIPCHK(h, hipMemcpyAsync(sh.q_start.data(), o_start, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipMemcpyAsync(sh.q_cnt.data(), o_cnt, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            // park everything (keys + metas, grouped by owner) before the local group is shuffled further
+            // park everything (keys, metas, CSR positions, grouped by owner) before the local group is shuffled further
             CHK(buf_ensure(h, h->ar_shard[0], n_q * 8));
             CHK(buf_ensure(h, h->ar_shard[1], n_q * 8));
+            CHK(buf_ensure(h, h->ar_shard[3], n_q * 4));
             HIPCHK(h, hipMemcpyAsync(h->ar_shard[0].p, qk[1], n_q * 8, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(h, hipMemcpyAsync(h->ar_shard[1].p, qm[1], n_q * 8, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipMemcpyAsync(h->ar_shard[3].p, qc[1], n_q * 4, hipMemcpyDeviceToDevice, h->stream));
             root[0] = sh.q_start[my_shard];
             root[1] = sh.q_cnt[my_shard];
             sh.n_remote = n_q - root[1];
@@ -1754,10 +1770,11 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (n_q) {
             HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
             uint64_t *qk2[2] = {qk[qset], qk[qset ^ 1]}, *qm2[2] = {qm[qset], qm[qset ^ 1]};
+            uint32_t *qc2[2] = {qc[qset], qc[qset ^ 1]};
             int qwhere = 0;
             if (T > 0) {
-                CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n_q, qk2, qm2, dummy, 40, l1, l2, q_start,
-                                                           q_cnt, &qwhere)));
+                CHK((multisplit_two_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, n_q, qk2, qm2, qc2, 40, l1, l2, q_start,
+                                                          q_cnt, &qwhere)));
             } else {
                 HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
                 HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
@@ -1766,7 +1783,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             const size_t lds = sizeof(AnsLds<CAP>);
             HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt,
-                               qk2[qwhere], qm2[qwhere], h->d_keys, h->d_succ, sc_dev);
+                               qk2[qwhere], qm2[qwhere], qc2[qwhere], h->d_keys, h->d_succ, h->d_col, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1840,14 +1857,15 @@ __global__ __launch_bounds__(256) void k_tag_local(uint32_t *succ, uint64_t n, u
     if (i < n && succ[i] != NO_NODE) succ[i] |= tag;
 }
 
-__global__ __launch_bounds__(256) void k_apply_remote(const uint64_t *__restrict__ meta, const uint32_t *__restrict__ ans,
-                                                      uint64_t n, uint32_t tag, uint32_t *succ,
-                                                      unsigned long long *scalars) {
+__global__ __launch_bounds__(256) void k_apply_remote(const uint64_t *__restrict__ meta, const uint32_t *__restrict__ qcol,
+                                                      const uint32_t *__restrict__ ans, uint64_t n, uint32_t tag,
+                                                      uint32_t *succ, uint32_t *col, unsigned long long *scalars) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t a = ans[i];
     if (a == NO_NODE || a >= (1u << 29)) { atomicOr(&scalars[0], 256ull); return; }
     succ[meta[i] & ((1ull << 40) - 1)] = tag | a;
+    col[qcol[i]] = tag | a;
 }
 
 static int shard_args_ok(dbg *h, int k, int n_shards) {
@@ -1990,7 +2008,7 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     const size_t lds = sizeof(AnsLds<4096>);
     HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)h->sk_n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt, qk[qwhere],
-                       qm[qwhere], h->d_keys, (uint32_t *)d_answers, sc_dev);
+                       qm[qwhere], (const uint32_t *)nullptr, h->d_keys, (uint32_t *)d_answers, (uint32_t *)nullptr, sc_dev);
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;
     HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -2005,16 +2023,21 @@ extern "C" int dbg_shard_apply(dbg_t *h, const void *d_answers) {
     ShardState &sh = shard_of(h);
     Timer t(h->stream);
     HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-    if (h->n_nodes)
+    if (h->n_nodes) {
         hipLaunchKernelGGL(k_tag_local, dim3(grid_for(h->n_nodes * 4, 256)), dim3(256), 0, h->stream, h->d_succ,
                            h->n_nodes * 4, (uint32_t)sh.my_shard << 29);
+        if (h->n_edges)
+            hipLaunchKernelGGL(k_tag_local, dim3(grid_for(h->n_edges, 256)), dim3(256), 0, h->stream, h->d_col, h->n_edges,
+                               (uint32_t)sh.my_shard << 29);
+    }
     const uint64_t *meta = (const uint64_t *)h->ar_shard[1].p;
+    const uint32_t *qcol = (const uint32_t *)h->ar_shard[3].p;
     for (int d = 0; d < sh.n_shards; ++d) {
         if (d == sh.my_shard || !sh.q_cnt[d]) continue;
         if (!d_answers) { h->err = "answers missing"; return DBG_E_ARG; }
         hipLaunchKernelGGL(k_apply_remote, dim3(grid_for(sh.q_cnt[d], 256)), dim3(256), 0, h->stream, meta + sh.q_start[d],
-                           (const uint32_t *)d_answers + sh.q_start[d], sh.q_cnt[d], (uint32_t)d << 29, h->d_succ,
-                           (unsigned long long *)h->d_scalars);
+                           qcol + sh.q_start[d], (const uint32_t *)d_answers + sh.q_start[d], sh.q_cnt[d],
+                           (uint32_t)d << 29, h->d_succ, h->d_col, (unsigned long long *)h->d_scalars);
     }
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;

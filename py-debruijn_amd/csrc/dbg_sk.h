@@ -601,10 +601,10 @@ __device__ inline uint32_t slot_of(uint64_t kmer) {
 }
 
 // cross-bucket successor queries staged per workgroup; also the record staging depth.  With 64-bit
-// stamps the 4096-slot table leaves room for 512 only.
+// stamps the 4096-slot table leaves room for ~300 only (the edge-offset array took the rest).
 template <class ST, int CAP>
 struct CntCfg {
-    static constexpr int QBUF = (sizeof(ST) == 8 && CAP == 4096) ? 512 : 1024;
+    static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 304 : 768) : 1024;
 };
 constexpr int CNT_STACK = 24;    // pending hash sub-ranges of one bucket
 constexpr int CNT_NT = 1024;     // threads per bucket workgroup (one workgroup per CU: the table fills the LDS)
@@ -618,13 +618,14 @@ struct CntLds {
     ST stamp[CAP];
     uint16_t idx[CAP];    // slot -> local node index
     uint16_t list[CAP];   // local node index -> slot
+    uint16_t eoff[CAP];   // local node index -> first CSR edge of the node, relative to the bucket
     unsigned long long q_key[CNT_QBUF];   // insert phase: staged record w0; afterwards: query keys
     unsigned long long q_meta[CNT_QBUF];  // insert phase: staged record w1; afterwards: query meta
     ST st_stage[CNT_QBUF];                // insert phase: staged record stamps
     uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
     int stk_n;
-    uint32_t overflow, n_local, n_q, fail, n_flat;
-    unsigned long long gbase, qbase;
+    uint32_t overflow, n_local /* nodes | edges << 16 while the list is built */, n_q, fail, n_flat;
+    unsigned long long gbase, qbase, ebase;
 };
 
 // k-mer i of a record: 32-base window starting at base i (first base in bits 63:62)
@@ -647,15 +648,19 @@ __device__ inline int lds_find(const unsigned long long *keys, uint64_t key) {
 struct SkCountOut {
     uint64_t *keys, *stamps;
     uint32_t *cnt;
-    uint8_t *flags, *order, *deg;
+    uint8_t *flags, *order;
     uint32_t *succ;
     uint64_t node_cap;
-    uint64_t *q_key, *q_meta;
+    uint64_t *rowptr;          // CSR: first edge of every node
+    uint32_t *col, *ecnt;      // CSR: successor id (NO_NODE until k_q_answer fills a cross-bucket one), count
+    uint64_t edge_cap;
+    uint64_t *q_key, *q_meta;  // cross-bucket successors: k-mer, bucket << 40 | dense succ slot
+    uint32_t *q_col;           // ... and the CSR position to patch
     uint64_t q_cap;
     SkRange *ranges;        // [0, n_buckets): the unsplit range of each bucket; beyond: ranges of split buckets
     uint64_t n_buckets;
     uint64_t range_cap;
-    unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | queries (high 32) [6] extra ranges
+    unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | edges (high 32) [5] queries [6] extra ranges
 };
 
 // wave-aggregated LDS counter: returns this lane's index, adds popcount(active & pred) once per wave
@@ -824,15 +829,39 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                 }
                 continue;
             }
-            // ---- dense list of occupied slots (one LDS atomic per wave)
+            // ---- dense list of occupied slots + CSR edge offsets: one packed LDS atomic per wave hands out a
+            //      block of node indices and the matching block of edge slots, so rows stay in node order
             for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
                 const bool occ = s.keys[i] != EMPTY_KEY;
-                const uint32_t li = wave_alloc(&s.n_local, occ);
-                if (occ) { s.idx[i] = (uint16_t)li; s.list[li] = (uint16_t)i; }
+                uint32_t deg = 0;
+                if (occ) {
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
+                    deg = (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
+                }
+                const unsigned long long mask = __ballot(occ);
+                if (mask) {
+                    const int lane = threadIdx.x & 63;
+                    uint32_t einc = deg;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) {
+                        const uint32_t o = __shfl_up(einc, d, 64);
+                        if (lane >= d) einc += o;
+                    }
+                    const uint32_t etot = __shfl(einc, 63, 64);
+                    uint32_t base = 0;
+                    if (lane == 63) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
+                    base = __shfl(base, 63, 64);
+                    if (occ) {
+                        const uint32_t li = (base & 0xFFFFu) + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+                        s.idx[i] = (uint16_t)li;
+                        s.list[li] = (uint16_t)i;
+                        s.eoff[li] = (uint16_t)((base >> 16) + einc - deg);
+                    }
+                }
             }
             __syncthreads();
             if (phase_limit == 3) { skip_rest = true; break; }  // + dense list
-            const uint32_t n_local = s.n_local;
+            const uint32_t n_local = s.n_local & 0xFFFFu, n_edges_local = s.n_local >> 16;
             // ---- successor lookups into registers; misses are staged as queries (slot index local for now).
             //      Per node only the bases that occur are looked up (usually one): the wave loops
             //      max-popcount times instead of four.  Result per base, 16 bits: local node index,
@@ -878,14 +907,14 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
             __syncthreads();
             if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
             const uint32_t nq = s.n_q;
-            if (threadIdx.x == 0) {  // one packed reservation: nodes in the low half, queries in the high half
+            if (threadIdx.x == 0) {  // one packed reservation: nodes (low half) and CSR edges (high half) advance together
                 const unsigned long long got =
-                    atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)nq << 32));
-                const unsigned long long base = got & 0xFFFFFFFFull, qb = got >> 32;
+                    atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
+                const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
                 s.gbase = base;
-                s.qbase = qb;
+                s.ebase = eb;
                 if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
-                if (qb + nq > out.q_cap || qb + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+                if (eb + n_edges_local > out.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
                 uint64_t ri = bucket;
                 if (cur_mask) {
                     ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
@@ -897,14 +926,31 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                     out.ranges[ri] = rg;
                 }
             }
+            if (threadIdx.x == 64 && nq) {  // the query list has its own cursor (another wave: both atomics in flight together)
+                const unsigned long long qb = atomicAdd(&out.scalars[5], (unsigned long long)nq);
+                s.qbase = qb;
+                if (qb + nq > out.q_cap || qb + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+            }
             // while the reservation is in flight: minimizer bucket of every staged query (dense, no divergence)
             for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
                 s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
             __syncthreads();
             if (phase_limit == 5) { skip_rest = true; break; }  // + reservation + query buckets
             if (s.fail) break;
-            const uint64_t gbase = s.gbase, qbase = s.qbase;
-            // ---- write nodes: consecutive lanes -> consecutive nodes; every slot read is cleared for the next bucket
+            const uint64_t gbase = s.gbase, qbase = s.qbase, ebase = s.ebase;
+            // ---- staged queries out (before the node pass clears the counters they rank against)
+            for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
+                const unsigned long long meta = s.q_meta[i];
+                const uint32_t lslot = (uint32_t)(meta & 0xFFFFFFFFFFull), li = lslot >> 2, b = lslot & 3u;
+                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[s.list[li]];
+                const uint32_t nzb = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
+                out.q_key[qbase + i] = s.q_key[i];
+                out.q_meta[qbase + i] = meta + gbase * 4;  // local slot index -> global
+                out.q_col[qbase + i] = (uint32_t)(ebase + s.eoff[li] + __popc(nzb & ((1u << b) - 1u)));
+            }
+            __syncthreads();
+            // ---- write nodes and their CSR rows: consecutive lanes -> consecutive nodes; every slot read is
+            //      cleared for the next bucket
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 if ((uint32_t)(u * CNT_NT) >= n_local) break;
@@ -923,7 +969,6 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                 out.stamps[node] = stamp;
                 reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
                 out.flags[node] = (uint8_t)(stamp & 1);
-                out.deg[node] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
                 uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
 #pragma unroll
                 for (int a = 1; a < 4; ++a) {
@@ -934,6 +979,8 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                 }
                 out.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
                 uint32_t sc[4];
+                uint64_t e = ebase + s.eoff[li];
+                out.rowptr[node] = e;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
@@ -943,13 +990,15 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                         const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
                         out.q_key[qbase + qi] = skey;
                         out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
+                        out.q_col[qbase + qi] = (uint32_t)e;
+                    }
+                    if (c[b]) {
+                        out.col[e] = sc[b];
+                        out.ecnt[e] = c[b];
+                        ++e;
                     }
                 }
                 reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
-            }
-            for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
-                out.q_key[qbase + i] = s.q_key[i];
-                out.q_meta[qbase + i] = s.q_meta[i] + gbase * 4;  // local slot index -> global
             }
             clean = true;  // every occupied slot was reset above (uniform: all waves pass here)
         }
@@ -971,8 +1020,9 @@ struct AnsLds {
 template <int CAP>
 __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ q_start,
                                                   const uint64_t *__restrict__ q_cnt, const uint64_t *__restrict__ q_key,
-                                                  const uint64_t *__restrict__ q_meta, const uint64_t *__restrict__ keys,
-                                                  uint32_t *succ, unsigned long long *scalars) {
+                                                  const uint64_t *__restrict__ q_meta, const uint32_t *__restrict__ q_col,
+                                                  const uint64_t *__restrict__ keys, uint32_t *succ, uint32_t *col,
+                                                  unsigned long long *scalars) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ans_raw[];
     AnsLds<CAP> &s = *reinterpret_cast<AnsLds<CAP> *>(ans_raw);
     const SkRange rg = ranges[blockIdx.x];
@@ -997,7 +1047,9 @@ __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ra
         if (rg.mask && (sub_hash(skey) & rg.mask) != rg.val) continue;
         const int f = lds_find<CAP>(s.keys, skey);
         if (f < 0) { atomicOr(&scalars[0], 128ull); continue; }  // every successor exists as a node
-        succ[q_meta[qb + i] & ((1ull << 40) - 1)] = (uint32_t)(rg.node_base + s.idx[f]);
+        const uint32_t id = (uint32_t)(rg.node_base + s.idx[f]);
+        succ[q_meta[qb + i] & ((1ull << 40) - 1)] = id;
+        if (col) col[q_col[qb + i]] = id;
     }
 }
 
