@@ -862,6 +862,11 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
             __syncthreads();
             if (phase_limit == 3) { skip_rest = true; break; }  // + dense list
             const uint32_t n_local = s.n_local & 0xFFFFu, n_edges_local = s.n_local >> 16;
+            // ---- reservation of the node ids and CSR rows: one packed global atomic, issued now and consumed after
+            //      the lookups (its ~1.5 us round trip hides behind them)
+            unsigned long long got = 0;
+            if (threadIdx.x == 0)
+                got = atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
             // ---- successor lookups into registers; misses are staged as queries (slot index local for now).
             //      Per node only the bases that occur are looked up (usually one): the wave loops
             //      max-popcount times instead of four.  Result per base, 16 bits: local node index,
@@ -880,6 +885,7 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                     const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[sl];
                     nz = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
                 }
+                const uint32_t nz_all = nz;
                 uint32_t missmask = 0;
                 while (nz) {
                     const uint32_t b = __ffs(nz) - 1;
@@ -895,7 +901,9 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                     unsigned long long code;
                     if (qi < CNT_QBUF) {
                         s.q_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
-                        s.q_meta[qi] = (unsigned long long)li * 4 + b;
+                        // local dense slot (li*4+b) in bits 0..15, bucket-relative CSR column in bits 16..31
+                        s.q_meta[qi] = ((unsigned long long)li * 4 + b) |
+                                       ((unsigned long long)(s.eoff[li] + __popc(nz_all & ((1u << b) - 1u))) << 16);
                         code = 0xFFFEull;
                     } else {
                         code = 0x8000ull | (qi - CNT_QBUF);
@@ -907,9 +915,9 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
             __syncthreads();
             if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
             const uint32_t nq = s.n_q;
-            if (threadIdx.x == 0) {  // one packed reservation: nodes (low half) and CSR edges (high half) advance together
-                const unsigned long long got =
-                    atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
+            unsigned long long qgot = 0;
+            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);  // query cursor
+            if (threadIdx.x == 0) {
                 const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
                 s.gbase = base;
                 s.ebase = eb;
@@ -926,29 +934,13 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                     out.ranges[ri] = rg;
                 }
             }
-            if (threadIdx.x == 64 && nq) {  // the query list has its own cursor (another wave: both atomics in flight together)
-                const unsigned long long qb = atomicAdd(&out.scalars[5], (unsigned long long)nq);
-                s.qbase = qb;
-                if (qb + nq > out.q_cap || qb + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
-            }
-            // while the reservation is in flight: minimizer bucket of every staged query (dense, no divergence)
+            // minimizer bucket of every staged query (dense, no divergence) while the query cursor is in flight
             for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
                 s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
             __syncthreads();
             if (phase_limit == 5) { skip_rest = true; break; }  // + reservation + query buckets
             if (s.fail) break;
-            const uint64_t gbase = s.gbase, qbase = s.qbase, ebase = s.ebase;
-            // ---- staged queries out (before the node pass clears the counters they rank against)
-            for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
-                const unsigned long long meta = s.q_meta[i];
-                const uint32_t lslot = (uint32_t)(meta & 0xFFFFFFFFFFull), li = lslot >> 2, b = lslot & 3u;
-                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[s.list[li]];
-                const uint32_t nzb = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
-                out.q_key[qbase + i] = s.q_key[i];
-                out.q_meta[qbase + i] = meta + gbase * 4;  // local slot index -> global
-                out.q_col[qbase + i] = (uint32_t)(ebase + s.eoff[li] + __popc(nzb & ((1u << b) - 1u)));
-            }
-            __syncthreads();
+            const uint64_t gbase = s.gbase, ebase = s.ebase;
             // ---- write nodes and their CSR rows: consecutive lanes -> consecutive nodes; every slot read is
             //      cleared for the next bucket
 #pragma unroll
@@ -985,13 +977,6 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
                     sc[b] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
-                    if (v >= 0x8000u && v < 0xFFFEu) {  // query that did not fit the staging buffer: write it straight out
-                        const uint64_t qi = (uint64_t)(v & 0x7FFFu) + CNT_QBUF;
-                        const uint64_t skey = ((key << 2) | (uint64_t)b) & kmask;
-                        out.q_key[qbase + qi] = skey;
-                        out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
-                        out.q_col[qbase + qi] = (uint32_t)e;
-                    }
                     if (c[b]) {
                         out.col[e] = sc[b];
                         out.ecnt[e] = c[b];
@@ -999,6 +984,43 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
                     }
                 }
                 reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+            }
+            // ---- queries out (the cursor has had the whole node pass to come back)
+            if (threadIdx.x == 64 && nq) {
+                s.qbase = qgot;
+                if (qgot + nq > out.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+            }
+            __syncthreads();
+            if (s.fail) break;
+            if (nq) {
+                const uint64_t qbase = s.qbase;
+                for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
+                    const unsigned long long meta = s.q_meta[i];
+                    out.q_key[qbase + i] = s.q_key[i];
+                    out.q_meta[qbase + i] = (meta & ~0xFFFFFFFFull) | ((meta & 0xFFFFull) + gbase * 4);
+                    out.q_col[qbase + i] = (uint32_t)(ebase + ((meta >> 16) & 0xFFFFull));
+                }
+                if (nq > (uint32_t)CNT_QBUF) {  // rare: queries that did not fit the staging, straight from the registers
+#pragma unroll
+                    for (int u = 0; u < NPT; ++u) {
+                        const uint32_t li = threadIdx.x + u * CNT_NT;
+                        if (li >= n_local) continue;
+                        uint32_t rank = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
+                            if (v >= 0x8000u && v < 0xFFFEu) {
+                                const uint64_t qi = (uint64_t)(v & 0x7FFFu) + CNT_QBUF;
+                                const uint64_t node = gbase + li;
+                                const uint64_t skey = ((out.keys[node] << 2) | (uint64_t)b) & kmask;
+                                out.q_key[qbase + qi] = skey;
+                                out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
+                                out.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
+                            }
+                            if (v != 0xFFFFu) ++rank;  // every base that occurs owns one CSR column
+                        }
+                    }
+                }
             }
             clean = true;  // every occupied slot was reset above (uniform: all waves pass here)
         }
