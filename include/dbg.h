@@ -72,6 +72,7 @@ typedef struct dbg_sizes {
     uint64_t n_contigs;
     uint64_t contig_chars;     /* total characters over all contigs */
     uint64_t tip_rounds;       /* reservation rounds the tip removal needed */
+    uint64_t contigs_materialised; /* 1: contig text available (dbg_export_contigs); 0: index only */
 } dbg_sizes_t;
 
 typedef struct dbg_stats {
@@ -103,7 +104,8 @@ const char *dbg_last_error(const dbg_t *h);
 int dbg_abi_version(void);
 /* Tunables (no reference counterpart): "engine" 0 = partitioned super-k-mer build (default),
  * 1 = single global hash table; "bucket_bits" 0 = auto, else log2 of the bucket count (<= 18);
- * "lds_slots" 2048 or 4096 slots of the per-bucket LDS table. */
+ * "lds_slots" 2048 or 4096 slots of the per-bucket LDS table; "walk_jump_min_nodes" see dbg_walk;
+ * "phase_limit" timing ablation of the count kernel (the build then fails on purpose). */
 int dbg_set_option(dbg_t *h, const char *name, int64_t value);
 
 /* ---- reads (replaces the `reads` list argument, debruijn.py:206; FASTA
@@ -135,6 +137,9 @@ int dbg_mark_pull_reads(dbg_t *h);
  *      (II_assembleFromReads.py:14-18).  final_mode != 0 walks with branch_kmer == []
  *      (debruijn.py:281-283).  max_chars bounds the materialised contig text (0 = 1 GiB). */
 int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars);
+/* Non-final walks of graphs with >= "walk_jump_min_nodes" nodes (dbg_set_option, default 2^20) resolve every
+ * chain by pointer jumping (contigs overlap massively at scale); if the text would exceed max_chars
+ * dbg_walk still returns DBG_OK with the contig index only (dbg_get_sizes: contigs_materialised == 0). */
 
 int dbg_get_sizes(dbg_t *h, dbg_sizes_t *out);
 int dbg_get_stats(dbg_t *h, dbg_stats_t *out);
@@ -155,6 +160,8 @@ int dbg_export_pull_reads(dbg_t *h, uint8_t *read_flags /* [n_reads] */);
  * seq_in_start[n_contigs] (emission index within its start) */
 int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint64_t *scores, uint64_t *start_stamp,
                        uint32_t *seq_in_start);
+/* the same without the text: offsets[n_contigs+1] (contig i has offsets[i+1]-offsets[i] characters) */
+int dbg_export_contig_index(dbg_t *h, uint64_t *offsets, uint64_t *scores, uint64_t *start_stamp, uint32_t *seq_in_start);
 /* device-side views for callers that stay on the GPU (valid until the next build/destroy) */
 int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const void **d_stamps,
                      const void **d_flags, const void **d_succ);

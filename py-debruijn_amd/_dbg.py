@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdbg_hip.so")
+LIB_PATH = os.environ.get("DBG_LIB") or os.path.join(_HERE, "libdbg_hip.so")  # DBG_LIB: A/B builds (tools/)
 
 DBG_OK, DBG_E_ARG, DBG_E_HIP, DBG_E_ALPHABET, DBG_E_CAPACITY, DBG_E_NOMEM = 0, -1, -2, -3, -4, -5
 F_INDEG, F_KEEP_MASK, F_KEEP_SHIFT, F_BRANCH, F_PULLED = 0x01, 0x1E, 1, 0x20, 0x40
@@ -24,8 +24,8 @@ SYMBOLS = (
     "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_device",
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
-    "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs", "dbg_device_views",
-    "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
+    "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
+    "dbg_export_contig_index", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
 )
 
 
@@ -33,7 +33,8 @@ class Sizes(C.Structure):
     _fields_ = [("k", C.c_int32), ("abi_version", C.c_int32)] + [
         (n, C.c_uint64) for n in (
             "n_reads", "n_bytes", "n_kmer_instances", "n_edge_instances", "table_capacity", "n_nodes", "n_edges",
-            "n_branch", "n_pulled", "n_pull_reads", "n_starts", "n_contigs", "contig_chars", "tip_rounds")]
+            "n_branch", "n_pulled", "n_pull_reads", "n_starts", "n_contigs", "contig_chars", "tip_rounds",
+            "contigs_materialised")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -98,6 +99,7 @@ def load_library():
         "dbg_export_pull_ranks": (C.c_int, [H, vp]),
         "dbg_export_pull_reads": (C.c_int, [H, vp]),
         "dbg_export_contigs": (C.c_int, [H, vp, vp, vp, vp, vp]),
+        "dbg_export_contig_index": (C.c_int, [H, vp, vp, vp, vp]),
         "dbg_device_views": (C.c_int, [H] + [C.POINTER(vp)] * 5),
         "dbg_shard_extract": (C.c_int, [H, C.c_int, C.c_int, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
@@ -137,7 +139,8 @@ class Graph:
             self._h = None
             raise DbgError(rc, "dbg_create failed: no usable MI355X visible (the device path has no CPU fallback)")
         self._keep = []  # buffers the device borrows
-        for var, opt in (("DBG_ENGINE", "engine"), ("DBG_BUCKET_BITS", "bucket_bits"), ("DBG_LDS_SLOTS", "lds_slots")):
+        for var, opt in (("DBG_ENGINE", "engine"), ("DBG_BUCKET_BITS", "bucket_bits"), ("DBG_LDS_SLOTS", "lds_slots"),
+                         ("DBG_WALK_JUMP_MIN", "walk_jump_min_nodes")):
             if os.environ.get(var, "") != "":
                 self.set_option(opt, int(os.environ[var]))
 
@@ -249,6 +252,15 @@ class Graph:
         f = np.empty(self.sizes()["n_reads"], dtype=np.uint8)
         self._chk(self._lib.dbg_export_pull_reads(self._h, _ptr(f)))
         return f
+
+    def export_contig_index(self):
+        n = self.sizes()["n_contigs"]
+        off = np.empty(n + 1, dtype=np.uint64)
+        score = np.empty(n, dtype=np.uint64)
+        stamp = np.empty(n, dtype=np.uint64)
+        seq = np.empty(n, dtype=np.uint32)
+        self._chk(self._lib.dbg_export_contig_index(self._h, _ptr(off), _ptr(score), _ptr(stamp), _ptr(seq)))
+        return off, score, stamp, seq
 
     def export_contigs(self):
         sz = self.sizes()

@@ -3,6 +3,7 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-"$HIPCC" -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wall -Wno-unused-function \
-    -o ../libdbg_hip.so dbg_hip.hip
-echo "built $(cd .. && pwd)/libdbg_hip.so"
+OUT=${DBG_OUT:-../libdbg_hip.so}   # DBG_OUT / DBG_DEFS: experimental variants next to the product build
+"$HIPCC" -O3 --offload-arch=gfx950 -std=c++17 -shared -fPIC -Wall -Wno-unused-function ${DBG_DEFS:-} \
+    -o "$OUT" dbg_hip.hip
+echo "built $OUT"

@@ -77,7 +77,9 @@ struct dbg {
     char *d_ctg_chars = nullptr;
     uint64_t *d_ctg_score = nullptr, *d_ctg_stamp = nullptr;
     uint32_t *d_ctg_seq = nullptr;
-    bool walked = false;
+    bool walked = false;          // contig text materialised
+    bool walk_indexed = false;    // contig index (offsets, scores, start stamps) valid
+    uint64_t walk_jump_min = 1ull << 20;  // non-final walk: pointer jumping from this many nodes on
 
     // options (dbg_set_option)
     int engine = 0;          // 0 = super-k-mer partitioned build, 1 = single global hash table
@@ -841,6 +843,84 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// non-final walk at scale: pointer jumping.  Every start walks its chain to the next branch node /
+// dead end / pulled node, so contigs overlap massively (10M x 150 bp: 3.0e6 starts, 1.9e12 chain
+// steps in total).  Doubling resolves (end node, hops, score) of EVERY node's chain in
+// ceil(log2 n) rounds; a chain that never terminates is a cycle and emits nothing (debruijn.py:289-290).
+// ------------------------------------------------------------------------------------------
+struct Jump {
+    uint32_t target;
+    uint32_t pad;
+    unsigned long long hops;   // bit 63: chain is resolved (target is its last node)
+    unsigned long long score;  // sum of edge counts over the hops (getScore, II_assembleFromReads.py:14-18)
+};
+constexpr unsigned long long JUMP_TERM = 1ull << 63;
+
+__global__ __launch_bounds__(256) void k_jump_init(uint64_t n_nodes, const uint8_t *flags, const uint32_t *succ,
+                                                   const uint32_t *cnt, Jump *J) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes) return;
+    const uint8_t f = flags[v];
+    const uint32_t keep = (f & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;
+    Jump j{(uint32_t)v, 0, JUMP_TERM, 0};
+    if (!(f & (DBG_F_PULLED | DBG_F_BRANCH)) && keep) {  // chain node: exactly one surviving successor
+        const uint32_t code = __ffs(keep) - 1;
+        const uint32_t nxt = succ[v * 4 + code];
+        if (!(flags[nxt] & DBG_F_PULLED)) { j.target = nxt; j.hops = 1; j.score = cnt[v * 4 + code]; }
+    }
+    J[v] = j;
+}
+
+__global__ __launch_bounds__(256) void k_jump_step(uint64_t n_nodes, const Jump *__restrict__ in, Jump *__restrict__ out) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes) return;
+    Jump a = in[v];
+    if (!(a.hops & JUMP_TERM)) {
+        const Jump b = in[a.target];
+        a.target = b.target;
+        a.hops = (a.hops + (b.hops & ~JUMP_TERM)) | (b.hops & JUMP_TERM);
+        a.score += b.score;
+    }
+    out[v] = a;
+}
+
+struct UnresolvedStart {
+    const uint32_t *starts;
+    const Jump *J;
+    const uint8_t *flags;
+    __device__ uint64_t operator()(uint64_t i) const {
+        const uint32_t s = starts[i];
+        return !(flags[s] & DBG_F_PULLED) && !(J[s].hops & JUMP_TERM);
+    }
+};
+
+__global__ __launch_bounds__(256) void k_jump_starts(const uint32_t *starts, uint64_t n_starts, const Jump *J,
+                                                     const uint8_t *flags, int k, uint64_t *per_ctg, uint64_t *per_chr,
+                                                     uint64_t *per_score) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_starts) return;
+    const uint32_t s = starts[i];
+    const Jump a = J[s];
+    const bool emit = !(flags[s] & DBG_F_PULLED) && (a.hops & JUMP_TERM);
+    per_ctg[i] = emit;
+    per_chr[i] = emit ? (uint64_t)k + (a.hops & ~JUMP_TERM) : 0;
+    per_score[i] = emit ? a.score : 0;
+}
+
+__global__ __launch_bounds__(256) void k_walk_desc(const uint32_t *starts, uint64_t n_starts, const uint64_t *per_ctg,
+                                                   const uint64_t *ctg_base, const uint64_t *char_base,
+                                                   const uint64_t *per_score, const uint64_t *stamps, uint64_t *ctg_off,
+                                                   uint64_t *score_out, uint64_t *stamp_out, uint32_t *seq_out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_starts || !per_ctg[i]) return;
+    const uint64_t c = ctg_base[i];
+    ctg_off[c] = char_base[i];
+    score_out[c] = per_score[i];
+    stamp_out[c] = stamps[starts[i]];
+    seq_out[c] = 0;
+}
+
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
@@ -861,7 +941,7 @@ static void free_build(dbg *h) {
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
     dev_free(h->d_ctg_seq);
     h->k = 0; h->cap = 0; h->n_nodes = h->n_edges = 0;
-    h->pruned = h->tipped = h->pull_reads_done = h->walked = false;
+    h->pruned = h->tipped = h->pull_reads_done = h->walked = h->walk_indexed = false;
     h->n_branch = h->n_pulled = h->tip_rounds = h->n_pull_reads = 0;
     h->n_starts = h->n_contigs = h->contig_chars = 0;
     h->n_kmer_inst = h->n_edge_inst = 0;
@@ -1051,6 +1131,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "bucket_bits" && value >= 0 && value <= 18) { h->bucket_bits = (int)value; return DBG_OK; }
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
+    if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
 }
@@ -1258,14 +1339,17 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
     dev_free(h->d_ctg_seq);
     h->n_contigs = h->contig_chars = 0;
     h->walked = false;
+    h->walk_indexed = false;
     const uint64_t ns = h->n_starts;
+    const bool use_jump = !final_mode && h->n_nodes >= h->walk_jump_min && ns;
     uint32_t *starts = nullptr;
-    uint64_t *per_ctg = nullptr, *per_chr = nullptr, *base_ctg = nullptr, *base_chr = nullptr;
+    uint64_t *per_ctg = nullptr, *per_chr = nullptr, *base_ctg = nullptr, *base_chr = nullptr, *per_score = nullptr;
     uint32_t *st_node = nullptr, *onpath = nullptr;
     uint8_t *st_next = nullptr;
+    Jump *jump[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
         dev_free(starts); dev_free(per_ctg); dev_free(per_chr); dev_free(base_ctg); dev_free(base_chr);
-        dev_free(st_node); dev_free(onpath); dev_free(st_next);
+        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score); dev_free(jump[0]); dev_free(jump[1]);
     };
     int rc = DBG_OK;
     do {
@@ -1304,29 +1388,60 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
                                    per_ctg, per_chr, base_ctg, base_chr, h->d_ctg_off, h->d_ctg_chars,
                                    h->d_ctg_score, h->d_ctg_stamp, h->d_ctg_seq, h->d_stamps);
         };
-        launch(0);
+        if (use_jump) {
+            if ((rc = dev_alloc(h, &per_score, ns)) != DBG_OK) break;
+            if ((rc = dev_alloc(h, &jump[0], h->n_nodes)) != DBG_OK) break;
+            if ((rc = dev_alloc(h, &jump[1], h->n_nodes)) != DBG_OK) break;
+            const dim3 grid(grid_for(h->n_nodes, 256));
+            hipLaunchKernelGGL(k_jump_init, grid, dim3(256), 0, h->stream, h->n_nodes, h->d_flags, h->d_succ, h->d_cnt, jump[0]);
+            int cur = 0, max_rounds = 2;
+            while ((1ull << (max_rounds - 1)) < h->n_nodes) ++max_rounds;  // chains are shorter than n_nodes
+            for (int round = 0; round < max_rounds; ++round) {
+                uint64_t open = 0;
+                if ((rc = reduce_sum(h, ns, UnresolvedStart{starts, jump[cur], h->d_flags}, &open)) != DBG_OK) break;
+                if (!open) break;
+                hipLaunchKernelGGL(k_jump_step, grid, dim3(256), 0, h->stream, h->n_nodes, jump[cur], jump[cur ^ 1]);
+                cur ^= 1;
+            }
+            if (rc != DBG_OK) break;
+            hipLaunchKernelGGL(k_jump_starts, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, jump[cur],
+                               h->d_flags, h->k, per_ctg, per_chr, per_score);
+            dev_free(jump[0]);  // 24 B per node each: give them back before the text is allocated
+            dev_free(jump[1]);
+        } else {
+            launch(0);
+        }
         if (hipGetLastError() != hipSuccess) { h->err = "walk pass 0 launch failed"; rc = DBG_E_HIP; break; }
         uint64_t n_ctg = 0, n_chr = 0;
         if ((rc = exclusive_scan(h, ns, U64At{per_ctg}, base_ctg, &n_ctg)) != DBG_OK) break;
         if ((rc = exclusive_scan(h, ns, U64At{per_chr}, base_chr, &n_chr)) != DBG_OK) break;
         h->n_contigs = n_ctg;
         h->contig_chars = n_chr;
-        if (n_chr > max_chars) {
+        if (n_chr > max_chars && !use_jump) {
             h->err = "contig text exceeds max_chars (sizes are valid, text not materialised)";
             rc = DBG_E_CAPACITY;
             break;
         }
         if ((rc = dev_alloc(h, &h->d_ctg_off, n_ctg + 1)) != DBG_OK) break;
-        if ((rc = dev_alloc(h, &h->d_ctg_chars, n_chr)) != DBG_OK) break;
         if ((rc = dev_alloc(h, &h->d_ctg_score, n_ctg)) != DBG_OK) break;
         if ((rc = dev_alloc(h, &h->d_ctg_stamp, n_ctg)) != DBG_OK) break;
         if ((rc = dev_alloc(h, &h->d_ctg_seq, n_ctg)) != DBG_OK) break;
         (void)hipMemcpyAsync(h->d_ctg_off + n_ctg, &h->contig_chars, 8, hipMemcpyHostToDevice, h->stream);
+        if (use_jump) {  // the index (offsets, scores, start stamps) comes straight from the jump table
+            hipLaunchKernelGGL(k_walk_desc, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, per_ctg, base_ctg,
+                               base_chr, per_score, h->d_stamps, h->d_ctg_off, h->d_ctg_score, h->d_ctg_stamp, h->d_ctg_seq);
+            hipError_t e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { h->err = std::string("walk index: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
+            h->walk_indexed = true;
+            if (n_chr > max_chars) break;  // index only: the text would not fit (rc stays DBG_OK)
+        }
+        if ((rc = dev_alloc(h, &h->d_ctg_chars, n_chr)) != DBG_OK) break;
         launch(1);
         if (hipGetLastError() != hipSuccess) { h->err = "walk pass 1 launch failed"; rc = DBG_E_HIP; break; }
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { h->err = std::string("walk: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
         h->walked = true;
+        h->walk_indexed = true;
     } while (0);
     cleanup();
     h->stats.ms_walk = t.stop();
@@ -1352,6 +1467,7 @@ extern "C" int dbg_get_sizes(dbg_t *h, dbg_sizes_t *o) {
     o->n_contigs = h->n_contigs;
     o->contig_chars = h->contig_chars;
     o->tip_rounds = h->tip_rounds;
+    o->contigs_materialised = h->walked ? 1 : 0;
     return DBG_OK;
 }
 
@@ -1408,9 +1524,25 @@ extern "C" int dbg_export_pull_reads(dbg_t *h, uint8_t *read_flags) {
     return DBG_OK;
 }
 
+extern "C" int dbg_export_contig_index(dbg_t *h, uint64_t *offsets, uint64_t *scores, uint64_t *start_stamp,
+                                       uint32_t *seq_in_start) {
+    if (!h || !h->walk_indexed) { if (h) h->err = "dbg_walk must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    D2H(h, offsets, h->d_ctg_off, (h->n_contigs + 1) * 8);
+    D2H(h, scores, h->d_ctg_score, h->n_contigs * 8);
+    D2H(h, start_stamp, h->d_ctg_stamp, h->n_contigs * 8);
+    D2H(h, seq_in_start, h->d_ctg_seq, h->n_contigs * 4);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
 extern "C" int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint64_t *scores, uint64_t *start_stamp,
                                   uint32_t *seq_in_start) {
-    if (!h || !h->walked) { if (h) h->err = "dbg_walk must run first"; return DBG_E_ARG; }
+    if (!h || !h->walked) {
+        if (h) h->err = h->walk_indexed ? "contig text was not materialised (larger than max_chars): use dbg_export_contig_index"
+                                        : "dbg_walk must run first";
+        return DBG_E_ARG;
+    }
     HIPCHK(h, hipSetDevice(h->device));
     D2H(h, offsets, h->d_ctg_off, (h->n_contigs + 1) * 8);
     D2H(h, chars, h->d_ctg_chars, h->contig_chars);

@@ -214,8 +214,11 @@ struct SkLdsW {
     uint32_t nrec;
 };
 
+#ifndef DBG_EXW_WAVES
+#define DBG_EXW_WAVES 3
+#endif
 template <class ST, int W>
-__global__ __launch_bounds__(256) void k_sk_extract_w(const char *__restrict__ bases, uint64_t n_bytes,
+__global__ __launch_bounds__(256, DBG_EXW_WAVES) void k_sk_extract_w(const char *__restrict__ bases, uint64_t n_bytes,
                                                       const uint32_t *__restrict__ startbits, uint64_t n_tiles,
                                                       uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
                                                       uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
@@ -371,8 +374,11 @@ __global__ __launch_bounds__(256) void k_sk_extract_w(const char *__restrict__ b
 // nb children each; a workgroup owns one super-chunk (MS_SC records of one parent).
 // counts matrix: cmat[sc * nb + b]; offsets come from an exclusive scan in (parent, b, sc) order.
 // ------------------------------------------------------------------------------------------------
-constexpr int MS_CH = 4096;           // records sorted per LDS round
-constexpr int MS_SC = 8 * MS_CH;      // records per super-chunk
+#ifndef DBG_MS_CH
+#define DBG_MS_CH 4096
+#endif
+constexpr int MS_CH = DBG_MS_CH;      // records sorted per LDS round
+constexpr int MS_SC = 32768;          // records per super-chunk
 constexpr int MS_MAX_NB = 512;
 
 // Input of one multisplit level: `n_seg` contiguous segments of the record arrays.  Either all

@@ -44,8 +44,8 @@ def test_binding_covers_header():
 
 def test_struct_layouts_match_header(lib):
     import _dbg
-    # dbg_sizes_t: 2 x int32 + 14 x uint64; dbg_stats_t: 14 doubles + 4 uint64
-    assert ctypes.sizeof(_dbg.Sizes) == 8 + 14 * 8
+    # dbg_sizes_t: 2 x int32 + 15 x uint64; dbg_stats_t: 14 doubles + 4 uint64
+    assert ctypes.sizeof(_dbg.Sizes) == 8 + 15 * 8
     assert ctypes.sizeof(_dbg.Stats) == 14 * 8 + 4 * 8
 
 

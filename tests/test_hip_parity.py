@@ -161,3 +161,41 @@ def test_csr_matches_node_table():
         want = ((keys[has] << np.uint64(2)) | np.uint64(code)) & mask
         assert np.array_equal(keys[succ[has, code]], want)
     assert len(np.unique(keys)) == keys.size and len(np.unique(stamps)) == stamps.size
+
+
+@pytest.mark.parametrize("name", [n for n in golden_case_names() if "nonfinal" in n or n.startswith("dna_")])
+def test_walk_by_pointer_jumping(name, monkeypatch):
+    """Non-final walk through the pointer-jumping path (the one used at scale), forced on at test sizes."""
+    case = load_golden(name)
+    reads = case_reads(case)
+    inp = case["inputs"]
+    if not is_dna(reads) or inp["final"]:
+        pytest.skip("DNA, non-final only")
+    monkeypatch.setenv("DBG_WALK_JUMP_MIN", "0")
+    got = run_product(reads, inp["k"], inp["threshold"], False)
+    want = run_oracle(reads, inp["k"], inp["threshold"], False)
+    assert got["contigs"] == want["contigs"]
+    assert got["scores"] == want["scores"]
+
+
+def test_walk_index_without_text():
+    """max_chars too small: the walk still returns the contig index (lengths, scores, start stamps)."""
+    import _dbg
+    import synth
+    reads = synth.reads_ascii(8, 20000, 2500, 100, 0.01)
+    g = _dbg.Graph()
+    g.set_option("walk_jump_min_nodes", 0)
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64))
+    g.build(21)
+    g.prune(2)
+    g.remove_tips()
+    g.walk(False)
+    off, chars, score, stamp, seq = g.export_contigs()
+    g.walk(False, max_chars=1000)
+    assert g.sizes()["contigs_materialised"] == 0
+    off2, score2, stamp2, seq2 = g.export_contig_index()
+    a, b = np.argsort(stamp), np.argsort(stamp2)  # the start list is collected in no particular order
+    assert np.array_equal(stamp[a], stamp2[b]) and np.array_equal(score[a], score2[b])
+    assert np.array_equal(np.diff(off.astype(np.int64))[a], np.diff(off2.astype(np.int64))[b])
+    with pytest.raises(_dbg.DbgError):
+        g.export_contigs()
