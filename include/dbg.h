@@ -127,6 +127,15 @@ int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets); /* D2H of the curr
  * otherwise a slot count (rounded up to a power of two); DBG_E_CAPACITY if too small. */
 int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint);
 
+/* ---- exact successor order (Counter semantics of debruijn.py:159-165 and :215-216): finds the first
+ *      occurrence of every out-edge of the nodes with >= 2 distinct successors (one more pass over the
+ *      reads) and rewrites the per-node rank bytes.  Without it equal-count successors are ranked
+ *      A<C<G<T; sets, counts and degrees do not depend on it.  Call after dbg_build, before dbg_prune. */
+int dbg_refine_edge_order(dbg_t *h);
+/* order[n_nodes]: successor base codes, 2 bits each, rank 0 in bits 1:0: count descending, ties by first
+ * appearance (== Counter.most_common); fsorder[n_nodes]: by first appearance (== Counter key order). */
+int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder);
+
 /* ---- a5 + a6: pruningEdges (debruijn.py:150-166) + branch detection (:230-236) */
 int dbg_prune(dbg_t *h, double threshold);
 /* ---- a7: tip removal (debruijn.py:169-186 driven by :241-254) */

@@ -22,7 +22,8 @@ ABI_VERSION = 1
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
     "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_device",
-    "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_prune", "dbg_remove_tips",
+    "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
+    "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
@@ -87,6 +88,8 @@ def load_library():
         "dbg_reads_checksum": (C.c_int, [H, u64p]),
         "dbg_copy_reads": (C.c_int, [H, vp, vp]),
         "dbg_build": (C.c_int, [H, C.c_int, C.c_uint64]),
+        "dbg_refine_edge_order": (C.c_int, [H]),
+        "dbg_export_orders": (C.c_int, [H, vp, vp]),
         "dbg_prune": (C.c_int, [H, C.c_double]),
         "dbg_remove_tips": (C.c_int, [H]),
         "dbg_mark_pull_reads": (C.c_int, [H]),
@@ -196,6 +199,15 @@ class Graph:
     # ---- pipeline
     def build(self, k, table_capacity_hint=0):
         self._chk(self._lib.dbg_build(self._h, int(k), int(table_capacity_hint)))
+
+    def refine_edge_order(self):
+        self._chk(self._lib.dbg_refine_edge_order(self._h))
+
+    def export_orders(self):
+        n = self.sizes()["n_nodes"]
+        a, b = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8)
+        self._chk(self._lib.dbg_export_orders(self._h, _ptr(a), _ptr(b)))
+        return a, b
 
     def prune(self, threshold):
         self._chk(self._lib.dbg_prune(self._h, float(threshold)))

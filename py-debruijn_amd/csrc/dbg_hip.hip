@@ -55,6 +55,8 @@ struct dbg {
     uint8_t *d_flags = nullptr;
     uint8_t *d_order = nullptr;  // successor codes ranked by (count desc, ascii asc), 2 bits each
     uint8_t *d_deg = nullptr;    // distinct successors (pre-pruning outdegree) -- feeds the CSR row scan
+    uint8_t *d_fsorder = nullptr; // successor codes in first-seen order (dbg_refine_edge_order)
+    bool order_exact = false;
     uint32_t *d_succ = nullptr;
     bool nodes_in_arena = false;  // node arrays borrowed from ar_node (super-k-mer engine)
     bool csr_built = false;       // rowptr/col/ecnt already written by k_sk_count
@@ -481,8 +483,8 @@ __global__ __launch_bounds__(256) void k_csr_fill(uint64_t n_nodes, const uint64
 // ------------------------------------------------------------------------------------------
 // a5 + a6: pruningEdges + branch flag
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prune(uint64_t n_nodes, const uint32_t *cnt, double threshold, uint8_t *flags,
-                                               unsigned long long *n_branch) {
+__global__ __launch_bounds__(256) void k_prune(uint64_t n_nodes, const uint32_t *cnt, const uint8_t *order, double threshold,
+                                               uint8_t *flags, unsigned long long *n_branch) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t br = 0;
     if (i < n_nodes) {
@@ -498,9 +500,8 @@ __global__ __launch_bounds__(256) void k_prune(uint64_t n_nodes, const uint32_t 
             bool top_taken = false;
             for (int r = 0; r < 4; ++r) {
                 // the arg-max is kept unconditionally (:159); any other count is tested against lim.
-                // Among equal maxima the reference keeps the first-seen one; this build breaks that
-                // tie in ASCII order (only visible for threshold < 1).
-                const int b = (0x2310 >> (4 * r)) & 3;  // codes in ASCII order A, C, G, T
+                // Among equal maxima the reference keeps the first-seen one (first in the rank byte).
+                const int b = (order[i] >> (2 * r)) & 3;  // most_common order: the first maximum is the arg-max
                 if (!c[b]) continue;
                 if (c[b] == mx && !top_taken) { keep |= 1u << b; top_taken = true; continue; }
                 if ((double)c[b] >= lim) keep |= 1u << b;
@@ -844,6 +845,91 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
 }
 
 // ------------------------------------------------------------------------------------------
+// exact successor order.  The reference lists the successors of a vertex in Counter order:
+// first-seen order for the edge-count table (debruijn.py:215-216) and count-descending with
+// first-seen ties after pruning (Counter.most_common, :159-165).  The build only keeps the first
+// occurrence of NODES; for the few nodes with two or more distinct successors this pass finds the
+// first occurrence of every out-edge by streaming the k-mer instances once more, and rewrites the
+// rank bytes: order[] = (count desc, first-seen asc), fsorder[] = first-seen asc.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_multi_insert(uint64_t n_nodes, const uint32_t *cnt, const uint64_t *keys,
+                                                      unsigned long long *set_keys, uint32_t *set_node, uint64_t cap_mask) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
+    if ((c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0) < 2) return;
+    const unsigned long long key = keys[i];
+    uint64_t slot = kmer_hash(key) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        const unsigned long long cur = atomicCAS(&set_keys[slot], EMPTY_KEY, key);
+        if (cur == EMPTY_KEY) { set_node[slot] = (uint32_t)i; return; }
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_edge_first_seen(const char *__restrict__ bases, uint64_t n_bytes,
+                                                         const uint32_t *__restrict__ startbits, int k,
+                                                         const uint64_t *__restrict__ set_keys, uint64_t cap_mask,
+                                                         unsigned long long *estamp /* [slot * 4 + code] */) {
+    __shared__ TileLds t;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    (void)load_tile(t, bases, n_bytes, startbits, tile0);
+    __syncthreads();
+    const uint32_t mid_mask = (k >= 2) ? ((1u << (k - 1)) - 1u) : 0u;
+    for (int j = threadIdx.x; j < TILE; j += 256) {
+        const uint64_t p = tile0 + j;
+        if (p + k >= n_bytes) break;  // needs a successor base
+        const uint32_t sw = startwin32(t, j);
+        if (((sw >> 1) & mid_mask) || ((sw >> k) & 1u)) continue;  // k-mer or its successor crosses a read boundary
+        const uint64_t win = window32(t, j);
+        const uint64_t kmer = win >> (64 - 2 * k);
+        const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
+        uint64_t slot = kmer_hash(kmer) & cap_mask;
+        for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+            const uint64_t cur = set_keys[slot];
+            if (cur == kmer) { atomicMin(&estamp[slot * 4 + b], (unsigned long long)p); break; }
+            if (cur == EMPTY_KEY) break;
+            slot = (slot + 1) & cap_mask;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_order_refine(uint64_t cap, const unsigned long long *set_keys,
+                                                      const uint32_t *set_node, const unsigned long long *estamp,
+                                                      const uint32_t *cnt, uint8_t *order, uint8_t *fsorder) {
+    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= cap || set_keys[slot] == EMPTY_KEY) return;
+    const uint32_t node = set_node[slot];
+    const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[node];
+    const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+    unsigned long long st[4];
+    for (int b = 0; b < 4; ++b) st[b] = c[b] ? estamp[slot * 4 + b] : ~0ull;
+    uint32_t a[4] = {0, 1, 2, 3}, f[4] = {0, 1, 2, 3};
+    for (int x = 1; x < 4; ++x)
+        for (int y = x; y > 0; --y) {
+            // most_common order: count descending, ties by first appearance
+            const bool swap_a = c[a[y]] > c[a[y - 1]] || (c[a[y]] == c[a[y - 1]] && st[a[y]] < st[a[y - 1]]);
+            if (swap_a) { uint32_t tmp = a[y]; a[y] = a[y - 1]; a[y - 1] = tmp; }
+            if (st[f[y]] < st[f[y - 1]]) { uint32_t tmp = f[y]; f[y] = f[y - 1]; f[y - 1] = tmp; }
+        }
+    order[node] = (uint8_t)(a[0] | (a[1] << 2) | (a[2] << 4) | (a[3] << 6));
+    fsorder[node] = (uint8_t)(f[0] | (f[1] << 2) | (f[2] << 4) | (f[3] << 6));
+}
+
+__global__ __launch_bounds__(256) void k_fsorder_default(uint64_t n_nodes, const uint8_t *order, uint8_t *fsorder) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_nodes) fsorder[i] = order[i];  // at most one successor: any order of the empty codes will do
+}
+
+struct MultiSucc {
+    const uint32_t *cnt;
+    __device__ uint64_t operator()(uint64_t i) const {
+        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
+        return (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0) >= 2;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
 // non-final walk at scale: pointer jumping.  Every start walks its chain to the next branch node /
 // dead end / pulled node, so contigs overlap massively (10M x 150 bp: 3.0e6 starts, 1.9e12 chain
 // steps in total).  Doubling resolves (end node, hops, score) of EVERY node's chain in
@@ -933,6 +1019,8 @@ static void free_build(dbg *h) {
     }
     dev_free(h->d_btab);
     h->btab_cap = 0;
+    dev_free(h->d_fsorder);
+    h->order_exact = false;
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
     dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_deg);
     h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
@@ -1228,6 +1316,55 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     return DBG_OK;
 }
 
+extern "C" int dbg_refine_edge_order(dbg_t *h) {
+    if (!h || !h->k) return DBG_E_ARG;
+    if (h->shard_state && shard_of(h).shard_bits) { h->err = "edge-order refinement is single-GPU for now"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    dev_free(h->d_fsorder);
+    CHK(dev_alloc(h, &h->d_fsorder, h->n_nodes));
+    if (!h->n_nodes) { h->order_exact = true; return DBG_OK; }
+    hipLaunchKernelGGL(k_fsorder_default, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_order,
+                       h->d_fsorder);
+    uint64_t n_multi = 0;
+    CHK(reduce_sum(h, h->n_nodes, MultiSucc{h->d_cnt}, &n_multi));
+    if (n_multi) {
+        uint64_t cap = 1024;
+        while (cap < n_multi * 2) cap <<= 1;
+        unsigned long long *set_keys = nullptr, *estamp = nullptr;
+        uint32_t *set_node = nullptr;
+        int rc = dev_alloc(h, &set_keys, cap);
+        if (rc == DBG_OK) rc = dev_alloc(h, &set_node, cap);
+        if (rc == DBG_OK) rc = dev_alloc(h, &estamp, cap * 4);
+        if (rc == DBG_OK) {
+            (void)hipMemsetAsync(set_keys, 0xFF, cap * 8, h->stream);
+            (void)hipMemsetAsync(estamp, 0xFF, cap * 32, h->stream);
+            hipLaunchKernelGGL(k_multi_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_cnt,
+                               h->d_keys, set_keys, set_node, cap - 1);
+            const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+            hipLaunchKernelGGL(k_edge_first_seen, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, h->k, (const uint64_t *)set_keys, cap - 1, estamp);
+            hipLaunchKernelGGL(k_order_refine, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, cap, set_keys, set_node,
+                               estamp, h->d_cnt, h->d_order, h->d_fsorder);
+            hipError_t e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { h->err = std::string("refine: ") + hipGetErrorString(e); rc = DBG_E_HIP; }
+        }
+        dev_free(set_keys); dev_free(set_node); dev_free(estamp);
+        if (rc != DBG_OK) return rc;
+    }
+    h->order_exact = true;
+    return DBG_OK;
+}
+
+extern "C" int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder) {
+    if (!h || !h->k) return DBG_E_ARG;
+    if (fsorder && !h->d_fsorder) { h->err = "dbg_refine_edge_order must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (order && h->n_nodes) HIPCHK(h, hipMemcpyAsync(order, h->d_order, h->n_nodes, hipMemcpyDeviceToHost, h->stream));
+    if (fsorder && h->n_nodes) HIPCHK(h, hipMemcpyAsync(fsorder, h->d_fsorder, h->n_nodes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
 extern "C" int dbg_prune(dbg_t *h, double threshold) {
     if (!h || !h->k) return DBG_E_ARG;
     if (threshold == 0.0) { h->err = "threshold must be non-zero (the reference divides by it)"; return DBG_E_ARG; }
@@ -1236,7 +1373,7 @@ extern "C" int dbg_prune(dbg_t *h, double threshold) {
     HIPCHK(h, hipMemsetAsync(h->d_scalars + 16, 0, 8, h->stream));
     if (h->n_nodes) {
         hipLaunchKernelGGL(k_prune, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_cnt,
-                           threshold, h->d_flags, (unsigned long long *)(h->d_scalars + 16));
+                           h->d_order, threshold, h->d_flags, (unsigned long long *)(h->d_scalars + 16));
         HIPCHK(h, hipGetLastError());
     }
     HIPCHK(h, hipMemcpyAsync(&h->n_branch, h->d_scalars + 16, 8, hipMemcpyDeviceToHost, h->stream));

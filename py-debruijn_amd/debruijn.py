@@ -8,10 +8,9 @@ path: without the built library and a GPU every call raises.
 
 Differences a caller can observe, all documented in DESIGN.md:
   * reads must be upper-case A/C/G/T and 1 <= k <= 31 (ValueError otherwise);
-  * where the reference orders equal-count successors by first appearance
-    (``Counter.most_common`` ties), this module orders them A < C < G < T.  Sets,
-    counts, degrees, branch/pulled/pull-out sets and non-final contig lists are
-    identical; only the order inside such tie groups can differ.
+  * ``output_contigs`` needs the objects returned by this module's ``construct_graph``.
+Everything else -- values AND orders (dict insertion order, ``Counter.most_common`` tie order,
+the append order of ``already_pull_out``, contig order) -- equals the reference.
 """
 from __future__ import annotations
 
@@ -21,7 +20,6 @@ import _dbg
 
 __all__ = ["Node", "read_reads", "construct_graph", "output_contigs", "get_score_device"]
 
-_ASCII_RANK_CODES = (0, 1, 3, 2)  # base codes in ASCII order A, C, G, T
 _CODE_CHAR = "ACTG"               # code = (ascii >> 1) & 3
 
 
@@ -91,6 +89,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     g = _dbg.Graph()
     g.set_reads(bases, offsets)
     g.build(k)
+    g.refine_edge_order()  # Counter order of the successors (first-seen ties), debruijn.py:159-165, :215-216
     sz = g.sizes()
     print('number of {}mer: '.format(k), sz["n_nodes"])  # debruijn.py:224
 
@@ -108,9 +107,11 @@ def construct_graph(reads, k, threshold=3, final=False):
         g.mark_pull_reads()
 
     keys, stamps, counts, flags = g.export_nodes()
+    rank_mc, rank_fs = g.export_orders()
     order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
     labels = _dbg.decode_keys(keys[order], k)
     counts_o = counts[order]
+    rank_mc, rank_fs = rank_mc[order], rank_fs[order]
     flags_o = flags[order]
     outdeg = (counts_o != 0).sum(axis=1)
     indeg = flags_o & _dbg.F_INDEG
@@ -124,9 +125,9 @@ def construct_graph(reads, k, threshold=3, final=False):
         vertices[lab] = Node(lab, int(indeg[i]), int(outdeg[i]))
         c = counts_o[i]
         tail = lab[1:]
-        # successors ranked by (count desc, ASCII asc) -- Counter.most_common order up to ties
-        ranked = sorted((code for code in _ASCII_RANK_CODES if c[code]), key=lambda code: -int(c[code]))
-        for code in _ASCII_RANK_CODES:
+        mc, fs = int(rank_mc[i]), int(rank_fs[i])
+        ranked = [code for code in ((mc >> (2 * r)) & 3 for r in range(4)) if c[code]]  # Counter.most_common order
+        for code in ((fs >> (2 * r)) & 3 for r in range(4)):                            # Counter key order
             if c[code]:
                 ect[lab + _CODE_CHAR[code]] = int(c[code])
         if not pulled_o[i]:

@@ -21,9 +21,7 @@ def test_driver_matches_reference_vectors(name):
     inp = case["inputs"]
     with contextlib.redirect_stdout(io.StringIO()):
         final = drv.assemble(list(inp["reads"]), inp["k_lowerlimit"], inp["k_upperlimit"], inp["threshold"])
-    # final-mode contigs are emitted per start in successor order; equal-count successors are
-    # ordered A<C<G<T here and first-seen in the reference -> compare the final list as a multiset
-    assert sorted(final) == sorted(case["result"]["final_contigs"])
+    assert final == case["result"]["final_contigs"]
 
 
 def test_driver_nonfinal_rounds_exact():
@@ -61,7 +59,7 @@ def test_cli_fasta_in_contigs_out(tmp_path):
         want, _ = orc.assemble(reads, 15, 17, 2)
     heads, seqs = out[0::2], out[1::2]
     assert len(seqs) == 2 * len(want)
-    assert sorted(seqs[:len(want)]) == sorted(want) and seqs[:len(want)] == seqs[len(want):]
+    assert seqs[:len(want)] == want and seqs[:len(want)] == seqs[len(want):]
     assert heads[0] == ">SEQUENCE_0_17mer" and heads[len(want) - 1] == f">SEQUENCE_{len(want) - 1}_17mer"
 
 

@@ -1,10 +1,8 @@
 """HIP path vs the oracle and the reference's golden vectors (run with -m gpu on an MI355X).
 
-Every call goes through the C ABI (ctypes -> libdbg_hip.so).  Integer/byte/index work: bit-exact.
-Ordering rule: the product orders equal-count successors A<C<G<T where the
-reference uses first-seen order, so successor lists, edge_count_table key order,
-already_pull_out order and final-mode contig order are compared order-independently;
-everything else is compared exactly, including dict order.
+Every call goes through the C ABI (ctypes -> libdbg_hip.so).  Integer/byte/index work: bit-exact,
+orders included: dict insertion order, Counter.most_common tie order of successor lists, the append
+order of already_pull_out and the contig order in both modes.
 """
 import contextlib
 import io
@@ -53,20 +51,13 @@ def run_oracle(reads, k, threshold, final):
 
 def assert_same(got, want, final, tag):
     assert got["vertices"] == want["vertices"], f"{tag}: vertices (label, indegree, outdegree, dict order)"
-    assert [v for v, _ in got["edges"]] == [v for v, _ in want["edges"]], f"{tag}: edges keys / order"
-    for (v, a), (_, b) in zip(got["edges"], want["edges"]):
-        assert sorted(a) == sorted(b), f"{tag}: successors of {v}"
-    assert dict(map(tuple, got["edge_count_table"])) == dict(map(tuple, want["edge_count_table"])), f"{tag}: edge counts"
+    assert got["edges"] == want["edges"], f"{tag}: edges (keys, dict order, successor lists in most_common order)"
+    assert got["edge_count_table"] == want["edge_count_table"], f"{tag}: edge counts (values and insertion order)"
     assert got["branch_kmer"] == want["branch_kmer"], f"{tag}: branch_kmer"
-    assert sorted(got["already_pull_out"]) == sorted(want["already_pull_out"]), f"{tag}: already_pull_out"
-    assert len(set(got["already_pull_out"])) == len(got["already_pull_out"])
+    assert got["already_pull_out"] == want["already_pull_out"], f"{tag}: already_pull_out (append order)"
     assert got["pull_out_read"] == want["pull_out_read"], f"{tag}: pull_out_read"
-    if final:
-        assert sorted(got["contigs"]) == sorted(want["contigs"]), f"{tag}: contigs (final mode, as multiset)"
-        assert sorted(zip(got["contigs"], got["scores"])) == sorted(zip(want["contigs"], want["scores"]))
-    else:
-        assert got["contigs"] == want["contigs"], f"{tag}: contigs"
-        assert got["scores"] == want["scores"], f"{tag}: getScore"
+    assert got["contigs"] == want["contigs"], f"{tag}: contigs"
+    assert got["scores"] == want["scores"], f"{tag}: getScore"
     assert got["stdout"] == want["stdout"], f"{tag}: stdout lines"
 
 
