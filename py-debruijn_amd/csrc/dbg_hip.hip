@@ -1216,7 +1216,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (!h || !name) return DBG_E_ARG;
     const std::string n(name);
     if (n == "engine" && (value == 0 || value == 1)) { h->engine = (int)value; return DBG_OK; }
-    if (n == "bucket_bits" && value >= 0 && value <= 18) { h->bucket_bits = (int)value; return DBG_OK; }
+    if (n == "bucket_bits" && value >= 0 && value <= 19) { h->bucket_bits = (int)value; return DBG_OK; }
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
@@ -1868,13 +1868,14 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     uint64_t sc[8] = {0};
     // ---- bucket geometry.  Level 1 takes up to 9 bits of the bucket hash; the remaining bits are
     //      chosen after level 1 from a distinct-k-mer estimate on one level-1 bucket (auto mode).
-    constexpr double TARGET_DISTINCT = CAP * 0.27;  // mean distinct k-mers per final bucket (table ~27 % full)
+    constexpr double TARGET_DISTINCT = CAP * 0.36;  // mean distinct k-mers per final bucket (table ~1/3 full: measured optimum)
+    constexpr int T_MAX = 19;                       // 9 + 10 bits over the two multisplit levels
     const double own = shard_bits ? (double)(1 << shard_bits) : 1.0;  // buckets are spread over `own` shards
     int T = h->bucket_bits;
     const bool auto_T = (T == 0);
     if (auto_T) {  // provisional: assume 40 % of the instances are distinct
         const double want = (double)n_inst * own * 0.4 / TARGET_DISTINCT;
-        while (T < 18 && (double)(1ull << T) < want) ++T;
+        while (T < T_MAX && (double)(1ull << T) < want) ++T;
     }
     if (T < shard_bits) T = shard_bits;
     int l1 = T < 9 ? T : 9, l2 = T - l1;
@@ -1904,7 +1905,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (est[0]) {
             const double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
             T = 9;
-            while (T < 18 && (double)(1ull << T) < distinct / TARGET_DISTINCT) ++T;
+            while (T < T_MAX && (double)(1ull << T) < distinct / TARGET_DISTINCT) ++T;
             l2 = T - l1;
         }
     }
@@ -1975,8 +1976,10 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (n_rec) {
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
-            const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);  // persistent: one per CU
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(CNT_NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
+            constexpr int NT = CntCfg<ST, CAP>::NT;
+            const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / NT, (160 * 1024) / lds));
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu * per_cu);  // persistent
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
                                st[where], k, m, n_buckets, out, h->phase_limit);
             HIPCHK(h, hipGetLastError());
         }

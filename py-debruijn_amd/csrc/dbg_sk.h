@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, DBG_EXW_WAVES) void k_sk_extract_w(const char 
 #endif
 constexpr int MS_CH = DBG_MS_CH;      // records sorted per LDS round
 constexpr int MS_SC = 32768;          // records per super-chunk
-constexpr int MS_MAX_NB = 512;
+constexpr int MS_MAX_NB = 1024;
 
 // Input of one multisplit level: `n_seg` contiguous segments of the record arrays.  Either all
 // segments form ONE group (level 1: the per-workgroup output segments of k_sk_extract) or every
@@ -507,13 +507,16 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
             }
         }
         __syncthreads();
-        {  // exclusive scan of hist (nb <= 512: two entries per thread)
-            const int b0 = threadIdx.x * 2;
-            const uint32_t a = b0 < nb ? s.hist[b0] : 0, b = b0 + 1 < nb ? s.hist[b0 + 1] : 0;
+        {  // exclusive scan of hist (nb <= 1024: four entries per thread)
+            const int b0 = threadIdx.x * 4;
+            uint32_t h4[4];
+            uint64_t sum = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h4[j] = (b0 + j < nb) ? s.hist[b0 + j] : 0; sum += h4[j]; }
             uint64_t tot;
-            const uint64_t ex = block_exscan_256((uint64_t)a + b, &tot);
-            if (b0 < nb) s.start[b0] = (uint32_t)ex;
-            if (b0 + 1 < nb) s.start[b0 + 1] = (uint32_t)ex + a;
+            uint32_t ex = (uint32_t)block_exscan_256(sum, &tot);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (b0 + j < nb) s.start[b0 + j] = ex; ex += h4[j]; }
         }
         __syncthreads();
 #pragma unroll
@@ -610,10 +613,12 @@ __device__ inline uint32_t slot_of(uint64_t kmer) {
 // stamps the 4096-slot table leaves room for ~300 only (the edge-offset array took the rest).
 template <class ST, int CAP>
 struct CntCfg {
-    static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 304 : 768) : 1024;
+    static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 304 : 768) : 400;
+    // 4096 slots fill the LDS: one 1024-thread workgroup per CU.  2048 slots: two 512-thread workgroups per CU
+    // that run out of step, so one's barriers and LDS stalls overlap the other's work.
+    static constexpr int NT = CAP == 4096 ? 1024 : 512;
 };
 constexpr int CNT_STACK = 24;    // pending hash sub-ranges of one bucket
-constexpr int CNT_NT = 1024;     // threads per bucket workgroup (one workgroup per CU: the table fills the LDS)
 constexpr int CNT_PROBE_LIMIT = 1024;
 
 template <class ST, int CAP>
@@ -699,7 +704,7 @@ __device__ inline uint32_t wave_alloc_n(uint32_t *counter, uint32_t n) {
 }
 
 template <class ST, int CAP>
-__global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
+__global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
                                                      const ST *__restrict__ rec_st, int k, int m, uint64_t n_buckets,
                                                      SkCountOut out, int phase_limit /* ablation only: 0 = run everything */) {
@@ -710,6 +715,7 @@ __global__ __launch_bounds__(CNT_NT) void k_sk_count(const uint64_t *__restrict_
     extern __shared__ __attribute__((aligned(16))) unsigned char cnt_raw[];
     CntLds<ST, CAP> &s = *reinterpret_cast<CntLds<ST, CAP> *>(cnt_raw);
     using LdsT = CntLds<ST, CAP>;
+    constexpr int CNT_NT = CntCfg<ST, CAP>::NT;
     constexpr int NPT = CAP / CNT_NT;  // nodes per thread, upper bound
     constexpr int CNT_QBUF = CntCfg<ST, CAP>::QBUF;
     static_assert(offsetof(LdsT, list) == offsetof(LdsT, idx) + sizeof(uint16_t) * CAP, "layout");
