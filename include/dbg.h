@@ -112,6 +112,10 @@ int dbg_set_option(dbg_t *h, const char *name, int64_t value);
  *      ingest debruijn.py:22-32 stays on the host side of the boundary) ---- */
 /* bases: all reads concatenated without separators; offsets[n_reads+1], offsets[0]==0. Copies H2D. */
 int dbg_set_reads(dbg_t *h, const char *bases, const uint64_t *offsets, uint64_t n_reads);
+/* read_reads (debruijn.py:22-32) on the device: `text` is the raw FASTA file (host buffer); every line that
+ * does not start with '>' becomes one read, rstrip'ed (universal newlines, multi-line records are separate
+ * reads, blank lines are empty reads).  Sizes afterwards: dbg_get_sizes; the reads: dbg_copy_reads. */
+int dbg_set_reads_fasta(dbg_t *h, const char *text, uint64_t n_text);
 /* Zero-copy: device pointers the caller keeps alive (16-byte aligned bases, u64 offsets[n_reads+1]). */
 int dbg_set_reads_device(dbg_t *h, const void *d_bases, uint64_t n_bytes, const void *d_offsets, uint64_t n_reads);
 /* Generate reads [first_read, first_read+n_reads) of the synthetic set on the device

@@ -16,7 +16,7 @@ import argparse
 import json
 
 import debruijn as db
-from debruijn import read_reads
+from debruijn import read_reads, read_reads_device
 
 
 def getScore(edge_count_table, contig, k):
@@ -65,6 +65,7 @@ if __name__ == '__main__':
     k_lowerlimit = setting['k_lowerlimit']
     k_upperlimit = setting['k_upperlimit']
     threshold = setting['threshold']
-    sequences = read_reads(f'{froot}/input_reads.fasta')
+    # II_assembleFromReads.py:53 with the FASTA parsed on the GPU (read_reads semantics, no Python string per read)
+    sequences = read_reads_device(f'{froot}/input_reads.fasta')
     print(len(sequences))
     assemble(sequences, k_lowerlimit, k_upperlimit, threshold, out_path=f'{froot}/{froot}.fasta')

@@ -21,7 +21,8 @@ ABI_VERSION = 1
 
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
-    "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_device",
+    "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_fasta",
+    "dbg_set_reads_device",
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
     "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
@@ -83,6 +84,7 @@ def load_library():
         "dbg_abi_version": (C.c_int, []),
         "dbg_set_option": (C.c_int, [H, C.c_char_p, C.c_int64]),
         "dbg_set_reads": (C.c_int, [H, vp, vp, C.c_uint64]),
+        "dbg_set_reads_fasta": (C.c_int, [H, vp, C.c_uint64]),
         "dbg_set_reads_device": (C.c_int, [H, vp, C.c_uint64, vp, C.c_uint64]),
         "dbg_synth_reads": (C.c_int, [H, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]),
         "dbg_reads_checksum": (C.c_int, [H, u64p]),
@@ -174,6 +176,14 @@ class Graph:
         o = np.ascontiguousarray(offsets, dtype=np.uint64)
         assert o.ndim == 1 and o.size >= 1 and int(o[-1]) == b.size
         self._chk(self._lib.dbg_set_reads(self._h, _ptr(b), _ptr(o), o.size - 1))
+
+    def set_reads_fasta(self, path_or_bytes):
+        """Parses a FASTA file on the GPU (read_reads semantics); no Python strings are created."""
+        if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+            raw = np.frombuffer(path_or_bytes, dtype=np.uint8)
+        else:
+            raw = np.fromfile(path_or_bytes, dtype=np.uint8)
+        self._chk(self._lib.dbg_set_reads_fasta(self._h, _ptr(raw) if raw.size else None, raw.size))
 
     def set_reads_device(self, bases_ptr, n_bytes, offsets_ptr, n_reads, keepalive=()):
         self._keep = list(keepalive)

@@ -845,6 +845,74 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
 }
 
 // ------------------------------------------------------------------------------------------
+// FASTA ingest on the device (read_reads, debruijn.py:22-32): every line that does not start with
+// '>' is one read, rstrip'ed; multi-line records are separate reads; a blank line is an empty read.
+// Line terminators follow Python's universal-newline text mode ('\n', '\r\n' and a lone '\r').
+// ------------------------------------------------------------------------------------------
+__device__ inline bool fa_line_start(const char *text, uint64_t i) {
+    if (i == 0) return true;
+    const char prev = text[i - 1];
+    return prev == '\n' || (prev == '\r' && text[i] != '\n');
+}
+__device__ inline bool fa_space(char c) {  // str.isspace() over the ASCII range
+    return c == ' ' || (c >= 9 && c <= 13) || (c >= 28 && c <= 31);
+}
+
+__global__ __launch_bounds__(256) void k_fa_mark(const char *__restrict__ text, uint64_t n, uint32_t *bits) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 32-bit word of the bitmap per thread
+    const uint64_t base = w * 32;
+    if (base >= n) return;
+    uint32_t m = 0;
+    for (int b = 0; b < 32 && base + b < n; ++b) m |= (uint32_t)fa_line_start(text, base + b) << b;
+    bits[w] = m;
+}
+
+__global__ __launch_bounds__(256) void k_fa_line_starts(const uint32_t *bits, const uint32_t *word_rank, uint64_t n_words,
+                                                        uint64_t *line_start) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t m = bits[w], r = word_rank[w];
+    while (m) {
+        const int b = __ffs(m) - 1;
+        m &= m - 1;
+        line_start[r++] = w * 32 + b;
+    }
+}
+
+// per line: is it a read (not a header), and how long after rstrip
+__global__ __launch_bounds__(256) void k_fa_lines(const char *__restrict__ text, uint64_t n, const uint64_t *line_start,
+                                                  uint64_t n_lines, uint8_t *is_read, uint32_t *len) {
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lines) return;
+    const uint64_t s0 = line_start[l];
+    uint64_t e = (l + 1 < n_lines) ? line_start[l + 1] : n;
+    const bool rd = text[s0] != '>';
+    while (e > s0 && fa_space(text[e - 1])) --e;  // terminator + trailing white space
+    is_read[l] = rd;
+    len[l] = rd ? (uint32_t)(e - s0) : 0;
+}
+
+struct ByteSet {
+    const uint8_t *p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+struct U32At {
+    const uint32_t *p;
+    __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
+};
+
+__global__ __launch_bounds__(256) void k_fa_copy(const char *__restrict__ text, const uint64_t *line_start,
+                                                 uint64_t n_lines, const uint8_t *is_read, const uint32_t *len,
+                                                 const uint64_t *read_idx, const uint64_t *byte_off, char *bases,
+                                                 uint64_t *offsets) {
+    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= n_lines || !is_read[l]) return;
+    const uint64_t src = line_start[l], dst = byte_off[l];
+    offsets[read_idx[l]] = dst;
+    for (uint32_t i = 0; i < len[l]; ++i) bases[dst + i] = text[src + i];
+}
+
+// ------------------------------------------------------------------------------------------
 // exact successor order.  The reference lists the successors of a vertex in Counter order:
 // first-seen order for the edge-count table (debruijn.py:215-216) and count-descending with
 // first-seen ties after pruning (Counter.most_common, :159-165).  The build only keeps the first
@@ -1116,6 +1184,63 @@ extern "C" int dbg_set_reads(dbg_t *h, const char *bases, const uint64_t *offset
     h->stats.ms_h2d = t.stop();
     h->n_bytes = nb;
     h->n_reads = n_reads;
+    return make_startbits(h);
+}
+
+extern "C" int dbg_set_reads_fasta(dbg_t *h, const char *text, uint64_t n_text) {
+    if (!h || (n_text && !text)) return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    free_build(h);
+    free_reads(h);
+    char *d_text = nullptr;
+    uint32_t *bits = nullptr, *word_rank = nullptr, *len = nullptr;
+    uint64_t *line_start = nullptr, *read_idx = nullptr, *byte_off = nullptr;
+    uint8_t *is_read = nullptr;
+    auto cleanup = [&]() {
+        dev_free(d_text); dev_free(bits); dev_free(word_rank); dev_free(len); dev_free(line_start); dev_free(read_idx);
+        dev_free(byte_off); dev_free(is_read);
+    };
+    int rc = DBG_OK;
+    uint64_t n_lines = 0, n_reads = 0, n_bases = 0;
+    do {
+        Timer t(h->stream);
+        if ((rc = dev_alloc(h, &d_text, n_text + 64)) != DBG_OK) break;
+        if (n_text && hipMemcpyAsync(d_text, text, n_text, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "H2D copy failed"; rc = DBG_E_HIP; break; }
+        h->stats.ms_h2d = t.stop();
+        const uint64_t n_words = (n_text + 31) / 32;
+        if ((rc = dev_alloc(h, &bits, n_words)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &word_rank, n_words)) != DBG_OK) break;
+        if (n_words) {
+            hipLaunchKernelGGL(k_fa_mark, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, d_text, n_text, bits);
+            if ((rc = exclusive_scan(h, n_words, PopcWords{bits}, word_rank, &n_lines)) != DBG_OK) break;
+        }
+        if ((rc = dev_alloc(h, &line_start, n_lines)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &is_read, n_lines)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &len, n_lines)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &read_idx, n_lines)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &byte_off, n_lines)) != DBG_OK) break;
+        if (n_lines) {
+            hipLaunchKernelGGL(k_fa_line_starts, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, bits, word_rank, n_words,
+                               line_start);
+            hipLaunchKernelGGL(k_fa_lines, dim3(grid_for(n_lines, 256)), dim3(256), 0, h->stream, d_text, n_text, line_start,
+                               n_lines, is_read, len);
+            if ((rc = exclusive_scan(h, n_lines, ByteSet{is_read}, read_idx, &n_reads)) != DBG_OK) break;
+            if ((rc = exclusive_scan(h, n_lines, U32At{len}, byte_off, &n_bases)) != DBG_OK) break;
+        }
+        if ((rc = dev_alloc(h, &h->d_bases, n_bases + 64)) != DBG_OK) break;
+        h->own_bases = true;
+        if ((rc = dev_alloc(h, &h->d_offsets, n_reads + 1)) != DBG_OK) break;
+        h->own_offsets = true;
+        if (n_lines)
+            hipLaunchKernelGGL(k_fa_copy, dim3(grid_for(n_lines, 256)), dim3(256), 0, h->stream, d_text, line_start, n_lines,
+                               is_read, len, read_idx, byte_off, h->d_bases, h->d_offsets);
+        if (hipMemcpyAsync(h->d_offsets + n_reads, &n_bases, 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "FASTA ingest failed on the device"; rc = DBG_E_HIP; break; }
+        h->n_bytes = n_bases;
+        h->n_reads = n_reads;
+    } while (0);
+    cleanup();
+    if (rc != DBG_OK) { free_reads(h); return rc; }
     return make_startbits(h);
 }
 

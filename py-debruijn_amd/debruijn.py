@@ -18,7 +18,8 @@ import numpy as np
 
 import _dbg
 
-__all__ = ["Node", "read_reads", "construct_graph", "output_contigs", "get_score_device"]
+__all__ = ["Node", "read_reads", "read_reads_device", "DeviceReads", "construct_graph", "output_contigs",
+           "get_score_device"]
 
 _CODE_CHAR = "ACTG"               # code = (ascii >> 1) & 3
 
@@ -41,6 +42,53 @@ def read_reads(fname):
     """
     with open(fname, "r") as fh:
         return [line.rstrip() for line in fh.readlines() if line[0] != ">"]
+
+
+class DeviceReads:
+    """``read_reads`` on the GPU: a read-only sequence of the reads of a FASTA file.
+
+    The file is parsed on the device (``dbg_set_reads_fasta``: newline scan, header lines dropped,
+    ``rstrip``) and stays there; ``construct_graph`` accepts the object in place of the list and
+    builds from the resident reads, so no Python string is created per read.  Items are
+    materialised lazily (one device-to-host copy of the packed buffer on first access).
+    The object owns one device handle: a later ``construct_graph`` on the same object replaces the
+    graph of an earlier one.
+    """
+
+    def __init__(self, fname):
+        self._graph = _dbg.Graph()
+        self._graph.set_reads_fasta(fname)
+        self._n = self._graph.sizes()["n_reads"]
+        self._host = None
+
+    def _pull(self):
+        if self._host is None:
+            bases, offsets = self._graph.copy_reads()
+            self._host = (bases.tobytes().decode("ascii", "replace"), offsets)
+        return self._host
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        text, off = self._pull()
+        return text[int(off[i]):int(off[i + 1])]
+
+    def __iter__(self):
+        text, off = self._pull()
+        for i in range(self._n):
+            yield text[int(off[i]):int(off[i + 1])]
+
+
+def read_reads_device(fname):
+    """``read_reads`` (debruijn.py:22-32) without leaving the GPU; see DeviceReads."""
+    return DeviceReads(fname)
 
 
 class _Vertices(dict):
@@ -85,9 +133,12 @@ def construct_graph(reads, k, threshold=3, final=False):
     if not isinstance(k, (int, np.integer)) or not (1 <= int(k) <= 31):
         raise ValueError("the device path supports 1 <= k <= 31")
     k = int(k)
-    bases, offsets = _pack_reads(reads)
-    g = _dbg.Graph()
-    g.set_reads(bases, offsets)
+    if isinstance(reads, DeviceReads):
+        g = reads._graph  # reads are resident (alphabet is checked by the kernels: AlphabetError is a ValueError)
+    else:
+        bases, offsets = _pack_reads(reads)
+        g = _dbg.Graph()
+        g.set_reads(bases, offsets)
     g.build(k)
     g.refine_edge_order()  # Counter order of the successors (first-seen ties), debruijn.py:159-165, :215-216
     sz = g.sizes()

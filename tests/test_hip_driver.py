@@ -68,3 +68,49 @@ def test_read_reads_semantics(tmp_path):
     p = tmp_path / "x.fasta"
     p.write_text(">a\nACGT\nTTGA  \n>b\n\n>c\nGG\n")
     assert prod.read_reads(str(p)) == orc.read_reads(str(p)) == ["ACGT", "TTGA", "", "GG"]
+
+
+FASTA_CASES = {
+    "plain": ">r0\nACGTACGTTG\n>r1\nTTGACCA\n",
+    "no_final_newline": ">r0\nACGTACGTTG\n>r1\nTTGACCA",
+    "crlf": ">r0\r\nACGTACGTTG\r\n>r1\r\nTTGACCA\r\n",
+    "lone_cr": ">r0\rACGTACGTTG\r>r1\rTTGACCA\r",
+    "blank_and_multiline": ">r0\nACGT\nACGTTG\n\n>r1\n\nTTGACCA\n\n",
+    "trailing_space": ">r0 some text\nACGTACGTTG  \t\n>r1\nTTGACCA \n",
+    "gt_inside": "ACG>TT\n>hdr\n >notheader\nAC\n",
+    "empty": "",
+    "only_headers": ">a\n>b\n",
+    "double_cr": "ACGT\r\r\nTTGA\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(FASTA_CASES))
+def test_device_fasta_ingest_matches_read_reads(name, tmp_path):
+    """dbg_set_reads_fasta == read_reads (debruijn.py:22-32) on awkward files, through the C ABI."""
+    import debruijn as prod
+    p = tmp_path / (name + ".fasta")
+    p.write_bytes(FASTA_CASES[name].encode())
+    want = orc.read_reads(str(p))            # Python text mode: the reference's semantics
+    assert prod.read_reads(str(p)) == want
+    dev = prod.read_reads_device(str(p))
+    assert len(dev) == len(want)
+    assert list(dev) == want
+    if want:
+        assert dev[-1] == want[-1] and dev[0:2] == want[0:2]
+
+
+def test_construct_graph_from_device_reads(tmp_path):
+    import debruijn as prod
+    import synth
+    reads = synth.reads_list(51, 4000, 500, 90, 0.01)
+    p = tmp_path / "input_reads.fasta"
+    synth.write_fasta(str(p), reads)
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = prod.construct_graph(reads, 21, threshold=2)
+        ca = prod.output_contigs(a[0], a[2], a[3])
+        dev = prod.read_reads_device(str(p))
+        b = prod.construct_graph(dev, 21, threshold=2)
+        cb = prod.output_contigs(b[0], b[2], b[3])
+    assert list(a[0][0]) == list(b[0][0]) and a[0][1] == b[0][1]
+    assert a[1] == b[1] and list(a[2]) == list(b[2]) and list(a[3]) == list(b[3]) and a[4] == b[4]
+    assert list(ca) == list(cb)
