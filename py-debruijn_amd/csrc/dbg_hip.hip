@@ -525,21 +525,39 @@ __global__ __launch_bounds__(256) void k_prune(uint64_t n_nodes, const uint32_t 
 // ------------------------------------------------------------------------------------------
 constexpr int TIP_DEPTH = 5;  // debruijn.py:246
 
-struct TipGraph {
+// Graph accessors: the tip / walk / jump kernels are written against this interface so that the 4-way DNA
+// layout (2-bit codes, ranks and keep mask packed in bytes) and the generic layout (5-bit codes, up
+// to 32 successors, dbg_generic.h) share them.
+struct GDna {
+    const uint64_t *keys;
     const uint8_t *flags;
     const uint8_t *order;
     const uint32_t *succ;
     const uint32_t *cnt;
+    int k;
+    __device__ int n_ranks(uint32_t) const { return 4; }
+    __device__ uint32_t code_at(uint32_t x, int r) const { return (order[x] >> (2 * r)) & 3u; }
+    __device__ bool kept(uint32_t x, uint32_t code) const { return (flags[x] >> (DBG_F_KEEP_SHIFT + code)) & 1u; }
+    __device__ uint32_t keep_count(uint32_t x) const { return __popc((uint32_t)(flags[x] & DBG_F_KEEP_MASK)); }
+    __device__ uint32_t first_kept(uint32_t x) const { return __ffs((uint32_t)(flags[x] & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT) - 1; }
+    __device__ uint32_t succ_of(uint32_t x, uint32_t code) const { return succ[(uint64_t)x * 4 + code]; }
+    __device__ uint32_t cnt_of(uint32_t x, uint32_t code) const { return cnt[(uint64_t)x * 4 + code]; }
     __device__ bool terminal(uint32_t x) const {  // pre-pruning outdegree == 0 [:173]
         const uint4 c = reinterpret_cast<const uint4 *>(cnt)[x];
         return (c.x | c.y | c.z | c.w) == 0;
+    }
+    __device__ uint32_t last_code(uint32_t x) const { return (uint32_t)(keys[x] & 3u); }
+    __device__ char sym_char(uint32_t code) const { return code_to_ascii(code); }
+    __device__ void spell(uint32_t x, char *out) const {
+        const uint64_t key = keys[x];
+        for (int q = 0; q < k; ++q) out[q] = code_to_ascii((uint32_t)(key >> (2 * (k - 1 - q))) & 3u);
     }
 };
 
 // DFS below `root` over surviving edges, depth-limited like debruijn.py:169-186.
 // visit(x): every node entered at levels 1..4; term(path, len): a path root..t ending in a terminal node.
-template <bool CHECK_PULLED, class Visit, class Term>
-__device__ inline void tip_dfs(const TipGraph &g, uint32_t root, Visit visit, Term term) {
+template <bool CHECK_PULLED, class G, class Visit, class Term>
+__device__ inline void tip_dfs(const G &g, uint32_t root, Visit visit, Term term) {
     uint32_t path[TIP_DEPTH];
     int idx[TIP_DEPTH];
     path[0] = root;
@@ -547,11 +565,11 @@ __device__ inline void tip_dfs(const TipGraph &g, uint32_t root, Visit visit, Te
     int d = 0;
     while (d >= 0) {
         const uint32_t cur = path[d];
-        if (idx[d] >= 4) { --d; continue; }
+        if (idx[d] >= g.n_ranks(cur)) { --d; continue; }
         const int r = idx[d]++;
-        const uint32_t code = (g.order[cur] >> (2 * r)) & 3u;
-        if (!((g.flags[cur] >> (DBG_F_KEEP_SHIFT + code)) & 1u)) continue;
-        const uint32_t s = g.succ[(uint64_t)cur * 4 + code];
+        const uint32_t code = g.code_at(cur, r);
+        if (!g.kept(cur, code)) continue;
+        const uint32_t s = g.succ_of(cur, code);
         if (CHECK_PULLED && (g.flags[s] & DBG_F_PULLED)) continue;
         if (d + 1 >= TIP_DEPTH) continue;  // child would be entered with depth == 0
         visit(s);
@@ -562,14 +580,16 @@ __device__ inline void tip_dfs(const TipGraph &g, uint32_t root, Visit visit, Te
     }
 }
 
-__global__ __launch_bounds__(256) void k_tip_reset(TipGraph g, const uint32_t *pending, uint64_t n_pending,
+template <class G>
+__global__ __launch_bounds__(256) void k_tip_reset(G g, const uint32_t *pending, uint64_t n_pending,
                                                    unsigned long long *owner) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pending) return;
     tip_dfs<false>(g, pending[i], [&](uint32_t x) { owner[x] = ~0ull; }, [](const uint32_t *, int) {});
 }
 
-__global__ __launch_bounds__(256) void k_tip_claim(TipGraph g, const uint32_t *pending, uint64_t n_pending,
+template <class G>
+__global__ __launch_bounds__(256) void k_tip_claim(G g, const uint32_t *pending, uint64_t n_pending,
                                                    const uint64_t *stamps, unsigned long long *owner) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_pending) return;
@@ -578,7 +598,8 @@ __global__ __launch_bounds__(256) void k_tip_claim(TipGraph g, const uint32_t *p
     tip_dfs<false>(g, b, [&](uint32_t x) { atomicMin(&owner[x], me); }, [](const uint32_t *, int) {});
 }
 
-__global__ __launch_bounds__(256) void k_tip_commit(TipGraph g, uint8_t *flags_rw, const uint32_t *pending,
+template <class G>
+__global__ __launch_bounds__(256) void k_tip_commit(G g, uint8_t *flags_rw, const uint32_t *pending,
                                                     uint64_t n_pending, const uint64_t *stamps,
                                                     const unsigned long long *owner, unsigned long long *pull_rank,
                                                     uint32_t *next_pending, unsigned long long *counters) {
@@ -601,7 +622,7 @@ __global__ __launch_bounds__(256) void k_tip_commit(TipGraph g, uint8_t *flags_r
             for (int q = 1; q < len; ++q) {  // path[0] is the branch node itself, never pulled [:251]
                 const uint32_t x = path[q];
                 if ((g.flags[x] & (DBG_F_PULLED | DBG_F_BRANCH)) == 0 && pull_rank[x] == ~0ull) {
-                    pull_rank[x] = me * 512ull + j;
+                    pull_rank[x] = (me << 22) + j;  // pull order: branch (dict order), then discovery order
                     ++j;
                 }
             }
@@ -692,24 +713,11 @@ struct ByteAt {
 // ------------------------------------------------------------------------------------------
 // a11 + a12: contig walk.  PASS 0 counts (contigs, chars) per start, PASS 1 writes them.
 // ------------------------------------------------------------------------------------------
-struct WalkGraph {
-    const uint64_t *keys;
-    const uint8_t *flags;
-    const uint8_t *order;
-    const uint32_t *succ;
-    const uint32_t *cnt;
-    int k;
-};
-
-__device__ inline void spell_first(const WalkGraph &g, uint32_t node, char *out) {
-    const uint64_t key = g.keys[node];
-    for (int q = 0; q < g.k; ++q) out[q] = code_to_ascii((uint32_t)(key >> (2 * (g.k - 1 - q))) & 3u);
-}
-
 // non-final mode: each start yields at most one contig, a chain walk that stops at a branch
 // node / dead end (inclusive) or before a pulled node; a chain that closes on itself yields
 // nothing (debruijn.py:289-290).  Cycle detection by Brent's algorithm (no per-start memory).
-__global__ __launch_bounds__(256) void k_walk_chain(WalkGraph g, const uint32_t *starts, uint64_t n_starts, int pass,
+template <class G>
+__global__ __launch_bounds__(256) void k_walk_chain(G g, const uint32_t *starts, uint64_t n_starts, int pass,
                                                     uint64_t *ctg_per_start, uint64_t *chars_per_start,
                                                     const uint64_t *ctg_base, const uint64_t *char_base,
                                                     uint64_t *ctg_off, char *chars, uint64_t *score_out,
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256) void k_walk_chain(WalkGraph g, const uint32_t 
     char *out = nullptr;
     if (pass == 1) {
         out = chars + char_base[i];
-        spell_first(g, s, out);
+        g.spell(s, out);
         out += g.k;
     }
     uint32_t cur = s, tortoise = s;
@@ -731,14 +739,13 @@ __global__ __launch_bounds__(256) void k_walk_chain(WalkGraph g, const uint32_t 
     bool emit = false;
     while (true) {
         const uint8_t f = g.flags[cur];
-        const uint32_t keep = (f & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;
-        if ((f & DBG_F_BRANCH) || keep == 0) { emit = true; break; }  // [:304-313]
-        const uint32_t code = __ffs(keep) - 1;
-        const uint32_t nxt = g.succ[(uint64_t)cur * 4 + code];
+        if ((f & DBG_F_BRANCH) || g.keep_count(cur) == 0) { emit = true; break; }  // [:304-313]
+        const uint32_t code = g.first_kept(cur);
+        const uint32_t nxt = g.succ_of(cur, code);
         if (nxt == tortoise) break;  // revisit: nothing emitted [:289-290]
         if (g.flags[nxt] & DBG_F_PULLED) { emit = true; break; }  // path before the pulled node [:292-303]
-        score += g.cnt[(uint64_t)cur * 4 + code];
-        if (pass == 1) *out++ = code_to_ascii(code);
+        score += g.cnt_of(cur, code);
+        if (pass == 1) *out++ = g.sym_char(code);
         cur = nxt;
         ++len;
         if (++lam == power) { tortoise = cur; power <<= 1; lam = 0; }
@@ -761,7 +768,8 @@ __global__ __launch_bounds__(256) void k_walk_chain(WalkGraph g, const uint32_t 
 
 // final mode: every simple path from a start (debruijn.py:288-316 with branch_kmer == []).
 // One walker per thread; walker w owns stack slices of `stride` entries and a bitmap slice.
-__global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *starts, uint64_t n_starts, int pass,
+template <class G>
+__global__ __launch_bounds__(64) void k_walk_dfs(G g, const uint32_t *starts, uint64_t n_starts, int pass,
                                                  uint64_t n_walkers, uint64_t stride, uint32_t *st_node,
                                                  uint8_t *st_next, uint32_t *onpath, uint64_t bm_words,
                                                  uint64_t *ctg_per_start, uint64_t *chars_per_start,
@@ -771,7 +779,7 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_walkers) return;
     uint32_t *path = st_node + w * stride;
-    uint8_t *nxt = st_next + w * stride;  // low 3 bits: next rank to try, bit 7: prefix already emitted
+    uint8_t *nxt = st_next + w * stride;  // low 6 bits: next rank to try, bit 7: prefix already emitted
     uint32_t *bm = onpath + w * bm_words;
     for (uint64_t i = w; i < n_starts; i += n_walkers) {
         uint64_t n_ctg = 0, n_chr = 0;
@@ -783,15 +791,15 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
             const uint64_t nch = g.k + nn - 1;
             if (pass == 1) {
                 char *out = chars + ch_out;
-                spell_first(g, len > 0 ? path[0] : extra, out);
+                g.spell(len > 0 ? path[0] : extra, out);
                 out += g.k;
                 uint64_t score = 0;
                 uint32_t prev = len > 0 ? path[0] : extra;
                 for (uint64_t q = 1; q < nn; ++q) {
                     const uint32_t x = (q < (uint64_t)len) ? path[q] : extra;
-                    const uint32_t code = (uint32_t)(g.keys[x] & 3u);
-                    *out++ = code_to_ascii(code);
-                    score += g.cnt[(uint64_t)prev * 4 + code];
+                    const uint32_t code = g.last_code(x);
+                    *out++ = g.sym_char(code);
+                    score += g.cnt_of(prev, code);
                     prev = x;
                 }
                 ctg_off[c_out] = ch_out;
@@ -815,8 +823,7 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
                 }
                 return false;
             }
-            const uint32_t keep = (f & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;
-            if ((stop_at_branch && (f & DBG_F_BRANCH)) || keep == 0) {  // [:304-313]
+            if ((stop_at_branch && (f & DBG_F_BRANCH)) || g.keep_count(x) == 0) {  // [:304-313]
                 emit(depth, x, true);
                 return false;
             }
@@ -829,16 +836,16 @@ __global__ __launch_bounds__(64) void k_walk_dfs(WalkGraph g, const uint32_t *st
         enter(s0);
         while (depth > 0) {
             const uint32_t cur = path[depth - 1];
-            const int r = nxt[depth - 1] & 7;
-            if (r >= 4) {
+            const int r = nxt[depth - 1] & 0x3F;
+            if (r >= g.n_ranks(cur)) {
                 bm[cur >> 5] &= ~(1u << (cur & 31));
                 --depth;
                 continue;
             }
             nxt[depth - 1] = (uint8_t)((nxt[depth - 1] & 0x80) | (r + 1));
-            const uint32_t code = (g.order[cur] >> (2 * r)) & 3u;
-            if (!((g.flags[cur] >> (DBG_F_KEEP_SHIFT + code)) & 1u)) continue;
-            enter(g.succ[(uint64_t)cur * 4 + code]);
+            const uint32_t code = g.code_at(cur, r);
+            if (!g.kept(cur, code)) continue;
+            enter(g.succ_of(cur, code));
         }
         if (pass == 0) { ctg_per_start[i] = n_ctg; chars_per_start[i] = n_chr; }
     }
@@ -1011,17 +1018,16 @@ struct Jump {
 };
 constexpr unsigned long long JUMP_TERM = 1ull << 63;
 
-__global__ __launch_bounds__(256) void k_jump_init(uint64_t n_nodes, const uint8_t *flags, const uint32_t *succ,
-                                                   const uint32_t *cnt, Jump *J) {
+template <class G>
+__global__ __launch_bounds__(256) void k_jump_init(uint64_t n_nodes, G g, Jump *J) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_nodes) return;
-    const uint8_t f = flags[v];
-    const uint32_t keep = (f & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;
+    const uint8_t f = g.flags[v];
     Jump j{(uint32_t)v, 0, JUMP_TERM, 0};
-    if (!(f & (DBG_F_PULLED | DBG_F_BRANCH)) && keep) {  // chain node: exactly one surviving successor
-        const uint32_t code = __ffs(keep) - 1;
-        const uint32_t nxt = succ[v * 4 + code];
-        if (!(flags[nxt] & DBG_F_PULLED)) { j.target = nxt; j.hops = 1; j.score = cnt[v * 4 + code]; }
+    if (!(f & (DBG_F_PULLED | DBG_F_BRANCH)) && g.keep_count((uint32_t)v)) {  // chain node: exactly one surviving successor
+        const uint32_t code = g.first_kept((uint32_t)v);
+        const uint32_t nxt = g.succ_of((uint32_t)v, code);
+        if (!(g.flags[nxt] & DBG_F_PULLED)) { j.target = nxt; j.hops = 1; j.score = g.cnt_of((uint32_t)v, code); }
     }
     J[v] = j;
 }
@@ -1511,9 +1517,8 @@ extern "C" int dbg_prune(dbg_t *h, double threshold) {
     return DBG_OK;
 }
 
-extern "C" int dbg_remove_tips(dbg_t *h) {
-    if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
-    HIPCHK(h, hipSetDevice(h->device));
+template <class G>
+static int remove_tips_impl(dbg *h, const G &g) {
     Timer t(h->stream);
     h->tip_rounds = 0;
     h->n_pulled = 0;
@@ -1533,16 +1538,15 @@ extern "C" int dbg_remove_tips(dbg_t *h) {
         hipLaunchKernelGGL(k_collect_flagged, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                            h->d_flags, (uint8_t)DBG_F_BRANCH, (uint8_t)DBG_F_BRANCH, pend[0], ctr);
         HIPCHK(h, hipStreamSynchronize(h->stream));
-        TipGraph g{h->d_flags, h->d_order, h->d_succ, h->d_cnt};
         uint64_t n_pending = h->n_branch;
         int cur = 0;
         while (n_pending) {
             ++h->tip_rounds;
             HIPCHK(h, hipMemsetAsync(ctr, 0, 8, h->stream));
             const dim3 grid(grid_for(n_pending, 256));
-            hipLaunchKernelGGL(k_tip_reset, grid, dim3(256), 0, h->stream, g, pend[cur], n_pending, owner);
-            hipLaunchKernelGGL(k_tip_claim, grid, dim3(256), 0, h->stream, g, pend[cur], n_pending, h->d_stamps, owner);
-            hipLaunchKernelGGL(k_tip_commit, grid, dim3(256), 0, h->stream, g, h->d_flags, pend[cur], n_pending,
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tip_reset<G>), grid, dim3(256), 0, h->stream, g, pend[cur], n_pending, owner);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tip_claim<G>), grid, dim3(256), 0, h->stream, g, pend[cur], n_pending, h->d_stamps, owner);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tip_commit<G>), grid, dim3(256), 0, h->stream, g, h->d_flags, pend[cur], n_pending,
                                h->d_stamps, owner, (unsigned long long *)h->d_pull_rank, pend[cur ^ 1], ctr);
             uint64_t c2[2];
             HIPCHK(h, hipMemcpyAsync(c2, ctr, 16, hipMemcpyDeviceToHost, h->stream));
@@ -1560,6 +1564,14 @@ extern "C" int dbg_remove_tips(dbg_t *h) {
     h->tipped = true;
     h->walked = false;
     return DBG_OK;
+}
+
+static GDna dna_view(const dbg *h) { return GDna{h->d_keys, h->d_flags, h->d_order, h->d_succ, h->d_cnt, h->k}; }
+
+extern "C" int dbg_remove_tips(dbg_t *h) {
+    if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    return remove_tips_impl(h, dna_view(h));
 }
 
 extern "C" int dbg_mark_pull_reads(dbg_t *h) {
@@ -1592,9 +1604,8 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
     return DBG_OK;
 }
 
-extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
-    if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
-    HIPCHK(h, hipSetDevice(h->device));
+template <class G>
+static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     if (!max_chars) max_chars = 1ull << 30;
     Timer t(h->stream);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
@@ -1625,7 +1636,6 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
         if (h->n_nodes)
             hipLaunchKernelGGL(k_collect_flagged, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                                h->d_flags, (uint8_t)DBG_F_INDEG, (uint8_t)0, starts, ctr);
-        WalkGraph g{h->d_keys, h->d_flags, h->d_order, h->d_succ, h->d_cnt, h->k};
         uint64_t n_walkers = 0, stride = 0, bm_words = 0;
         if (final_mode && ns) {
             stride = h->n_nodes + 1;
@@ -1641,12 +1651,12 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
         auto launch = [&](int pass) {
             if (!ns) return;
             if (final_mode)
-                hipLaunchKernelGGL(k_walk_dfs, dim3(grid_for(n_walkers, 64)), dim3(64), 0, h->stream, g, starts, ns, pass,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_dfs<G>), dim3(grid_for(n_walkers, 64)), dim3(64), 0, h->stream, g, starts, ns, pass,
                                    n_walkers, stride, st_node, st_next, onpath, bm_words, per_ctg, per_chr, base_ctg,
                                    base_chr, h->d_ctg_off, h->d_ctg_chars, h->d_ctg_score, h->d_ctg_stamp,
                                    h->d_ctg_seq, h->d_stamps, false);
             else
-                hipLaunchKernelGGL(k_walk_chain, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, g, starts, ns, pass,
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_walk_chain<G>), dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, g, starts, ns, pass,
                                    per_ctg, per_chr, base_ctg, base_chr, h->d_ctg_off, h->d_ctg_chars,
                                    h->d_ctg_score, h->d_ctg_stamp, h->d_ctg_seq, h->d_stamps);
         };
@@ -1655,7 +1665,7 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
             if ((rc = dev_alloc(h, &jump[0], h->n_nodes)) != DBG_OK) break;
             if ((rc = dev_alloc(h, &jump[1], h->n_nodes)) != DBG_OK) break;
             const dim3 grid(grid_for(h->n_nodes, 256));
-            hipLaunchKernelGGL(k_jump_init, grid, dim3(256), 0, h->stream, h->n_nodes, h->d_flags, h->d_succ, h->d_cnt, jump[0]);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_jump_init<G>), grid, dim3(256), 0, h->stream, h->n_nodes, g, jump[0]);
             int cur = 0, max_rounds = 2;
             while ((1ull << (max_rounds - 1)) < h->n_nodes) ++max_rounds;  // chains are shorter than n_nodes
             for (int round = 0; round < max_rounds; ++round) {
@@ -1708,6 +1718,12 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
     cleanup();
     h->stats.ms_walk = t.stop();
     return rc;
+}
+
+extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
+    if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    return walk_impl(h, dna_view(h), final_mode, max_chars);
 }
 
 extern "C" int dbg_get_sizes(dbg_t *h, dbg_sizes_t *o) {
