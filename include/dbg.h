@@ -22,9 +22,10 @@
  *     concatenated read buffer << 1) | (1 if that occurrence is NOT at position
  *     0 of its read).  Ascending stamp == the reference's dict insertion order
  *     (debruijn.py:121-147); stamp & 1 == the reference's Node.indegree.
- *   - only upper-case A/C/G/T reads are accepted (DBG_E_ALPHABET otherwise);
- *     the reference's str-based code is alphabet-agnostic, the peptide alphabet
- *     is a later row of SURVEY.md section 8f.
+ *   - reads made of upper-case A/C/G/T only take the 2-bit path above (k <= 31).  Any other
+ *     alphabet (the reference is alphabet-agnostic; its real inputs are peptides) takes the
+ *     generic path: up to 32 distinct bytes, 5 bits per character, codes in byte order
+ *     (dbg_get_alphabet), k <= 11, 32 successor slots per node; DBG_E_ALPHABET beyond that.
  */
 #ifndef DBG_H
 #define DBG_H
@@ -73,6 +74,7 @@ typedef struct dbg_sizes {
     uint64_t contig_chars;     /* total characters over all contigs */
     uint64_t tip_rounds;       /* reservation rounds the tip removal needed */
     uint64_t contigs_materialised; /* 1: contig text available (dbg_export_contigs); 0: index only */
+    uint64_t max_degree;       /* successor slots per node: 4 (ACGT reads) or 32 (any other alphabet) */
 } dbg_sizes_t;
 
 typedef struct dbg_stats {
@@ -139,6 +141,12 @@ int dbg_refine_edge_order(dbg_t *h);
 /* order[n_nodes]: successor base codes, 2 bits each, rank 0 in bits 1:0: count descending, ties by first
  * appearance (== Counter.most_common); fsorder[n_nodes]: by first appearance (== Counter key order). */
 int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder);
+/* Generic alphabet (max_degree == 32): order / fsorder are [n_nodes][32] bytes, one successor code per
+ * rank, 0xFF beyond the out-degree; counts and succ of dbg_export_nodes / dbg_export_succ are [n_nodes][32]. */
+/* codes32[code] = the byte a code stands for; bits per symbol 2 (ACGT) or 5 */
+int dbg_get_alphabet(dbg_t *h, char *codes32, int *n_symbols, int *bits_per_symbol);
+/* surviving successors after dbg_prune, bit `code` per node (both layouts) */
+int dbg_export_keepmask(dbg_t *h, uint32_t *keepmask);
 
 /* ---- a5 + a6: pruningEdges (debruijn.py:150-166) + branch detection (:230-236) */
 int dbg_prune(dbg_t *h, double threshold);

@@ -31,12 +31,23 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = os.environ.get("DBG_REFERENCE", "/root/reference")
-sys.path.insert(0, REF)
-sys.path.insert(0, os.path.join(ROOT, "py-debruijn_amd"))
 sys.dont_write_bytecode = True
+import importlib.util  # noqa: E402
 
-import debruijn as ref  # noqa: E402  (the reference itself)
-import synth  # noqa: E402
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# The reference is loaded BY PATH (this repo ships a drop-in that is also called debruijn.py).  Its driver does
+# ``import debruijn as db``: the name must resolve to the reference while the driver module is loaded.
+ref = _load("debruijn", os.path.join(REF, "debruijn.py"))
+assert os.path.realpath(ref.__file__).startswith(os.path.realpath(REF)), "fixtures must come from the reference"
+synth = _load("synth", os.path.join(ROOT, "py-debruijn_amd", "synth.py"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
@@ -83,10 +94,10 @@ def run_reference_driver(reads, kl, ku, threshold):
     box = {}
 
     def work():
-        import importlib.util
         spec = importlib.util.spec_from_file_location("ref_II", os.path.join(REF, "II_assembleFromReads.py"))
         mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
+        spec.loader.exec_module(mod)  # its "import debruijn" finds the reference in sys.modules
+        assert mod.db is ref
         sequences = list(reads)
         trace = {}
         buf = io.StringIO()
@@ -247,6 +258,38 @@ def main():
     print("fuzz_small:", len(fuzz), "cases;",
           sum(1 for c in fuzz if c["result"]["already_pull_out"]), "with pulled tips;",
           sum(1 for c in fuzz if c["result"]["branch_kmer"]), "with branches")
+
+    # randomized peptide cases (the reference's real alphabet): 20 amino acids, plus low-complexity
+    # sub-alphabets that make branches, tips and cycles dense; k within the 5-bit packing limit
+    rng = random.Random(20260411)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    pfuzz = []
+    for i in range(240):
+        alpha = rng.choice([aa, aa, aa[:6], "EVQLG", "KR", aa[:12]])
+        k = rng.randint(2, 7)
+        n = rng.randint(1, 16)
+        if rng.random() < 0.6:
+            G = "".join(rng.choice(alpha) for _ in range(rng.randint(10, 60)))
+            reads = []
+            for _ in range(n):
+                L = rng.randint(1, min(len(G), k + 12))
+                st = rng.randint(0, len(G) - L)
+                r = list(G[st:st + L])
+                if rng.random() < 0.4:
+                    r[rng.randrange(L)] = rng.choice(alpha)
+                reads.append("".join(r))
+        else:
+            reads = ["".join(rng.choice(alpha) for _ in range(rng.randint(0, k + 10))) for _ in range(n)]
+        thr = rng.choice([1, 2, 2, 3, 3, 5])
+        final = rng.random() < 0.4
+        res = run_reference(reads, k, thr, final)
+        pfuzz.append({"inputs": {"reads": reads, "k": k, "threshold": thr, "final": final}, "result": res})
+    with open(os.path.join(GOLDEN, "fuzz_peptide.json"), "w") as fh:
+        json.dump(pfuzz, fh, separators=(",", ":"))
+    print("fuzz_peptide:", len(pfuzz), "cases;",
+          sum(1 for c in pfuzz if c["result"]["already_pull_out"]), "with pulled tips;",
+          sum(1 for c in pfuzz if c["result"]["branch_kmer"]), "with branches;",
+          sum(1 for c in pfuzz if c["result"]["contigs"]), "with contigs")
 
     # generator checksum (host twin; the device twin must match, tests/test_synth.py)
     chk = {"seed": 1, "genome_len": 100000, "n_reads": 10000, "read_len": 100}

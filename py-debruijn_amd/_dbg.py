@@ -24,6 +24,7 @@ SYMBOLS = (
     "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_fasta",
     "dbg_set_reads_device",
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
+    "dbg_get_alphabet", "dbg_export_keepmask",
     "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
@@ -36,7 +37,7 @@ class Sizes(C.Structure):
         (n, C.c_uint64) for n in (
             "n_reads", "n_bytes", "n_kmer_instances", "n_edge_instances", "table_capacity", "n_nodes", "n_edges",
             "n_branch", "n_pulled", "n_pull_reads", "n_starts", "n_contigs", "contig_chars", "tip_rounds",
-            "contigs_materialised")]
+            "contigs_materialised", "max_degree")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -92,6 +93,8 @@ def load_library():
         "dbg_build": (C.c_int, [H, C.c_int, C.c_uint64]),
         "dbg_refine_edge_order": (C.c_int, [H]),
         "dbg_export_orders": (C.c_int, [H, vp, vp]),
+        "dbg_get_alphabet": (C.c_int, [H, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+        "dbg_export_keepmask": (C.c_int, [H, vp]),
         "dbg_prune": (C.c_int, [H, C.c_double]),
         "dbg_remove_tips": (C.c_int, [H]),
         "dbg_mark_pull_reads": (C.c_int, [H]),
@@ -214,8 +217,16 @@ class Graph:
         self._chk(self._lib.dbg_refine_edge_order(self._h))
 
     def export_orders(self):
-        n = self.sizes()["n_nodes"]
-        a, b = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8)
+        """Successor codes by rank, as (n_nodes, max_degree) arrays (0xFF beyond the out-degree for the generic
+        layout): Counter.most_common order and first-seen order."""
+        sz = self.sizes()
+        n, d = sz["n_nodes"], sz["max_degree"]
+        if d == 4:  # packed: 2 bits per rank
+            a, b = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8)
+            self._chk(self._lib.dbg_export_orders(self._h, _ptr(a), _ptr(b)))
+            sh = np.array([0, 2, 4, 6], dtype=np.uint8)[None, :]
+            return (a[:, None] >> sh) & 3, (b[:, None] >> sh) & 3
+        a, b = np.empty((n, d), dtype=np.uint8), np.empty((n, d), dtype=np.uint8)
         self._chk(self._lib.dbg_export_orders(self._h, _ptr(a), _ptr(b)))
         return a, b
 
@@ -242,18 +253,32 @@ class Graph:
         return s.as_dict()
 
     # ---- exports
+    def alphabet(self):
+        """(bytes: code -> character, bits per symbol) of the built graph: b"ACTG"/2 for DNA reads, else byte order/5."""
+        buf = (C.c_char * 32)()
+        n, bits = C.c_int(), C.c_int()
+        self._chk(self._lib.dbg_get_alphabet(self._h, buf, C.byref(n), C.byref(bits)))
+        return bytes(buf.raw[:n.value]), bits.value
+
+    def export_keepmask(self):
+        m = np.empty(self.sizes()["n_nodes"], dtype=np.uint32)
+        self._chk(self._lib.dbg_export_keepmask(self._h, _ptr(m)))
+        return m
+
     def export_nodes(self, keys=True, stamps=True, counts=True, flags=True):
-        n = self.sizes()["n_nodes"]
+        sz = self.sizes()
+        n, d = sz["n_nodes"], sz["max_degree"]
         a = np.empty(n, dtype=np.uint64) if keys else None
         b = np.empty(n, dtype=np.uint64) if stamps else None
-        c = np.empty((n, 4), dtype=np.uint32) if counts else None
+        c = np.empty((n, d), dtype=np.uint32) if counts else None
         d = np.empty(n, dtype=np.uint8) if flags else None
         self._chk(self._lib.dbg_export_nodes(self._h, _ptr(a), _ptr(b), _ptr(c), _ptr(d)))
         return a, b, c, d
 
     def export_succ(self):
-        n = self.sizes()["n_nodes"]
-        s = np.empty((n, 4), dtype=np.uint32)
+        sz = self.sizes()
+        n = sz["n_nodes"]
+        s = np.empty((n, sz["max_degree"]), dtype=np.uint32)
         self._chk(self._lib.dbg_export_succ(self._h, _ptr(s)))
         return s
 
@@ -354,17 +379,15 @@ def device_tensor(ptr, n, dtype, device_index):
 
 
 # ---- 2-bit key <-> str helpers (host side of the boundary) -------------------------------
-_CODE_ASCII = np.frombuffer(b"ACTG", dtype=np.uint8)  # code = (ascii >> 1) & 3
-
-
-def decode_keys(keys, k):
-    """uint64 keys -> list of k-character str."""
+def decode_keys(keys, k, alphabet=b"ACTG", bits=2):
+    """uint64 keys -> list of k-character str (alphabet[code] = character; DNA: code = (ascii >> 1) & 3)."""
     keys = np.asarray(keys, dtype=np.uint64)
     if keys.size == 0:
         return []
-    shifts = (2 * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
-    codes = ((keys[:, None] >> shifts[None, :]) & np.uint64(3)).astype(np.intp)
-    buf = _CODE_ASCII[codes].tobytes().decode("ascii")
+    table = np.frombuffer(alphabet.ljust(1 << bits, b"?"), dtype=np.uint8)
+    shifts = (bits * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
+    codes = ((keys[:, None] >> shifts[None, :]) & np.uint64((1 << bits) - 1)).astype(np.intp)
+    buf = table[codes].tobytes().decode("latin-1")
     return [buf[i * k:(i + 1) * k] for i in range(keys.size)]
 
 

@@ -20,6 +20,7 @@
 #include "../../include/dbg.h"
 #include "dbg_device.h"
 #include "dbg_sk.h"
+#include "dbg_generic.h"
 
 using namespace dbgk;
 
@@ -82,6 +83,15 @@ struct dbg {
     bool walked = false;          // contig text materialised
     bool walk_indexed = false;    // contig index (offsets, scores, start stamps) valid
     uint64_t walk_jump_min = 1ull << 20;  // non-final walk: pointer jumping from this many nodes on
+
+    // alphabet / node layout: 2 bits and 4 successors for DNA, 5 bits and 32 for the generic engine
+    int D = 4, sym_bits = 2, n_sym = 0;
+    bool alpha_known = false, is_dna = true;
+    uint8_t alphabet[32] = {0};       // generic: code -> byte (codes are assigned in byte order)
+    uint8_t *d_lut = nullptr;         // generic: byte -> code (256 entries)
+    char *d_alpha = nullptr;          // generic: code -> byte (32 entries, device)
+    uint32_t *d_keepmask = nullptr;   // generic: surviving successors per node
+    uint8_t *d_rank_mc = nullptr, *d_rank_fs = nullptr;  // generic: [n][32] successor codes by rank
 
     // options (dbg_set_option)
     int engine = 0;          // 0 = super-k-mer partitioned build, 1 = single global hash table
@@ -1095,6 +1105,8 @@ static void free_build(dbg *h) {
     h->btab_cap = 0;
     dev_free(h->d_fsorder);
     h->order_exact = false;
+    dev_free(h->d_keepmask); dev_free(h->d_rank_mc); dev_free(h->d_rank_fs);
+    h->D = 4; h->sym_bits = 2;
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
     dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_deg);
     h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
@@ -1115,6 +1127,8 @@ static void free_reads(dbg *h) {
     h->d_bases = nullptr; h->d_offsets = nullptr;
     h->own_bases = h->own_offsets = false;
     dev_free(h->d_startbits);
+    dev_free(h->d_lut); dev_free(h->d_alpha);
+    h->alpha_known = false;
     h->n_bytes = h->n_reads = 0;
 }
 
@@ -1327,8 +1341,12 @@ static int finish_graph(dbg *h) {
         h->d_col = (uint32_t *)h->ar_csr[1].p;
         h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
         if (h->n_nodes) {
-            hipLaunchKernelGGL(k_csr_fill, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
-                               h->d_rowptr, h->d_cnt, h->d_succ, h->d_col, h->d_ecnt);
+            if (h->D == GEN_D)
+                hipLaunchKernelGGL(k_g_csr_fill, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
+                                   h->d_rowptr, h->d_cnt, h->d_succ, h->d_col, h->d_ecnt);
+            else
+                hipLaunchKernelGGL(k_csr_fill, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
+                                   h->d_rowptr, h->d_cnt, h->d_succ, h->d_col, h->d_ecnt);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.ms_csr = t.stop();
@@ -1342,6 +1360,127 @@ static int finish_graph(dbg *h) {
     return DBG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// alphabet of the current read set; generic engine host side
+// ------------------------------------------------------------------------------------------
+static int compute_alphabet(dbg *h) {
+    if (h->alpha_known) return DBG_OK;
+    uint64_t hist[256];
+    memset(hist, 0, sizeof(hist));
+    if (h->n_bytes) {
+        unsigned long long *d_hist = nullptr;
+        CHK(dev_alloc(h, &d_hist, 256));
+        (void)hipMemsetAsync(d_hist, 0, 256 * 8, h->stream);
+        const unsigned grid = (unsigned)std::min<uint64_t>((h->n_bytes + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_g_hist, dim3(grid), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, d_hist);
+        hipError_t e = hipMemcpyAsync(hist, d_hist, sizeof(hist), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(d_hist);
+        if (e != hipSuccess) { h->err = std::string("alphabet scan: ") + hipGetErrorString(e); return DBG_E_HIP; }
+    }
+    h->n_sym = 0;
+    h->is_dna = true;
+    uint8_t lut[256];
+    memset(lut, 0xFF, sizeof(lut));
+    for (int c = 0; c < 256; ++c) {
+        if (!hist[c]) continue;
+        if (c != 'A' && c != 'C' && c != 'G' && c != 'T') h->is_dna = false;
+        if (h->n_sym < 32) { h->alphabet[h->n_sym] = (uint8_t)c; lut[c] = (uint8_t)h->n_sym; }
+        ++h->n_sym;
+    }
+    dev_free(h->d_lut);
+    dev_free(h->d_alpha);
+    CHK(dev_alloc(h, &h->d_lut, 256));
+    CHK(dev_alloc(h, &h->d_alpha, 32));
+    HIPCHK(h, hipMemcpyAsync(h->d_lut, lut, 256, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_alpha, h->alphabet, 32, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->alpha_known = true;
+    return DBG_OK;
+}
+
+static GGen gen_view(const dbg *h) {
+    return GGen{h->d_keys, h->d_flags, h->d_keepmask, h->d_rank_mc, h->d_deg, h->d_succ, h->d_cnt, h->d_alpha, h->k};
+}
+
+static int build_generic(dbg *h, int k) {
+    if (h->n_sym > GEN_D) { h->err = "reads hold more than 32 distinct characters"; return DBG_E_ALPHABET; }
+    if (GEN_BITS * (k + 1) > 64) {
+        h->err = "alphabets other than ACGT are packed at 5 bits per character: k must be <= 11";
+        return DBG_E_ALPHABET;
+    }
+    h->D = GEN_D;
+    h->sym_bits = GEN_BITS;
+    Timer t_count(h->stream);
+    uint64_t cap = 1024;
+    while (cap < (h->n_bytes + 1) * 2) cap <<= 1;
+    GenNodeSlot *nodes = nullptr;
+    GenEdgeSlot *edges = nullptr;
+    uint32_t *occ = nullptr, *eocc = nullptr, *word_rank = nullptr;
+    unsigned long long *estamp = nullptr;
+    auto cleanup = [&]() { dev_free(nodes); dev_free(edges); dev_free(occ); dev_free(eocc); dev_free(word_rank); dev_free(estamp); };
+    int rc = DBG_OK;
+    do {
+        if ((rc = dev_alloc(h, &nodes, cap)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &edges, cap)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &occ, cap / 32)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &eocc, cap / 32)) != DBG_OK) break;
+        (void)hipMemsetAsync(occ, 0, cap / 8, h->stream);
+        (void)hipMemsetAsync(eocc, 0, cap / 8, h->stream);
+        (void)hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream);
+        hipLaunchKernelGGL(k_g_init_tables, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, nodes, edges, cap);
+        if (h->n_bytes) {
+            const unsigned grid = (unsigned)std::min<uint64_t>((h->n_bytes + 255) / 256, 1u << 16);
+            hipLaunchKernelGGL(k_g_insert, dim3(grid), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, h->d_startbits, k,
+                               h->d_lut, nodes, occ, edges, eocc, cap - 1, (unsigned long long *)h->d_scalars);
+        }
+        uint64_t sc[4] = {0, 0, 0, 0};
+        if (hipMemcpyAsync(sc, h->d_scalars, 32, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "generic count failed"; rc = DBG_E_HIP; break; }
+        if (sc[0] & 2) { h->err = "generic engine: hash table full"; rc = DBG_E_CAPACITY; break; }
+        h->n_kmer_inst = sc[1];
+        h->n_edge_inst = sc[2];
+        h->stats.ms_count = t_count.stop();
+        h->stats.count_launches = 1;
+        // nodes in table order
+        Timer t_c(h->stream);
+        const uint64_t n_words = cap / 32;
+        if ((rc = dev_alloc(h, &word_rank, n_words)) != DBG_OK) break;
+        uint64_t n = 0;
+        if ((rc = exclusive_scan(h, n_words, PopcWords{occ}, word_rank, &n)) != DBG_OK) break;
+        h->n_nodes = n;
+        if ((rc = dev_alloc(h, &h->d_keys, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_stamps, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_flags, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_cnt, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_succ, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_deg, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_keepmask, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_rank_mc, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_rank_fs, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &estamp, n * GEN_D)) != DBG_OK) break;
+        if (n) {
+            (void)hipMemsetAsync(h->d_cnt, 0, n * GEN_D * 4, h->stream);
+            (void)hipMemsetAsync(h->d_succ, 0xFF, n * GEN_D * 4, h->stream);
+            (void)hipMemsetAsync(estamp, 0xFF, n * GEN_D * 8, h->stream);
+            (void)hipMemsetAsync(h->d_keepmask, 0, n * 4, h->stream);
+            hipLaunchKernelGGL(k_g_gather, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, nodes, occ, word_rank, n_words,
+                               h->d_keys, h->d_stamps, h->d_flags);
+            hipLaunchKernelGGL(k_g_edges, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, edges, cap, nodes, cap - 1, k,
+                               h->d_cnt, h->d_succ, estamp, (unsigned long long *)h->d_scalars);
+            hipLaunchKernelGGL(k_g_rank, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_cnt, estamp, h->d_rank_mc,
+                               h->d_rank_fs, h->d_deg);
+        }
+        if (hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "generic graph assembly failed"; rc = DBG_E_HIP; break; }
+        if (sc[0] & 128) { h->err = "internal: edge endpoint missing from the node table"; rc = DBG_E_HIP; break; }
+        h->stats.ms_succ = t_c.stop();
+        h->order_exact = true;  // ranks come from per-edge first-seen positions already
+    } while (0);
+    cleanup();
+    return rc;
+}
 
 extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (!h || !name) return DBG_E_ARG;
@@ -1363,6 +1502,15 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     free_build(h);
     h->k = k;
     h->stats = dbg_stats_t{};
+    CHK(compute_alphabet(h));
+    if (!h->is_dna) {  // any other alphabet: generic 5-bit engine (peptides: the reference's real inputs)
+        Timer t_total(h->stream);
+        int rc = build_generic(h, k);
+        if (rc == DBG_OK) rc = finish_graph(h);
+        if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+        h->stats.ms_build_total = t_total.stop();
+        return DBG_OK;
+    }
     if (h->engine == 0) {
         Timer t_total(h->stream);
         int rc = build_sk(h, k, table_capacity_hint);
@@ -1451,6 +1599,7 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
     if (!h || !h->k) return DBG_E_ARG;
     if (h->shard_state && shard_of(h).shard_bits) { h->err = "edge-order refinement is single-GPU for now"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->D == GEN_D) return DBG_OK;  // the generic engine ranks by per-edge first-seen positions at build time
     dev_free(h->d_fsorder);
     CHK(dev_alloc(h, &h->d_fsorder, h->n_nodes));
     if (!h->n_nodes) { h->order_exact = true; return DBG_OK; }
@@ -1488,11 +1637,55 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
 
 extern "C" int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder) {
     if (!h || !h->k) return DBG_E_ARG;
-    if (fsorder && !h->d_fsorder) { h->err = "dbg_refine_edge_order must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->D == GEN_D) {  // one byte per rank: [n_nodes][32] successor codes, 0xFF beyond the out-degree
+        if (order && h->n_nodes) HIPCHK(h, hipMemcpyAsync(order, h->d_rank_mc, h->n_nodes * GEN_D, hipMemcpyDeviceToHost, h->stream));
+        if (fsorder && h->n_nodes) HIPCHK(h, hipMemcpyAsync(fsorder, h->d_rank_fs, h->n_nodes * GEN_D, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return DBG_OK;
+    }
+    if (fsorder && !h->d_fsorder) { h->err = "dbg_refine_edge_order must run first"; return DBG_E_ARG; }
     if (order && h->n_nodes) HIPCHK(h, hipMemcpyAsync(order, h->d_order, h->n_nodes, hipMemcpyDeviceToHost, h->stream));
     if (fsorder && h->n_nodes) HIPCHK(h, hipMemcpyAsync(fsorder, h->d_fsorder, h->n_nodes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_keepmask_from_flags(uint64_t n, const uint8_t *flags, uint32_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)(flags[i] & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;
+}
+
+extern "C" int dbg_export_keepmask(dbg_t *h, uint32_t *keepmask) {
+    if (!h || !h->pruned || !keepmask) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->n_nodes) return DBG_OK;
+    if (h->D == GEN_D) {
+        HIPCHK(h, hipMemcpyAsync(keepmask, h->d_keepmask, h->n_nodes * 4, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        uint32_t *tmp = nullptr;
+        CHK(dev_alloc(h, &tmp, h->n_nodes));
+        hipLaunchKernelGGL(k_keepmask_from_flags, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
+                           h->d_flags, tmp);
+        hipError_t e = hipMemcpyAsync(keepmask, tmp, h->n_nodes * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        (void)hipFree(tmp);
+        if (e != hipSuccess) { h->err = hipGetErrorString(e); return DBG_E_HIP; }
+        return DBG_OK;
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
+extern "C" int dbg_get_alphabet(dbg_t *h, char *codes32, int *n_symbols, int *bits_per_symbol) {
+    if (!h || !h->k) return DBG_E_ARG;
+    if (codes32) {
+        memset(codes32, 0, 32);
+        if (h->D == GEN_D) memcpy(codes32, h->alphabet, 32);
+        else memcpy(codes32, "ACTG", 4);  // code = (ascii >> 1) & 3
+    }
+    if (n_symbols) *n_symbols = h->D == GEN_D ? h->n_sym : 4;
+    if (bits_per_symbol) *bits_per_symbol = h->sym_bits;
     return DBG_OK;
 }
 
@@ -1502,7 +1695,12 @@ extern "C" int dbg_prune(dbg_t *h, double threshold) {
     HIPCHK(h, hipSetDevice(h->device));
     Timer t(h->stream);
     HIPCHK(h, hipMemsetAsync(h->d_scalars + 16, 0, 8, h->stream));
-    if (h->n_nodes) {
+    if (h->n_nodes && h->D == GEN_D) {
+        hipLaunchKernelGGL(k_g_prune, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_cnt,
+                           h->d_rank_mc, h->d_deg, threshold, h->d_keepmask, h->d_flags,
+                           (unsigned long long *)(h->d_scalars + 16));
+        HIPCHK(h, hipGetLastError());
+    } else if (h->n_nodes) {
         hipLaunchKernelGGL(k_prune, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_cnt,
                            h->d_order, threshold, h->d_flags, (unsigned long long *)(h->d_scalars + 16));
         HIPCHK(h, hipGetLastError());
@@ -1571,6 +1769,7 @@ static GDna dna_view(const dbg *h) { return GDna{h->d_keys, h->d_flags, h->d_ord
 extern "C" int dbg_remove_tips(dbg_t *h) {
     if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->D == GEN_D) return remove_tips_impl(h, gen_view(h));
     return remove_tips_impl(h, dna_view(h));
 }
 
@@ -1592,8 +1791,13 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
         HIPCHK(h, hipMemsetAsync(h->d_btab, 0xFF, bcap * 8, h->stream));
         hipLaunchKernelGGL(k_branch_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                            h->d_flags, h->d_keys, (unsigned long long *)h->d_btab, bcap - 1);
-        hipLaunchKernelGGL(k_pull_reads, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
-                           h->d_startbits, h->k, h->d_btab, bcap - 1, h->d_offsets, h->n_reads, h->d_read_flags);
+        if (h->D == GEN_D)
+            hipLaunchKernelGGL(k_g_pull_reads, dim3((unsigned)std::min<uint64_t>(tiles * 32, 1u << 16)), dim3(256), 0, h->stream,
+                               h->d_bases, h->n_bytes, h->d_startbits, h->k, h->d_lut, h->d_btab, bcap - 1, h->d_offsets,
+                               h->n_reads, h->d_read_flags);
+        else
+            hipLaunchKernelGGL(k_pull_reads, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, h->k, h->d_btab, bcap - 1, h->d_offsets, h->n_reads, h->d_read_flags);
         HIPCHK(h, hipGetLastError());
         uint64_t total = 0;
         CHK(reduce_sum(h, h->n_reads, ByteAt{h->d_read_flags}, &total));
@@ -1723,6 +1927,7 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
 extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
     if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    if (h->D == GEN_D) return walk_impl(h, gen_view(h), final_mode, max_chars);
     return walk_impl(h, dna_view(h), final_mode, max_chars);
 }
 
@@ -1746,6 +1951,7 @@ extern "C" int dbg_get_sizes(dbg_t *h, dbg_sizes_t *o) {
     o->contig_chars = h->contig_chars;
     o->tip_rounds = h->tip_rounds;
     o->contigs_materialised = h->walked ? 1 : 0;
+    o->max_degree = (uint64_t)h->D;
     return DBG_OK;
 }
 
@@ -1762,7 +1968,7 @@ extern "C" int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint
     HIPCHK(h, hipSetDevice(h->device));
     D2H(h, keys, h->d_keys, h->n_nodes * 8);
     D2H(h, stamps, h->d_stamps, h->n_nodes * 8);
-    D2H(h, counts, h->d_cnt, h->n_nodes * 16);
+    D2H(h, counts, h->d_cnt, h->n_nodes * 4 * h->D);
     D2H(h, flags, h->d_flags, h->n_nodes);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DBG_OK;
@@ -1771,7 +1977,7 @@ extern "C" int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint
 extern "C" int dbg_export_succ(dbg_t *h, uint32_t *succ) {
     if (!h || !h->k) return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    D2H(h, succ, h->d_succ, h->n_nodes * 16);
+    D2H(h, succ, h->d_succ, h->n_nodes * 4 * h->D);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DBG_OK;
 }

@@ -7,7 +7,9 @@ through the C ABI of ``include/dbg.h`` (binding: ``_dbg.py``).  There is no CPU
 path: without the built library and a GPU every call raises.
 
 Differences a caller can observe, all documented in DESIGN.md:
-  * reads must be upper-case A/C/G/T and 1 <= k <= 31 (ValueError otherwise);
+  * limits of the packed k-mer words: reads of upper-case A/C/G/T only: 1 <= k <= 31; any other alphabet
+    (peptides, lower case, N, ...): at most 32 distinct single-byte characters and 1 <= k <= 11
+    (ValueError otherwise -- never a silent drop or split);
   * ``output_contigs`` needs the objects returned by this module's ``construct_graph``.
 Everything else -- values AND orders (dict insertion order, ``Counter.most_common`` tie order,
 the append order of ``already_pull_out``, contig order) -- equals the reference.
@@ -21,7 +23,6 @@ import _dbg
 __all__ = ["Node", "read_reads", "read_reads_device", "DeviceReads", "construct_graph", "output_contigs",
            "get_score_device"]
 
-_CODE_CHAR = "ACTG"               # code = (ascii >> 1) & 3
 
 
 class Node:
@@ -109,16 +110,10 @@ class ContigList(list):
 
 def _pack_reads(reads):
     try:
-        blob = "".join(reads).encode("ascii")
+        blob = "".join(reads).encode("latin-1")  # one byte per character
     except UnicodeEncodeError as e:
-        raise ValueError("reads must be upper-case A/C/G/T for the device path") from e
+        raise ValueError("reads must be made of single-byte characters for the device path") from e
     arr = np.frombuffer(blob, dtype=np.uint8)
-    if arr.size:
-        ok = (arr == 65) | (arr == 67) | (arr == 71) | (arr == 84)
-        if not bool(ok.all()):
-            bad = chr(int(arr[np.argmin(ok)]))
-            raise ValueError(f"reads must be upper-case A/C/G/T for the device path (found {bad!r}); "
-                             f"other alphabets are not on the MI355X path yet")
     lens = np.fromiter((len(r) for r in reads), dtype=np.uint64, count=len(reads))
     offsets = np.zeros(len(reads) + 1, dtype=np.uint64)
     np.cumsum(lens, out=offsets[1:])
@@ -131,7 +126,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     Returns ((vertices, edges), pull_out_read, branch_kmer, already_pull_out, edge_count_table).
     """
     if not isinstance(k, (int, np.integer)) or not (1 <= int(k) <= 31):
-        raise ValueError("the device path supports 1 <= k <= 31")
+        raise ValueError("the device path supports 1 <= k <= 31 (1 <= k <= 11 for alphabets other than ACGT)")
     k = int(k)
     if isinstance(reads, DeviceReads):
         g = reads._graph  # reads are resident (alphabet is checked by the kernels: AlphabetError is a ValueError)
@@ -158,16 +153,19 @@ def construct_graph(reads, k, threshold=3, final=False):
         g.mark_pull_reads()
 
     keys, stamps, counts, flags = g.export_nodes()
-    rank_mc, rank_fs = g.export_orders()
+    rank_mc, rank_fs = g.export_orders()          # (n, D): successor codes by rank
+    alphabet, bits = g.alphabet()                 # code -> character
+    chars = alphabet.decode("latin-1")
     order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
-    labels = _dbg.decode_keys(keys[order], k)
+    labels = _dbg.decode_keys(keys[order], k, alphabet, bits)
     counts_o = counts[order]
     rank_mc, rank_fs = rank_mc[order], rank_fs[order]
     flags_o = flags[order]
     outdeg = (counts_o != 0).sum(axis=1)
     indeg = flags_o & _dbg.F_INDEG
     pulled_o = (flags_o & _dbg.F_PULLED) != 0
-    keep_o = (flags_o & _dbg.F_KEEP_MASK) >> _dbg.F_KEEP_SHIFT
+    keep_o = g.export_keepmask()[order]
+    n_ranks = rank_mc.shape[1]
 
     vertices = _Vertices()
     edges = {}
@@ -176,14 +174,15 @@ def construct_graph(reads, k, threshold=3, final=False):
         vertices[lab] = Node(lab, int(indeg[i]), int(outdeg[i]))
         c = counts_o[i]
         tail = lab[1:]
-        mc, fs = int(rank_mc[i]), int(rank_fs[i])
-        ranked = [code for code in ((mc >> (2 * r)) & 3 for r in range(4)) if c[code]]  # Counter.most_common order
-        for code in ((fs >> (2 * r)) & 3 for r in range(4)):                            # Counter key order
-            if c[code]:
-                ect[lab + _CODE_CHAR[code]] = int(c[code])
+        nd = int(outdeg[i])
+        # a rank holds a code only where the node has that many successors (DNA ranks all four codes)
+        ranked = [int(code) for code in rank_mc[i, :n_ranks] if code != 0xFF and c[code]][:nd]  # Counter.most_common order
+        for code in rank_fs[i, :n_ranks]:                                                        # Counter key order
+            if code != 0xFF and c[code]:
+                ect[lab + chars[code]] = int(c[code])
         if not pulled_o[i]:
             kp = int(keep_o[i])
-            edges[lab] = [tail + _CODE_CHAR[code] for code in ranked if (kp >> code) & 1]
+            edges[lab] = [tail + chars[code] for code in ranked if (kp >> code) & 1]
 
     ranks = g.export_pull_ranks()[order]
     pulled_idx = np.nonzero(pulled_o)[0]

@@ -44,8 +44,8 @@ def test_binding_covers_header():
 
 def test_struct_layouts_match_header(lib):
     import _dbg
-    # dbg_sizes_t: 2 x int32 + 15 x uint64; dbg_stats_t: 14 doubles + 4 uint64
-    assert ctypes.sizeof(_dbg.Sizes) == 8 + 15 * 8
+    # dbg_sizes_t: 2 x int32 + 16 x uint64; dbg_stats_t: 14 doubles + 4 uint64
+    assert ctypes.sizeof(_dbg.Sizes) == 8 + 16 * 8
     assert ctypes.sizeof(_dbg.Stats) == 14 * 8 + 4 * 8
 
 
@@ -73,3 +73,8 @@ def test_key_codec_roundtrip():
     for s in ("A", "ACGT", "TTTTGGGGCCCCAAAA", "ACGTACGTACGTACGTACGTACGTACGTACG"):
         key = _dbg.encode_kmer(s)
         assert _dbg.decode_keys(np.array([key], dtype=np.uint64), len(s)) == [s]
+    alpha = b"ACDEFGHIKLMNPQRSTVWY"  # peptides: 5 bits per character, codes in byte order
+    key = 0
+    for ch in b"EVQLV":
+        key = (key << 5) | alpha.index(ch)
+    assert _dbg.decode_keys(np.array([key], dtype=np.uint64), 5, alpha, 5) == ["EVQLV"]

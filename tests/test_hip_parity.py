@@ -65,8 +65,6 @@ def assert_same(got, want, final, tag):
 def test_golden_case(name):
     case = load_golden(name)
     reads = case_reads(case)
-    if not is_dna(reads):
-        pytest.skip("peptide alphabet: not on the device path yet (SURVEY.md 8f-3)")
     inp = case["inputs"]
     got = run_product(reads, inp["k"], inp["threshold"], inp["final"])
     want = run_oracle(reads, inp["k"], inp["threshold"], inp["final"])
@@ -84,38 +82,43 @@ def test_golden_case(name):
         assert_same(got, ref, inp["final"], name + " (reference)")
 
 
-def test_fuzz_family_against_reference_vectors():
-    with open(os.path.join(GOLDEN, "fuzz_small.json")) as fh:
+@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240)])
+def test_fuzz_family_against_reference_vectors(family, n_min):
+    """fuzz_small: sub-alphabets of ACGT (2-bit path); fuzz_peptide: amino acids (generic 5-bit path)."""
+    with open(os.path.join(GOLDEN, family + ".json")) as fh:
         cases = json.load(fh)
     n = 0
     for i, case in enumerate(cases):
         inp = case["inputs"]
-        if not is_dna(inp["reads"]):
-            continue
         got = run_product(inp["reads"], inp["k"], inp["threshold"], inp["final"])
         ref = dict(case["result"])
         ect = dict(map(tuple, ref["edge_count_table"]))
         ref["scores"] = [orc.get_score(ect, c, inp["k"]) for c in ref["contigs"]]
-        assert_same(got, ref, inp["final"], f"fuzz {i} {inp}")
+        assert_same(got, ref, inp["final"], f"{family} {i} {inp}")
         n += 1
-    assert n >= 400
+    assert n >= n_min
 
 
-def test_alphabet_rejected():
-    import debruijn as prod
-    with pytest.raises(ValueError):
-        prod.construct_graph(["ACGTN", "ACGTA"], 3)
-    with pytest.raises(ValueError):
-        prod.construct_graph(["acgtacgt"], 3)
+def test_other_alphabets_take_the_generic_path():
+    """N, lower case, digits ...: distinct characters like in the reference (str slices), never dropped."""
+    for reads, k in ((["ACGTN", "ACGTA", "NNACG"], 3), (["acgtacgt", "ACGTacgt"], 3), (["0120120", "1201"], 2)):
+        got = run_product(reads, k, 2, False)
+        want = run_oracle(reads, k, 2, False)
+        assert_same(got, want, False, str(reads))
 
 
-def test_device_rejects_bad_alphabet_through_abi():
+def test_alphabet_limits_fail_loudly():
     import _dbg
+    import debruijn as prod
+    with pytest.raises(ValueError):      # non-ACGT needs 5 bits per character: k <= 11
+        prod.construct_graph(["EVQLVESGGGLVQPGGSLRL"], 12)
+    with pytest.raises(ValueError):      # more than 32 distinct characters
+        prod.construct_graph(["".join(chr(48 + i) for i in range(40))], 3)
     g = _dbg.Graph()
-    b = np.frombuffer(b"ACGTNACGT", dtype=np.uint8)
-    g.set_reads(b, np.array([0, 9], dtype=np.uint64))
+    b = np.frombuffer(b"ACGTNACGTACGTACGT", dtype=np.uint8)
+    g.set_reads(b, np.array([0, b.size], dtype=np.uint64))
     with pytest.raises(_dbg.AlphabetError):
-        g.build(3)
+        g.build(12)
 
 
 def test_empty_and_degenerate_inputs():
@@ -160,8 +163,8 @@ def test_walk_by_pointer_jumping(name, monkeypatch):
     case = load_golden(name)
     reads = case_reads(case)
     inp = case["inputs"]
-    if not is_dna(reads) or inp["final"]:
-        pytest.skip("DNA, non-final only")
+    if inp["final"]:
+        pytest.skip("non-final only")
     monkeypatch.setenv("DBG_WALK_JUMP_MIN", "0")
     got = run_product(reads, inp["k"], inp["threshold"], False)
     want = run_oracle(reads, inp["k"], inp["threshold"], False)

@@ -38,10 +38,11 @@ def test_oracle_matches_reference_vectors(name):
         assert got[key] == want, f"{name}: digest {key} differs from the reference"
 
 
-def test_oracle_fuzz_family():
-    with open(os.path.join(GOLDEN, "fuzz_small.json")) as fh:
+@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240)])
+def test_oracle_fuzz_family(family, n_min):
+    with open(os.path.join(GOLDEN, family + ".json")) as fh:
         cases = json.load(fh)
-    assert len(cases) >= 400
+    assert len(cases) >= n_min
     for i, case in enumerate(cases):
         inp = case["inputs"]
         res = run_oracle(inp["reads"], inp["k"], inp["threshold"], inp["final"])
