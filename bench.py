@@ -41,6 +41,35 @@ def pmc_traffic(kernel="k_sk_count"):
     return None
 
 
+def extras(g, args, k, L, genome_len):
+    """Untimed extras on the graph the last step built: the rest of the hot path (debruijn.py:150-347) at the
+    same scale, and the same workload without substitution errors.  Not part of `value`."""
+    import _dbg
+    out = {}
+    t = {}
+    for name, fn in (("prune", lambda: g.prune(2)), ("remove_tips", g.remove_tips), ("pull_out_reads", g.mark_pull_reads),
+                     ("walk_index_nonfinal", lambda: g.walk(False, 1 << 20))):
+        t0 = time.perf_counter()
+        fn()
+        t[name] = round((time.perf_counter() - t0) * 1e3, 2)
+    sz = g.sizes()
+    out["rest_of_path_ms"] = t
+    out["rest_of_path_sizes"] = {key: sz[key] for key in ("n_branch", "n_pulled", "tip_rounds", "n_pull_reads", "n_starts",
+                                                          "n_contigs", "contig_chars")}
+    if args.err > 0:
+        g0 = _dbg.Graph(device=int(os.environ.get("LOCAL_RANK", "0")))
+        g0.synth_reads(args.seed, genome_len, args.reads, L, 0.0)
+        g0.build(k)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            g0.build(k)
+        dt = (time.perf_counter() - t0) / 3
+        out["error_free_variant"] = {"value": args.reads * (L - k + 1) / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3,
+                                     "n_nodes": g0.sizes()["n_nodes"]}
+        g0.close()
+    return out
+
+
 def cpu_baseline(seed, genome_len, read_len, k, err, sample_reads):
     """oracle/dbg_oracle.c (single-threaded port of the reference's algorithm) on a bounded sample."""
     import numpy as np
@@ -72,6 +101,7 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=1_500_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--table-hint", type=int, default=0)
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (rest of the path, error-free variant)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -165,6 +195,8 @@ def main():
             "graph": {"n_nodes": sz["n_nodes"], "n_edges": sz["n_edges"], "n_records": st["n_records"],
                       "n_buckets": st["n_buckets"], "n_cross_bucket_successors": st["n_queries"]},
         }
+        if world == 1 and not args.no_extras:
+            out["extras"] = extras(g, args, k, L, genome_len)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed, genome_len, L, k, args.err,
                                                min(args.cpu_sample_reads, args.reads))
