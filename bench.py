@@ -116,7 +116,8 @@ def main():
     import torch
     import _dbg
     dist = None
-    if world > 1:
+    force_sharded = os.environ.get("BENCH_FORCE_SHARDED", "") == "1"  # 1-rank rehearsal of the RCCL path
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         # BENCH_BACKEND=gloo BENCH_SAME_GPU=1: rehearsal of the N>1 path on a one-GPU box (not a measurement)
         backend = os.environ.get("BENCH_BACKEND", "nccl")
@@ -136,7 +137,7 @@ def main():
     g.synth_reads(args.seed, genome_len, args.reads, L, args.err, first_read=rank * args.reads)
 
     def step():
-        if world == 1:
+        if dist is None:
             g.build(k, args.table_hint)
             return g
         return multi_gpu.sharded_build(g, k, dist)
@@ -166,7 +167,7 @@ def main():
 
     sz = built.sizes()
     n_k_rank = args.reads * (L - k + 1)  # k-mer instances this rank's reads hold
-    assert world > 1 or sz["n_kmer_instances"] == n_k_rank, (sz, n_k_rank)
+    assert dist is not None or sz["n_kmer_instances"] == n_k_rank, (sz, n_k_rank)
     n_k_total = n_k_rank * world
     value = n_k_total * args.steps / dt
     mean_count_ms = sum(ms_count) / len(ms_count)
@@ -195,7 +196,7 @@ def main():
             "graph": {"n_nodes": sz["n_nodes"], "n_edges": sz["n_edges"], "n_records": st["n_records"],
                       "n_buckets": st["n_buckets"], "n_cross_bucket_successors": st["n_queries"]},
         }
-        if world == 1 and not args.no_extras:
+        if dist is None and not args.no_extras:
             out["extras"] = extras(g, args, k, L, genome_len)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.seed, genome_len, L, k, args.err,

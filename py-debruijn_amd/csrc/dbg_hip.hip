@@ -2316,7 +2316,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
         SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_succ, node_cap,
                        h->d_rowptr, h->d_col, h->d_ecnt, edge_cap, qk[0], qm[0], qc[0], q_cap,
-                       ranges, n_buckets, range_cap, sc_dev};
+                       ranges, n_buckets, range_cap, shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev};
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2402,7 +2402,8 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             const size_t lds = sizeof(AnsLds<CAP>);
             HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt,
-                               qk2[qwhere], qm2[qwhere], qc2[qwhere], h->d_keys, h->d_succ, h->d_col, sc_dev);
+                               qk2[qwhere], qm2[qwhere], qc2[qwhere], h->d_keys, h->d_succ, h->d_col,
+                               shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -2627,7 +2628,7 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     const size_t lds = sizeof(AnsLds<4096>);
     HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)h->sk_n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt, qk[qwhere],
-                       qm[qwhere], (const uint32_t *)nullptr, h->d_keys, (uint32_t *)d_answers, (uint32_t *)nullptr, sc_dev);
+                       qm[qwhere], (const uint32_t *)nullptr, h->d_keys, (uint32_t *)d_answers, (uint32_t *)nullptr, 0u, sc_dev);
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;
     HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -2642,13 +2643,7 @@ extern "C" int dbg_shard_apply(dbg_t *h, const void *d_answers) {
     ShardState &sh = shard_of(h);
     Timer t(h->stream);
     HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-    if (h->n_nodes) {
-        hipLaunchKernelGGL(k_tag_local, dim3(grid_for(h->n_nodes * 4, 256)), dim3(256), 0, h->stream, h->d_succ,
-                           h->n_nodes * 4, (uint32_t)sh.my_shard << 29);
-        if (h->n_edges)
-            hipLaunchKernelGGL(k_tag_local, dim3(grid_for(h->n_edges, 256)), dim3(256), 0, h->stream, h->d_col, h->n_edges,
-                               (uint32_t)sh.my_shard << 29);
-    }
+    // local successor ids already carry this shard's tag (k_sk_count / k_q_answer wrote them tagged)
     const uint64_t *meta = (const uint64_t *)h->ar_shard[1].p;
     const uint32_t *qcol = (const uint32_t *)h->ar_shard[3].p;
     for (int d = 0; d < sh.n_shards; ++d) {

@@ -671,6 +671,7 @@ struct SkCountOut {
     SkRange *ranges;        // [0, n_buckets): the unsplit range of each bucket; beyond: ranges of split buckets
     uint64_t n_buckets;
     uint64_t range_cap;
+    uint32_t id_tag;           // OR-ed into every successor id written (sharded builds: owner << 29)
     unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | edges (high 32) [5] queries [6] extra ranges
 };
 
@@ -988,7 +989,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
-                    sc[b] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
+                    sc[b] = v < 0x8000u ? ((uint32_t)(gbase + v) | out.id_tag) : NO_NODE;
                     if (c[b]) {
                         out.col[e] = sc[b];
                         out.ecnt[e] = c[b];
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ra
                                                   const uint64_t *__restrict__ q_cnt, const uint64_t *__restrict__ q_key,
                                                   const uint64_t *__restrict__ q_meta, const uint32_t *__restrict__ q_col,
                                                   const uint64_t *__restrict__ keys, uint32_t *succ, uint32_t *col,
-                                                  unsigned long long *scalars) {
+                                                  uint32_t id_tag, unsigned long long *scalars) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ans_raw[];
     AnsLds<CAP> &s = *reinterpret_cast<AnsLds<CAP> *>(ans_raw);
     const SkRange rg = ranges[blockIdx.x];
@@ -1081,7 +1082,7 @@ __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ra
         if (rg.mask && (sub_hash(skey) & rg.mask) != rg.val) continue;
         const int f = lds_find<CAP>(s.keys, skey);
         if (f < 0) { atomicOr(&scalars[0], 128ull); continue; }  // every successor exists as a node
-        const uint32_t id = (uint32_t)(rg.node_base + s.idx[f]);
+        const uint32_t id = (uint32_t)(rg.node_base + s.idx[f]) | id_tag;
         succ[q_meta[qb + i] & ((1ull << 40) - 1)] = id;
         if (col) col[q_col[qb + i]] = id;
     }
