@@ -198,7 +198,7 @@ def main():
         }
         if dist is None and not args.no_extras:
             out["extras"] = extras(g, args, k, L, genome_len)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args.seed, genome_len, L, k, args.err,
                                                min(args.cpu_sample_reads, args.reads))
         print(json.dumps(out), flush=True)

@@ -71,3 +71,35 @@ def test_full_size_invariants(err):
     a, b = np.argsort(keys), np.argsort(keys2)
     assert np.array_equal(keys[a], keys2[b]) and np.array_equal(stamps[a], stamps2[b])
     assert np.array_equal(counts[a], counts2[b])
+
+
+def test_reads_beyond_2_gib_use_64bit_stamps():
+    """15M x 150 bp = 2.25 GB of reads: byte offsets no longer fit the 32-bit stamp, the build switches to
+    64-bit stamps (smaller LDS staging); same invariants as at the BASELINE size."""
+    n, L, k, G = 15_000_000, 150, 31, 75_000_000
+    g = _dbg.Graph()
+    g.synth_reads(1, G, n, L, 0.0)
+    assert g.sizes()["n_bytes"] >= 1 << 31
+    g.build(k)
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == n * (L - k + 1) and sz["n_edge_instances"] == n * (L - k)
+    keys, stamps, counts, flags = g.export_nodes()
+    assert int(counts.sum(dtype=np.uint64)) == sz["n_edge_instances"]
+    assert np.unique(keys).size == keys.size and sz["n_nodes"] <= G - k + 1
+    pos = stamps >> np.uint64(1)
+    # (a 32-bit stamp would wrap for offsets >= 2^31 and win the min: the re-encoding check below would fail)
+    assert np.array_equal((stamps & np.uint64(1)) == 0, pos % np.uint64(L) == 0)
+    rp, col, cnt = g.export_csr()
+    assert int(rp[-1]) == sz["n_edges"] == int((counts != 0).sum())
+    succ = g.export_succ()
+    assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for c in range(4):
+        has = counts[:, c] != 0
+        assert np.array_equal(keys[succ[has, c]], ((keys[has] << np.uint64(2)) | np.uint64(c)) & mask)
+    # first occurrences re-encoded from the reads
+    reads, _ = g.copy_reads()
+    idx = np.linspace(0, keys.size - 1, 20000).astype(np.int64)
+    code = ((reads[(pos[idx][:, None] + np.arange(k, dtype=np.uint64)[None, :]).astype(np.int64)] >> 1) & 3).astype(np.uint64)
+    shifts = (2 * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
+    assert np.array_equal((code << shifts[None, :]).sum(axis=1, dtype=np.uint64), keys[idx])
