@@ -778,13 +778,42 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                         s.st_stage[r] = rec_st[r_beg + c0 + r];
                     }
                 }
+                // dedupe scratch (idx[] / list[] are free until the table is final): hash set of record indices
+                // and the multiplicity of every representative
+                uint32_t *dd_tab = reinterpret_cast<uint32_t *>(s.idx);    // DD_SLOTS entries
+                uint32_t *dd_mult = reinterpret_cast<uint32_t *>(s.list);  // STAGE entries
+                constexpr uint32_t DD_SLOTS = CAP / 2;                      // sizeof(idx) / 4; >= 2 * STAGE
+                static_assert(DD_SLOTS >= 2 * STAGE && CAP / 2 >= STAGE, "dedupe scratch");
+                for (uint32_t i = threadIdx.x; i < DD_SLOTS; i += CNT_NT) dd_tab[i] = 0xFFFFFFFFu;
+                for (uint32_t i = threadIdx.x; i < n_st; i += CNT_NT) dd_mult[i] = 0;
                 __syncthreads();
                 if (phase_limit == 1) { skip_rest = true; break; }  // clear + stage
                 if (s.overflow) break;  // uniform: read after the barrier
-                {  // quad list (STAGE <= CNT_NT: one record per thread)
+                // ---- identical records (same window of the genome seen by several reads) collapse to one
+                //      representative with a multiplicity and the smallest stamp: at 30x coverage this is
+                //      most of the error-free data, so the per-k-mer table work drops by about that factor
+                if (threadIdx.x < n_st) {
+                    const uint32_t r = threadIdx.x;
+                    const unsigned long long w0 = s.q_key[r], w1 = s.q_meta[r];
+                    uint32_t hslot = fmix32(fold32(w0) ^ (fold32(w1) * 0x9E3779B1u)) & (DD_SLOTS - 1);
+                    uint32_t rep = r;
+                    for (uint32_t probe = 0; probe < DD_SLOTS; ++probe) {
+                        uint32_t cur = dd_tab[hslot];
+                        if (cur == 0xFFFFFFFFu) {
+                            cur = atomicCAS(&dd_tab[hslot], 0xFFFFFFFFu, r);
+                            if (cur == 0xFFFFFFFFu) break;  // r is the representative
+                        }
+                        if (s.q_key[cur] == w0 && s.q_meta[cur] == w1) { rep = cur; break; }
+                        hslot = (hslot + 1) & (DD_SLOTS - 1);
+                    }
+                    atomicAdd(&dd_mult[rep], 1u);
+                    if (rep != r) atomicMin(&s.st_stage[rep], s.st_stage[r]);
+                }
+                __syncthreads();
+                {  // quad list of the representatives (STAGE <= CNT_NT: one record per thread)
                     const uint32_t r = threadIdx.x;
                     uint32_t nquad = 0;
-                    if (r < n_st) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
+                    if (r < n_st && dd_mult[r]) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
                     const uint32_t base = wave_alloc_n(&s.n_flat, nquad);
                     for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
                 }
@@ -798,6 +827,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     const int len = (int)((w1 >> 1) & 31) + 1;
                     if (i >= len) continue;
                     const ST st0 = s.st_stage[r];
+                    const uint32_t mult = dd_mult[r];
                     const uint64_t hi = w1 & (~0ull << SK_META_BITS);
                     const uint32_t hs = (uint32_t)(w1 & 1);
                     const uint64_t win = rec_window(w0, hi, i);
@@ -818,7 +848,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                         slot = (slot + 1) & (CAP - 1);
                     }
                     if (!ok) { s.overflow = 1; continue; }
-                    if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], 1u);
+                    if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], mult);
                     atomicMin(&s.stamp[slot], stamp);
                 }
             }
