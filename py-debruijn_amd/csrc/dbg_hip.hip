@@ -105,7 +105,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[2];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -1163,6 +1163,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_misc) buf_free(b);
     for (auto &b : h->ar_csr) buf_free(b);
     for (auto &b : h->ar_shard) buf_free(b);
+    for (auto &b : h->ar_walk) buf_free(b);
     buf_free(h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
@@ -1826,7 +1827,8 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     Jump *jump[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
         dev_free(starts); dev_free(per_ctg); dev_free(per_chr); dev_free(base_ctg); dev_free(base_chr);
-        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score); dev_free(jump[0]); dev_free(jump[1]);
+        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score);
+        jump[0] = jump[1] = nullptr;  // arena-owned
     };
     int rc = DBG_OK;
     do {
@@ -1866,8 +1868,11 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
         };
         if (use_jump) {
             if ((rc = dev_alloc(h, &per_score, ns)) != DBG_OK) break;
-            if ((rc = dev_alloc(h, &jump[0], h->n_nodes)) != DBG_OK) break;
-            if ((rc = dev_alloc(h, &jump[1], h->n_nodes)) != DBG_OK) break;
+            // 24 B per node each: kept in the arena (a fresh 17 GB hipMalloc costs ~0.5 s at the BASELINE size)
+            if ((rc = buf_ensure(h, h->ar_walk[0], h->n_nodes * sizeof(Jump))) != DBG_OK) break;
+            if ((rc = buf_ensure(h, h->ar_walk[1], h->n_nodes * sizeof(Jump))) != DBG_OK) break;
+            jump[0] = (Jump *)h->ar_walk[0].p;
+            jump[1] = (Jump *)h->ar_walk[1].p;
             const dim3 grid(grid_for(h->n_nodes, 256));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_jump_init<G>), grid, dim3(256), 0, h->stream, h->n_nodes, g, jump[0]);
             int cur = 0, max_rounds = 2;
@@ -1882,8 +1887,7 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
             if (rc != DBG_OK) break;
             hipLaunchKernelGGL(k_jump_starts, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, jump[cur],
                                h->d_flags, h->k, per_ctg, per_chr, per_score);
-            dev_free(jump[0]);  // 24 B per node each: give them back before the text is allocated
-            dev_free(jump[1]);
+            jump[0] = jump[1] = nullptr;  // arena-owned
         } else {
             launch(0);
         }
