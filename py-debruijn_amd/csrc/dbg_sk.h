@@ -687,21 +687,28 @@ __device__ inline uint32_t wave_alloc(uint32_t *counter, bool pred) {
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
 }
 
-// same for n items per lane: returns the index of the lane's first item
+// lanes below this one that are set in a ballot mask
+__device__ inline uint32_t lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// same for n <= NMAX items per lane: returns the index of the lane's first item.  The prefix sum is
+// NMAX ballots + mbcnt (scalar/VALU only) instead of a six-step cross-lane scan through the LDS crossbar.
+// Must be called with the wave converged.
+template <int NMAX>
 __device__ inline uint32_t wave_alloc_n(uint32_t *counter, uint32_t n) {
-    const int lane = threadIdx.x & 63;
-    uint32_t inc = n;
+    uint32_t excl = 0, total = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
+    for (int j = 1; j <= NMAX; ++j) {
+        const unsigned long long mj = __ballot(n >= (uint32_t)j);
+        if (j == 1 && !mj) return 0;
+        excl += lanes_below(mj);
+        total += (uint32_t)__popcll(mj);
     }
-    const uint32_t total = __shfl(inc, 63, 64);
-    if (!total) return 0;
     uint32_t base = 0;
-    if (lane == 63) base = atomicAdd(counter, total);
-    base = __shfl(base, 63, 64);
-    return base + inc - n;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+    return base + excl;
 }
 
 template <class ST, int CAP>
@@ -729,13 +736,16 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
     bool clean = false;  // uniform: every slot of the table is EMPTY / zero / max
     uint64_t pf_w0 = 0, pf_w1 = 0;
     ST pf_st = 0;
+    uint64_t nx_beg = 0, nx_n = 0;  // record range of the prefetched bucket (uniform)
     auto prefetch = [&](uint64_t bucket) {
+        nx_n = 0;
         if (bucket < n_buckets) {
-            const uint64_t beg = b_start[bucket], n = b_cnt[bucket];
-            if (threadIdx.x < min(n, (uint64_t)STAGE)) {
-                pf_w0 = rec_w0[beg + threadIdx.x];
-                pf_w1 = rec_w1[beg + threadIdx.x];
-                pf_st = rec_st[beg + threadIdx.x];
+            nx_beg = b_start[bucket];
+            nx_n = b_cnt[bucket];
+            if (threadIdx.x < min(nx_n, (uint64_t)STAGE)) {
+                pf_w0 = rec_w0[nx_beg + threadIdx.x];
+                pf_w1 = rec_w1[nx_beg + threadIdx.x];
+                pf_st = rec_st[nx_beg + threadIdx.x];
             }
         }
     };
@@ -743,17 +753,20 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
     prefetch(blockIdx.x);
 
     for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
-        const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
+        const uint64_t r_beg = nx_beg, r_n = nx_n;  // loaded with the prefetch: no exposed global latency here
         if (r_n == 0) { prefetch(bucket + gridDim.x); continue; }
         bool have_prefetch = true;  // registers hold the first STAGE records of this bucket
         bool skip_rest = false;     // ablation exit
-        __syncthreads();
-        if (threadIdx.x == 0) { s.stk_n = 1; s.stk_mask[0] = 0; s.stk_val[0] = 0; }
-        while (true) {
-            __syncthreads();
-            if (s.stk_n == 0 || s.fail) break;
-            const uint32_t cur_mask = s.stk_mask[s.stk_n - 1], cur_val = s.stk_val[s.stk_n - 1];
-            __syncthreads();
+        // The stack of hash sub-ranges still to count lives in registers (uniform) + LDS for its entries; the
+        // common case (the whole bucket fits the table) never touches LDS for it.
+        uint32_t stk_n = 1;
+        bool root = true, failed = false;
+        while (stk_n) {
+            uint32_t cur_mask = 0, cur_val = 0;
+            --stk_n;
+            if (!root) { cur_mask = s.stk_mask[stk_n]; cur_val = s.stk_val[stk_n]; }
+            root = false;
+            __syncthreads();  // the previous pass (or bucket) is done with the staging arrays and the table
             if (!clean) {
                 for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
                     s.keys[i] = EMPTY_KEY;
@@ -762,7 +775,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 }
             }
             clean = false;
-            if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; --s.stk_n; }
+            if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; }
             // ---- insert: records are staged in LDS (first chunk: from the prefetch registers), work
             //      items are "quads" (record, 4 consecutive k-mers) listed densely, 4 lanes per quad
             for (uint64_t c0 = 0; c0 < r_n; c0 += STAGE) {
@@ -814,7 +827,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     const uint32_t r = threadIdx.x;
                     uint32_t nquad = 0;
                     if (r < n_st && dd_mult[r]) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
-                    const uint32_t base = wave_alloc_n(&s.n_flat, nquad);
+                    const uint32_t base = wave_alloc_n<8>(&s.n_flat, nquad);
                     for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
                 }
                 __syncthreads();
@@ -860,16 +873,18 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             }
             if (phase_limit == 2) { skip_rest = true; break; }  // + insert
             if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
-                if (threadIdx.x == 0) {
-                    const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
-                    if (s.stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
-                        atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
-                        s.fail = 1;
-                    } else {
-                        s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val; ++s.stk_n;
-                        s.stk_mask[s.stk_n] = cur_mask | bit; s.stk_val[s.stk_n] = cur_val | bit; ++s.stk_n;
-                    }
+                const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
+                if (stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
+                    if (threadIdx.x == 0) atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
+                    failed = true;
+                    break;
                 }
+                if (threadIdx.x == 0) {
+                    s.stk_mask[stk_n] = cur_mask | bit; s.stk_val[stk_n] = cur_val;
+                    s.stk_mask[stk_n + 1] = cur_mask | bit; s.stk_val[stk_n + 1] = cur_val | bit;
+                }
+                stk_n += 2;
+                __syncthreads();  // entries visible to every thread's pop
                 continue;
             }
             // ---- dense list of occupied slots + CSR edge offsets: one packed LDS atomic per wave hands out a
@@ -883,22 +898,22 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 }
                 const unsigned long long mask = __ballot(occ);
                 if (mask) {
-                    const int lane = threadIdx.x & 63;
-                    uint32_t einc = deg;
+                    // exclusive prefix of deg (0..4) over the wave: four ballots, no cross-lane scan
+                    uint32_t eexc = 0, etot = 0;
 #pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) {
-                        const uint32_t o = __shfl_up(einc, d, 64);
-                        if (lane >= d) einc += o;
+                    for (int j = 1; j <= 4; ++j) {
+                        const unsigned long long mj = __ballot(deg >= (uint32_t)j);
+                        eexc += lanes_below(mj);
+                        etot += (uint32_t)__popcll(mj);
                     }
-                    const uint32_t etot = __shfl(einc, 63, 64);
                     uint32_t base = 0;
-                    if (lane == 63) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
-                    base = __shfl(base, 63, 64);
+                    if ((threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
+                    base = __builtin_amdgcn_readfirstlane(base);
                     if (occ) {
-                        const uint32_t li = (base & 0xFFFFu) + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+                        const uint32_t li = (base & 0xFFFFu) + lanes_below(mask);
                         s.idx[i] = (uint16_t)li;
                         s.list[li] = (uint16_t)i;
-                        s.eoff[li] = (uint16_t)((base >> 16) + einc - deg);
+                        s.eoff[li] = (uint16_t)((base >> 16) + eexc);
                     }
                 }
             }
@@ -937,7 +952,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     if (f >= 0) nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)s.idx[f] << (16 * b));
                     else missmask |= 1u << b;
                 }
-                uint32_t qi = wave_alloc_n(&s.n_q, (uint32_t)__popc(missmask));
+                uint32_t qi = wave_alloc_n<4>(&s.n_q, (uint32_t)__popc(missmask));
                 while (missmask) {
                     const uint32_t b = __ffs(missmask) - 1;
                     missmask &= missmask - 1;
@@ -1067,8 +1082,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             }
             clean = true;  // every occupied slot was reset above (uniform: all waves pass here)
         }
-        __syncthreads();
-        if (s.fail) return;
+        if (failed || s.fail) return;  // s.fail was written before the last barrier every thread passed
         if (skip_rest) { clean = false; if (have_prefetch) prefetch(bucket + gridDim.x); }
     }
 }
