@@ -130,7 +130,10 @@ int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets); /* D2H of the curr
 /* ---- a3 + a4: get_graph_from_reads (debruijn.py:98-147) + edge-count table (:213-222)
  *      -> node table, 4-way successor edges, CSR ------------------------------------ */
 /* table_capacity_hint: 0 = size for the worst case (every k-mer instance distinct);
- * otherwise a slot count (rounded up to a power of two); DBG_E_CAPACITY if too small. */
+ * otherwise a slot count (rounded up to a power of two); DBG_E_CAPACITY if too small.
+ * k: 1..63 for reads over ACGT (k <= 31: one 64-bit word per k-mer, the partitioned engine;
+ * 32..63: two words per k-mer, a reference-keyed global table -- BASELINE.json configs[4]);
+ * 1..11 for any other alphabet of at most 32 distinct bytes (5 bits per character). */
 int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint);
 
 /* ---- exact successor order (Counter semantics of debruijn.py:159-165 and :215-216): finds the first
@@ -168,6 +171,9 @@ int dbg_get_stats(dbg_t *h, dbg_stats_t *out);
 /* ---- exports: two-call pattern, sizes from dbg_get_sizes; NULL pointers are skipped */
 /* keys[n_nodes], stamps[n_nodes], counts[n_nodes*4] (by base code), flags[n_nodes]; table order */
 int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint32_t *counts, uint8_t *flags);
+/* k > 31: a k-mer is the 2k-bit number keys_hi[i] * 2^64 + keys[i] (first base in the top bit pair);
+ * keys_hi[n_nodes] is all zero for k <= 31. */
+int dbg_export_keys_hi(dbg_t *h, uint64_t *keys_hi);
 /* succ[n_nodes*4]: node id of successor by base code or DBG_NO_NODE */
 int dbg_export_succ(dbg_t *h, uint32_t *succ);
 /* CSR over distinct edges: row_ptr[n_nodes+1], col[n_edges], cnt[n_edges] */

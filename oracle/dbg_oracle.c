@@ -17,11 +17,13 @@
  * oracle/dbg_oracle.py, which is itself pinned by the reference's vectors.
  *
  * Base code = (ascii >> 1) & 3 (A=0 C=1 T=2 G=3), same packing as include/dbg.h.
- * Single-threaded, plain C, open-addressing table.
+ * Single-threaded, plain C, open-addressing table; k <= 31 in one 64-bit word, 32..63 in unsigned __int128.
  */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+
+typedef unsigned __int128 orc_u128; /* k in 32..63: a k-mer is up to 126 bits */
 
 typedef struct {
     uint64_t key;
@@ -30,7 +32,15 @@ typedef struct {
 } orc_slot;
 
 typedef struct {
-    orc_slot *tab;
+    orc_u128 key;
+    uint64_t stamp;
+    uint32_t cnt[4];
+    uint64_t pad_;
+} orc_wslot;
+
+typedef struct {
+    orc_slot *tab;   /* k <= 31 */
+    orc_wslot *wtab; /* k >= 32 */
     uint64_t cap, n_nodes, n_kmer_inst, n_edge_inst;
     int k;
 } orc_t;
@@ -41,16 +51,58 @@ static uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     return x;
 }
+static uint64_t hash_narrow(uint64_t key) { return mix64(key); }
+static uint64_t hash_wide(orc_u128 key) { return mix64((uint64_t)key ^ mix64((uint64_t)(key >> 64) + 0x9E3779B97F4A7C15ULL)); }
 
 void orc_free(orc_t *o) {
     if (!o) return;
     free(o->tab);
+    free(o->wtab);
     free(o);
 }
 
-/* returns NULL on bad input (k outside 1..31, byte outside ACGT, allocation failure) */
+/* The scan of debruijn.py:126-143 over one key width.  Returns 0, or -1 on a byte outside ACGT. */
+#define ORC_DEFINE_SCAN(NAME, KEY_T, SLOT_T, TAB, HASH)                                                     \
+    static int NAME(orc_t *o, const char *bases, const uint64_t *offsets, uint64_t n_reads) {               \
+        const int k = o->k;                                                                                  \
+        const uint64_t mask = o->cap - 1;                                                                    \
+        const KEY_T empty = ~(KEY_T)0, kmask = (((KEY_T)1) << (2 * k)) - 1;                                  \
+        SLOT_T *tab = o->TAB;                                                                                \
+        for (uint64_t r = 0; r < n_reads; ++r) {                                                             \
+            const uint64_t beg = offsets[r], len = offsets[r + 1] - beg;                                     \
+            if (len <= (uint64_t)k) continue; /* debruijn.py:126 */                                          \
+            const unsigned char *s = (const unsigned char *)bases + beg;                                     \
+            KEY_T key = 0;                                                                                   \
+            for (uint64_t i = 0; i <= len; ++i) {                                                            \
+                const unsigned char c = i < len ? s[i] : 0;                                                  \
+                if (i < len && c != 'A' && c != 'C' && c != 'G' && c != 'T') return -1;                      \
+                if (i >= (uint64_t)k) {                                                                      \
+                    /* window [i-k, i) is complete in `key`; s[i] is its successor base (none at i == len) */\
+                    const uint64_t pos = i - k;                                                              \
+                    uint64_t h = HASH(key) & mask;                                                           \
+                    while (tab[h].key != empty && tab[h].key != key) h = (h + 1) & mask;                     \
+                    SLOT_T *e = &tab[h];                                                                     \
+                    if (e->key == empty) {                                                                   \
+                        e->key = key;                                                                        \
+                        e->stamp = ((beg + pos) << 1) | (pos != 0);                                          \
+                        e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;                                   \
+                        o->n_nodes++;                                                                        \
+                    }                                                                                        \
+                    o->n_kmer_inst++;                                                                        \
+                    if (i < len) { e->cnt[(c >> 1) & 3]++; o->n_edge_inst++; }                               \
+                }                                                                                            \
+                key = ((key << 2) | ((c >> 1) & 3)) & kmask;                                                 \
+            }                                                                                                \
+        }                                                                                                    \
+        return 0;                                                                                            \
+    }
+
+ORC_DEFINE_SCAN(scan_narrow, uint64_t, orc_slot, tab, hash_narrow)
+ORC_DEFINE_SCAN(scan_wide, orc_u128, orc_wslot, wtab, hash_wide)
+
+/* returns NULL on bad input (k outside 1..63, byte outside ACGT, allocation failure) */
 orc_t *orc_build(const char *bases, const uint64_t *offsets, uint64_t n_reads, int k) {
-    if (k < 1 || k > 31) return NULL;
+    if (k < 1 || k > 63) return NULL;
     uint64_t windows = 0;
     for (uint64_t r = 0; r < n_reads; ++r) {
         uint64_t len = offsets[r + 1] - offsets[r];
@@ -61,50 +113,19 @@ orc_t *orc_build(const char *bases, const uint64_t *offsets, uint64_t n_reads, i
     o->k = k;
     o->cap = 1024;
     while (o->cap < windows * 2) o->cap <<= 1;
-    o->tab = (orc_slot *)malloc(o->cap * sizeof(orc_slot));
-    if (!o->tab) { free(o); return NULL; }
-    memset(o->tab, 0xFF, o->cap * sizeof(orc_slot));
-    const uint64_t mask = o->cap - 1, kmask = (1ULL << (2 * k)) - 1;
-    for (uint64_t r = 0; r < n_reads; ++r) {
-        const uint64_t beg = offsets[r], len = offsets[r + 1] - beg;
-        if (len <= (uint64_t)k) continue; /* debruijn.py:126 */
-        const unsigned char *s = (const unsigned char *)bases + beg;
-        uint64_t key = 0;
-        for (uint64_t i = 0; i < len; ++i) {
-            const unsigned char c = s[i];
-            if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { orc_free(o); return NULL; }
-            if (i >= (uint64_t)k) {
-                /* window [i-k, i) is complete in `key`; s[i] is its successor base */
-                const uint64_t pos = i - k;
-                uint64_t h = mix64(key) & mask;
-                while (o->tab[h].key != ~0ULL && o->tab[h].key != key) h = (h + 1) & mask;
-                orc_slot *e = &o->tab[h];
-                if (e->key == ~0ULL) {
-                    e->key = key;
-                    e->stamp = ((beg + pos) << 1) | (pos != 0);
-                    e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;
-                    o->n_nodes++;
-                }
-                e->cnt[(c >> 1) & 3]++;
-                o->n_kmer_inst++;
-                o->n_edge_inst++;
-            }
-            key = ((key << 2) | ((c >> 1) & 3)) & kmask;
-        }
-        { /* read-final window: vertex occurrence without a successor */
-            const uint64_t pos = len - k;
-            uint64_t h = mix64(key) & mask;
-            while (o->tab[h].key != ~0ULL && o->tab[h].key != key) h = (h + 1) & mask;
-            orc_slot *e = &o->tab[h];
-            if (e->key == ~0ULL) {
-                e->key = key;
-                e->stamp = ((beg + pos) << 1) | (pos != 0);
-                e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;
-                o->n_nodes++;
-            }
-            o->n_kmer_inst++;
-        }
+    int rc;
+    if (k <= 31) {
+        o->tab = (orc_slot *)malloc(o->cap * sizeof(orc_slot));
+        if (!o->tab) { free(o); return NULL; }
+        memset(o->tab, 0xFF, o->cap * sizeof(orc_slot));
+        rc = scan_narrow(o, bases, offsets, n_reads);
+    } else {
+        o->wtab = (orc_wslot *)malloc(o->cap * sizeof(orc_wslot));
+        if (!o->wtab) { free(o); return NULL; }
+        memset(o->wtab, 0xFF, o->cap * sizeof(orc_wslot));
+        rc = scan_wide(o, bases, offsets, n_reads);
     }
+    if (rc) { orc_free(o); return NULL; }
     return o;
 }
 
@@ -113,23 +134,37 @@ uint64_t orc_n_kmer_instances(const orc_t *o) { return o->n_kmer_inst; }
 uint64_t orc_n_edge_instances(const orc_t *o) { return o->n_edge_inst; }
 
 static int cmp_stamp(const void *a, const void *b) {
-    const uint64_t x = ((const orc_slot *)a)->stamp, y = ((const orc_slot *)b)->stamp;
+    const uint64_t x = ((const orc_wslot *)a)->stamp, y = ((const orc_wslot *)b)->stamp;
     return x < y ? -1 : x > y;
 }
 
-/* nodes in first-occurrence (dict) order; arrays sized orc_n_nodes (counts: n*4, by base code) */
-int orc_export(const orc_t *o, uint64_t *keys, uint64_t *stamps, uint32_t *counts) {
-    orc_slot *tmp = (orc_slot *)malloc((o->n_nodes ? o->n_nodes : 1) * sizeof(orc_slot));
+/* nodes in first-occurrence (dict) order; arrays sized orc_n_nodes (counts: n*4, by base code).
+ * keys: low 64 bits of the k-mer; keys_hi (may be NULL): bits 64.. (zero for k <= 32). */
+int orc_export2(const orc_t *o, uint64_t *keys, uint64_t *keys_hi, uint64_t *stamps, uint32_t *counts) {
+    orc_wslot *tmp = (orc_wslot *)malloc((o->n_nodes ? o->n_nodes : 1) * sizeof(orc_wslot));
     if (!tmp) return -1;
     uint64_t n = 0;
-    for (uint64_t i = 0; i < o->cap; ++i)
-        if (o->tab[i].key != ~0ULL) tmp[n++] = o->tab[i];
-    qsort(tmp, n, sizeof(orc_slot), cmp_stamp);
+    for (uint64_t i = 0; i < o->cap; ++i) {
+        if (o->tab && o->tab[i].key != ~0ULL) {
+            tmp[n].key = o->tab[i].key;
+            tmp[n].stamp = o->tab[i].stamp;
+            memcpy(tmp[n].cnt, o->tab[i].cnt, 16);
+            ++n;
+        } else if (o->wtab && o->wtab[i].key != ~(orc_u128)0) {
+            tmp[n++] = o->wtab[i];
+        }
+    }
+    qsort(tmp, n, sizeof(orc_wslot), cmp_stamp);
     for (uint64_t i = 0; i < n; ++i) {
-        if (keys) keys[i] = tmp[i].key;
+        if (keys) keys[i] = (uint64_t)tmp[i].key;
+        if (keys_hi) keys_hi[i] = (uint64_t)(tmp[i].key >> 64);
         if (stamps) stamps[i] = tmp[i].stamp;
         if (counts) memcpy(counts + 4 * i, tmp[i].cnt, 16);
     }
     free(tmp);
     return 0;
+}
+
+int orc_export(const orc_t *o, uint64_t *keys, uint64_t *stamps, uint32_t *counts) {
+    return orc_export2(o, keys, NULL, stamps, counts);
 }

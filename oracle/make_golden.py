@@ -169,6 +169,64 @@ def dna_case(name, seed, G, n, L, err, k, threshold, final, full):
     emit(name, inputs, res, full)
 
 
+def main_wide():
+    """k in 32..63 (two-word k-mers on the device, BASELINE.json configs[4]): `make_golden.py wide`."""
+    os.makedirs(GOLDEN, exist_ok=True)
+    dna_case("dna_small_k33_e1_t2", 41, 400, 90, 70, 0.02, 33, 2, False, True)
+    dna_case("dna_small_k40_e1_t3_final", 42, 300, 60, 80, 0.02, 40, 3, True, True)
+    dna_case("dna_med_k32_e1_t3", 43, 6000, 600, 120, 0.01, 32, 3, False, False)
+    dna_case("dna_med_k47_e0_t2", 44, 6000, 600, 120, 0.0, 47, 2, False, False)
+    dna_case("dna_med_k63_e1_t2", 45, 8000, 700, 150, 0.01, 63, 2, False, False)
+    dna_case("dna_med_k63_e2_t2_final", 46, 3000, 200, 150, 0.003, 63, 2, True, False)
+    reads = synth.reads_list(47, 1500, 160, 90, 0.01)
+    res = run_reference_driver(reads, 30, 34, 2)  # crosses the one-word / two-word boundary
+    with open(os.path.join(GOLDEN, "driver_dna_k30_34.json"), "w") as fh:
+        json.dump({"name": "driver_dna_k30_34",
+                   "inputs": {"reads": reads, "k_lowerlimit": 30, "k_upperlimit": 34, "threshold": 2},
+                   "result": res}, fh, separators=(",", ":"))
+    print("driver_dna_k30_34", len(res["final_contigs"]))
+
+    # randomized cases with repeats longer than k (branches), errors near read ends (tips), tandem repeats (cycles)
+    import random
+    rng = random.Random(20260412)
+    fuzz = []
+    for i in range(160):
+        alpha = rng.choice(["ACGT", "ACGT", "ACG", "AC"])
+        k = rng.choice([32, 33, 40, 47, 48, 56, 62, 63, rng.randint(32, 63)])
+        rnd = lambda n: "".join(rng.choice(alpha) for _ in range(n))
+        kind = rng.random()
+        if kind < 0.45:    # a block longer than k occurs twice with different continuations
+            R = rnd(k + rng.randint(1, 30))
+            G = rnd(rng.randint(5, 40)) + R + rnd(rng.randint(5, 50)) + R + rnd(rng.randint(5, 40))
+        elif kind < 0.65:  # tandem repeat: the k-mers close a cycle
+            unit = rnd(rng.randint(3, 20))
+            G = rnd(rng.randint(0, 10)) + unit * ((k + 40) // len(unit) + 2) + rnd(rng.randint(0, 10))
+        else:
+            G = rnd(rng.randint(k + 5, k + 120))
+        reads = []
+        for _ in range(rng.randint(1, 18)):
+            L = rng.randint(max(1, k - 3), min(len(G), k + 45))
+            st = rng.randint(0, len(G) - L)
+            r = list(G[st:st + L])
+            if rng.random() < 0.45:   # substitution, often within the last few bases (a tip)
+                j = L - 1 - rng.randint(0, 5) if rng.random() < 0.6 else rng.randrange(L)
+                r[max(j, 0)] = rng.choice(alpha)
+            reads.append("".join(r))
+        if rng.random() < 0.3:
+            reads += reads[:rng.randint(1, 3)]  # duplicates raise counts: pruning thresholds matter
+        thr = rng.choice([1, 2, 2, 3, 3, 5])
+        final = rng.random() < 0.4
+        res = run_reference(reads, k, thr, final)
+        fuzz.append({"inputs": {"reads": reads, "k": k, "threshold": thr, "final": final}, "result": res})
+    with open(os.path.join(GOLDEN, "fuzz_wide.json"), "w") as fh:
+        json.dump(fuzz, fh, separators=(",", ":"))
+    print("fuzz_wide:", len(fuzz), "cases;",
+          sum(1 for c in fuzz if c["result"]["already_pull_out"]), "with pulled tips;",
+          sum(1 for c in fuzz if c["result"]["branch_kmer"]), "with branches;",
+          sum(1 for c in fuzz if c["result"]["contigs"]), "with contigs;",
+          sum(1 for c in fuzz if c["result"]["vertices"] and not c["result"]["contigs"]), "with vertices but no contig")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     pep = ['EVQLVE', 'QLVAPG', 'LVESGGAL', 'LVESGGGL']  # II_assembleFromReads.py:55 (input only)
@@ -304,4 +362,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["wide"]:
+        main_wide()
+    else:
+        main()
+        main_wide()

@@ -26,7 +26,8 @@ SYMBOLS = (
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
     "dbg_get_alphabet", "dbg_export_keepmask",
     "dbg_prune", "dbg_remove_tips",
-    "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_succ",
+    "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_keys_hi",
+    "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
 )
@@ -102,6 +103,7 @@ def load_library():
         "dbg_get_sizes": (C.c_int, [H, C.POINTER(Sizes)]),
         "dbg_get_stats": (C.c_int, [H, C.POINTER(Stats)]),
         "dbg_export_nodes": (C.c_int, [H, vp, vp, vp, vp]),
+        "dbg_export_keys_hi": (C.c_int, [H, vp]),
         "dbg_export_succ": (C.c_int, [H, vp]),
         "dbg_export_csr": (C.c_int, [H, vp, vp, vp]),
         "dbg_export_pull_ranks": (C.c_int, [H, vp]),
@@ -275,6 +277,12 @@ class Graph:
         self._chk(self._lib.dbg_export_nodes(self._h, _ptr(a), _ptr(b), _ptr(c), _ptr(d)))
         return a, b, c, d
 
+    def export_keys_hi(self):
+        """Upper words of the node k-mers (k > 31: k-mer = hi * 2**64 + lo); zeros for k <= 31."""
+        hi = np.empty(self.sizes()["n_nodes"], dtype=np.uint64)
+        self._chk(self._lib.dbg_export_keys_hi(self._h, _ptr(hi)))
+        return hi
+
     def export_succ(self):
         sz = self.sizes()
         n = sz["n_nodes"]
@@ -379,14 +387,24 @@ def device_tensor(ptr, n, dtype, device_index):
 
 
 # ---- 2-bit key <-> str helpers (host side of the boundary) -------------------------------
-def decode_keys(keys, k, alphabet=b"ACTG", bits=2):
-    """uint64 keys -> list of k-character str (alphabet[code] = character; DNA: code = (ascii >> 1) & 3)."""
+def decode_keys(keys, k, alphabet=b"ACTG", bits=2, keys_hi=None):
+    """uint64 keys -> list of k-character str (alphabet[code] = character; DNA: code = (ascii >> 1) & 3).
+
+    keys_hi: upper words for k-mers wider than one word (k > 32 at 2 bits): k-mer = hi * 2**64 + lo."""
     keys = np.asarray(keys, dtype=np.uint64)
     if keys.size == 0:
         return []
     table = np.frombuffer(alphabet.ljust(1 << bits, b"?"), dtype=np.uint8)
-    shifts = (bits * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
-    codes = ((keys[:, None] >> shifts[None, :]) & np.uint64((1 << bits) - 1)).astype(np.intp)
+    shifts = bits * (k - 1 - np.arange(k, dtype=np.int64))
+    mask = np.uint64((1 << bits) - 1)
+    lo_cols = shifts < 64
+    codes = np.empty((keys.size, k), dtype=np.intp)
+    codes[:, lo_cols] = ((keys[:, None] >> shifts[lo_cols].astype(np.uint64)[None, :]) & mask).astype(np.intp)
+    if not lo_cols.all():
+        if keys_hi is None:
+            raise ValueError("k-mers wider than 64 bits need keys_hi")
+        hi = np.asarray(keys_hi, dtype=np.uint64)
+        codes[:, ~lo_cols] = ((hi[:, None] >> (shifts[~lo_cols] - 64).astype(np.uint64)[None, :]) & mask).astype(np.intp)
     buf = table[codes].tobytes().decode("latin-1")
     return [buf[i * k:(i + 1) * k] for i in range(keys.size)]
 

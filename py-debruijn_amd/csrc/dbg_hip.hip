@@ -21,6 +21,7 @@
 #include "dbg_device.h"
 #include "dbg_sk.h"
 #include "dbg_generic.h"
+#include "dbg_wide.h"
 
 using namespace dbgk;
 
@@ -52,6 +53,7 @@ struct dbg {
     uint64_t n_kmer_inst = 0, n_edge_inst = 0;
     uint64_t n_nodes = 0, n_edges = 0;
     uint64_t *d_keys = nullptr, *d_stamps = nullptr;
+    uint64_t *d_keys_hi = nullptr;  // k > 31 only: bits 2k-1..64 of every node's k-mer (dbg_wide.h)
     uint32_t *d_cnt = nullptr;
     uint8_t *d_flags = nullptr;
     uint8_t *d_order = nullptr;  // successor codes ranked by (count desc, ascii asc), 2 bits each
@@ -105,7 +107,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[2];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[2], ar_wide[6];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -540,6 +542,7 @@ constexpr int TIP_DEPTH = 5;  // debruijn.py:246
 // to 32 successors, dbg_generic.h) share them.
 struct GDna {
     const uint64_t *keys;
+    const uint64_t *keys_hi;  // k > 32 bases do not fit one word; nullptr for k <= 31
     const uint8_t *flags;
     const uint8_t *order;
     const uint32_t *succ;
@@ -559,8 +562,11 @@ struct GDna {
     __device__ uint32_t last_code(uint32_t x) const { return (uint32_t)(keys[x] & 3u); }
     __device__ char sym_char(uint32_t code) const { return code_to_ascii(code); }
     __device__ void spell(uint32_t x, char *out) const {
-        const uint64_t key = keys[x];
-        for (int q = 0; q < k; ++q) out[q] = code_to_ascii((uint32_t)(key >> (2 * (k - 1 - q))) & 3u);
+        const uint64_t key = keys[x], hi = keys_hi ? keys_hi[x] : 0ull;
+        for (int q = 0; q < k; ++q) {
+            const int sh = 2 * (k - 1 - q);
+            out[q] = code_to_ascii((uint32_t)(sh >= 64 ? hi >> (sh - 64) : key >> sh) & 3u);
+        }
     }
 };
 
@@ -979,12 +985,8 @@ __global__ __launch_bounds__(256) void k_edge_first_seen(const char *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_order_refine(uint64_t cap, const unsigned long long *set_keys,
-                                                      const uint32_t *set_node, const unsigned long long *estamp,
-                                                      const uint32_t *cnt, uint8_t *order, uint8_t *fsorder) {
-    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= cap || set_keys[slot] == EMPTY_KEY) return;
-    const uint32_t node = set_node[slot];
+__device__ inline void refine_node(uint64_t slot, uint32_t node, const unsigned long long *estamp, const uint32_t *cnt,
+                                   uint8_t *order, uint8_t *fsorder) {
     const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[node];
     const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
     unsigned long long st[4];
@@ -999,6 +1001,16 @@ __global__ __launch_bounds__(256) void k_order_refine(uint64_t cap, const unsign
         }
     order[node] = (uint8_t)(a[0] | (a[1] << 2) | (a[2] << 4) | (a[3] << 6));
     fsorder[node] = (uint8_t)(f[0] | (f[1] << 2) | (f[2] << 4) | (f[3] << 6));
+}
+
+// set_keys == nullptr: the set holds node ids only (two-word k-mers), NO_NODE marks a free slot
+__global__ __launch_bounds__(256) void k_order_refine(uint64_t cap, const unsigned long long *set_keys,
+                                                      const uint32_t *set_node, const unsigned long long *estamp,
+                                                      const uint32_t *cnt, uint8_t *order, uint8_t *fsorder) {
+    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= cap) return;
+    if (set_keys ? set_keys[slot] == EMPTY_KEY : set_node[slot] == NO_NODE) return;
+    refine_node(slot, set_node[slot], estamp, cnt, order, fsorder);
 }
 
 __global__ __launch_bounds__(256) void k_fsorder_default(uint64_t n_nodes, const uint8_t *order, uint8_t *fsorder) {
@@ -1098,11 +1110,12 @@ static void free_build(dbg *h) {
     dev_free(h->d_tab); dev_free(h->d_occ);
     if (h->nodes_in_arena) {
         h->d_keys = nullptr; h->d_stamps = nullptr; h->d_cnt = nullptr; h->d_flags = nullptr;
-        h->d_order = nullptr; h->d_succ = nullptr; h->d_deg = nullptr;
+        h->d_order = nullptr; h->d_succ = nullptr; h->d_deg = nullptr; h->d_keys_hi = nullptr;
         h->nodes_in_arena = false;
     }
     dev_free(h->d_btab);
     h->btab_cap = 0;
+    dev_free(h->d_keys_hi);
     dev_free(h->d_fsorder);
     h->order_exact = false;
     dev_free(h->d_keepmask); dev_free(h->d_rank_mc); dev_free(h->d_rank_fs);
@@ -1164,6 +1177,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_csr) buf_free(b);
     for (auto &b : h->ar_shard) buf_free(b);
     for (auto &b : h->ar_walk) buf_free(b);
+    for (auto &b : h->ar_wide) buf_free(b);
     buf_free(h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
@@ -1495,9 +1509,95 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     return DBG_E_ARG;
 }
 
+// ---- 32 <= k <= 63 over ACGT: two-word k-mers (see dbg_wide.h for the table protocol)
+static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
+    if (h->n_bytes >= (1ull << 46)) { h->err = "reads too large for 48-bit stamps"; return DBG_E_CAPACITY; }
+    uint64_t want = table_capacity_hint ? table_capacity_hint : (uint64_t)((double)(h->n_bytes + 1) / 0.7);
+    uint64_t cap = 1024;
+    int lg = 10;
+    while (cap < want) { cap <<= 1; ++lg; }
+    const uint64_t pk_words = (h->n_bytes + 31) / 32, n_occ = cap / 32;
+    uint64_t *pk = nullptr;
+    unsigned long long *tab = nullptr;
+    uint32_t *tcnt = nullptr, *occ = nullptr, *word_rank = nullptr;
+    auto cleanup = [&]() {};  // everything lives in the grow-only arena (hipMalloc of tens of GB costs seconds)
+    int rc = DBG_OK;
+    uint64_t sc[4] = {0, 0, 0, 0};
+    do {
+        Timer t(h->stream);
+        if ((rc = buf_ensure(h, h->ar_wide[0], (pk_words + 3) * 8)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[1], cap * 8)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[2], cap * 16)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[3], n_occ * 4)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[4], n_occ * 4)) != DBG_OK) break;
+        pk = (uint64_t *)h->ar_wide[0].p;
+        tab = (unsigned long long *)h->ar_wide[1].p;
+        tcnt = (uint32_t *)h->ar_wide[2].p;
+        occ = (uint32_t *)h->ar_wide[3].p;
+        word_rank = (uint32_t *)h->ar_wide[4].p;
+        (void)hipMemsetAsync(pk + pk_words, 0, 3 * 8, h->stream);
+        (void)hipMemsetAsync(tab, 0xFF, cap * 8, h->stream);
+        (void)hipMemsetAsync(tcnt, 0, cap * 16, h->stream);
+        (void)hipMemsetAsync(occ, 0, n_occ * 4, h->stream);
+        (void)hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream);
+        if (pk_words)
+            hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               pk_words, pk);
+        h->stats.ms_table_init = t.stop();
+        Timer tc(h->stream);
+        const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+        if (tiles)
+            hipLaunchKernelGGL(k_wcount, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, k, pk, tab, tcnt, cap - 1, 64 - lg, occ, (unsigned long long *)h->d_scalars);
+        h->stats.count_launches = tiles ? 1 : 0;
+        hipError_t e = hipMemcpyAsync(sc, h->d_scalars, 32, hipMemcpyDeviceToHost, h->stream);
+        h->stats.ms_count = tc.stop();
+        if (e != hipSuccess || hipGetLastError() != hipSuccess) { h->err = "k_wcount failed"; rc = DBG_E_HIP; break; }
+        if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; rc = DBG_E_ALPHABET; break; }
+        if (sc[0] & 2) { h->err = "hash table capacity exceeded"; rc = DBG_E_CAPACITY; break; }
+        h->n_kmer_inst = sc[1];
+        h->n_edge_inst = sc[2];
+
+        Timer tg(h->stream);
+        uint64_t total = 0;
+        if ((rc = exclusive_scan(h, n_occ, PopcWords{occ}, word_rank, &total)) != DBG_OK) break;
+        if (total >= 0xFFFFFFFFull) { h->err = "more than 2^32-1 nodes"; rc = DBG_E_CAPACITY; break; }
+        h->n_nodes = total;
+        if ((rc = buf_ensure(h, h->ar_node[0], total * 8)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_node[1], total * 8)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_node[2], total * 16)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_node[3], total)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_node[4], total)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_node[5], total * 16)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_node[6], total)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[5], total * 8)) != DBG_OK) break;
+        h->d_keys = (uint64_t *)h->ar_node[0].p;
+        h->d_stamps = (uint64_t *)h->ar_node[1].p;
+        h->d_cnt = (uint32_t *)h->ar_node[2].p;
+        h->d_flags = (uint8_t *)h->ar_node[3].p;
+        h->d_order = (uint8_t *)h->ar_node[4].p;
+        h->d_succ = (uint32_t *)h->ar_node[5].p;
+        h->d_deg = (uint8_t *)h->ar_node[6].p;
+        h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
+        h->nodes_in_arena = true;
+        hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
+                           pk, k, h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
+        h->stats.ms_compact = tg.stop();
+        Timer ts(h->stream);
+        if (total)
+            hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, total,
+                               h->d_keys, h->d_keys_hi, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
+        e = hipStreamSynchronize(h->stream);
+        h->stats.ms_succ = ts.stop();
+        if (e != hipSuccess || hipGetLastError() != hipSuccess) { h->err = std::string("wide build: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
+    } while (false);
+    cleanup();
+    return rc;
+}
+
 extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     if (!h) return DBG_E_ARG;
-    if (k < 1 || k > 31) { h->err = "k must be in 1..31 (64-bit (k+1)-mer words)"; return DBG_E_ARG; }
+    if (k < 1 || k > 63) { h->err = "k must be in 1..63 (k-mers of at most two 64-bit words)"; return DBG_E_ARG; }
     if (!h->d_offsets) { h->err = "no reads set"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     free_build(h);
@@ -1507,6 +1607,14 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     if (!h->is_dna) {  // any other alphabet: generic 5-bit engine (peptides: the reference's real inputs)
         Timer t_total(h->stream);
         int rc = build_generic(h, k);
+        if (rc == DBG_OK) rc = finish_graph(h);
+        if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+        h->stats.ms_build_total = t_total.stop();
+        return DBG_OK;
+    }
+    if (k > 31) {  // two-word k-mers: reference-keyed global table (dbg_wide.h)
+        Timer t_total(h->stream);
+        int rc = build_wide(h, k, table_capacity_hint);
         if (rc == DBG_OK) rc = finish_graph(h);
         if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
         h->stats.ms_build_total = t_total.stop();
@@ -1608,7 +1716,29 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
                        h->d_fsorder);
     uint64_t n_multi = 0;
     CHK(reduce_sum(h, h->n_nodes, MultiSucc{h->d_cnt}, &n_multi));
-    if (n_multi) {
+    if (n_multi && h->d_keys_hi) {  // two-word k-mers: the set holds node ids, keys are compared by reference
+        uint64_t cap = 1024;
+        while (cap < n_multi * 2) cap <<= 1;
+        unsigned long long *estamp = nullptr;
+        uint32_t *set_node = nullptr;
+        int rc = dev_alloc(h, &set_node, cap);
+        if (rc == DBG_OK) rc = dev_alloc(h, &estamp, cap * 4);
+        if (rc == DBG_OK) {
+            (void)hipMemsetAsync(set_node, 0xFF, cap * 4, h->stream);
+            (void)hipMemsetAsync(estamp, 0xFF, cap * 32, h->stream);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wset_insert<WSelMulti>), dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream,
+                               h->n_nodes, WSelMulti{h->d_cnt}, h->d_keys, h->d_keys_hi, set_node, cap - 1);
+            const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+            hipLaunchKernelGGL(k_wedge_first_seen, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, h->k, set_node, cap - 1, h->d_keys, h->d_keys_hi, estamp);
+            hipLaunchKernelGGL(k_order_refine, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, cap,
+                               (const unsigned long long *)nullptr, set_node, estamp, h->d_cnt, h->d_order, h->d_fsorder);
+            hipError_t e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { h->err = std::string("refine: ") + hipGetErrorString(e); rc = DBG_E_HIP; }
+        }
+        dev_free(set_node); dev_free(estamp);
+        if (rc != DBG_OK) return rc;
+    } else if (n_multi) {
         uint64_t cap = 1024;
         while (cap < n_multi * 2) cap <<= 1;
         unsigned long long *set_keys = nullptr, *estamp = nullptr;
@@ -1765,7 +1895,7 @@ static int remove_tips_impl(dbg *h, const G &g) {
     return DBG_OK;
 }
 
-static GDna dna_view(const dbg *h) { return GDna{h->d_keys, h->d_flags, h->d_order, h->d_succ, h->d_cnt, h->k}; }
+static GDna dna_view(const dbg *h) { return GDna{h->d_keys, h->d_keys_hi, h->d_flags, h->d_order, h->d_succ, h->d_cnt, h->k}; }
 
 extern "C" int dbg_remove_tips(dbg_t *h) {
     if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
@@ -1790,6 +1920,14 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
         CHK(dev_alloc(h, &h->d_btab, bcap));
         h->btab_cap = bcap;
         HIPCHK(h, hipMemsetAsync(h->d_btab, 0xFF, bcap * 8, h->stream));
+        if (h->d_keys_hi) {  // two-word k-mers: set of branch node ids (32-bit entries in the same buffer)
+            uint32_t *set = (uint32_t *)h->d_btab;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wset_insert<WSelBranch>), dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream,
+                               h->n_nodes, WSelBranch{h->d_flags}, h->d_keys, h->d_keys_hi, set, bcap - 1);
+            hipLaunchKernelGGL(k_wpull_reads, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, h->k, set, bcap - 1, h->d_keys, h->d_keys_hi, h->d_offsets, h->n_reads,
+                               h->d_read_flags);
+        } else {
         hipLaunchKernelGGL(k_branch_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                            h->d_flags, h->d_keys, (unsigned long long *)h->d_btab, bcap - 1);
         if (h->D == GEN_D)
@@ -1799,6 +1937,7 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
         else
             hipLaunchKernelGGL(k_pull_reads, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
                                h->d_startbits, h->k, h->d_btab, bcap - 1, h->d_offsets, h->n_reads, h->d_read_flags);
+        }
         HIPCHK(h, hipGetLastError());
         uint64_t total = 0;
         CHK(reduce_sum(h, h->n_reads, ByteAt{h->d_read_flags}, &total));
@@ -1974,6 +2113,18 @@ extern "C" int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint
     D2H(h, stamps, h->d_stamps, h->n_nodes * 8);
     D2H(h, counts, h->d_cnt, h->n_nodes * 4 * h->D);
     D2H(h, flags, h->d_flags, h->n_nodes);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
+extern "C" int dbg_export_keys_hi(dbg_t *h, uint64_t *keys_hi) {
+    if (!h || !h->k || !keys_hi) return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->d_keys_hi) {  // k <= 31: one word per k-mer
+        memset(keys_hi, 0, h->n_nodes * 8);
+        return DBG_OK;
+    }
+    D2H(h, keys_hi, h->d_keys_hi, h->n_nodes * 8);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DBG_OK;
 }

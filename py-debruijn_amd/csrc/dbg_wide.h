@@ -1,0 +1,309 @@
+// Two-word k-mers: 32 <= k <= 63 over ACGT (BASELINE.json configs[4]: k = 63, 128-bit keys).
+//
+// gfx950 has no 128-bit atomic, so the global table does not hold keys at all: a slot holds the
+// STAMP (byte offset << 1 | pos != 0) of the earliest instance of its k-mer seen so far, tagged
+// with a 16-bit fingerprint, and the key of a slot is "the k-mer at that offset of the reads".
+// Claiming a slot is one 64-bit CAS, keeping the first occurrence is one 64-bit atomicMin (every
+// value a slot ever holds points at an instance of the same k-mer, so its key never changes), and
+// a probe compares against the 2-bit packed copy of the reads -- immutable, hence race-free.
+// After compaction the slot holds the node id instead and compares go to the node key arrays.
+//
+//   k_wpack        ASCII reads -> 2 bits per base, 32 bases per word        [debruijn.py:129-143 input]
+//   k_wcount       every k-mer instance: insert / first-occurrence stamp / successor counter
+//   k_wgather      occupied slots -> node arrays (keys lo/hi, stamp, counts, indegree flag)
+//   k_wsucc        4-way successor ids + count-ranked successor order        [debruijn.py:159-165]
+//   k_wset_insert / k_wpull_reads / k_wedge_first_seen   the wide twins of the 64-bit lookups
+//                  used by pull_out_read [debruijn.py:248-263] and the Counter tie order
+#pragma once
+#include "dbg_device.h"
+
+namespace dbgk {
+
+struct K128 {
+    uint64_t hi, lo;  // value = hi * 2^64 + lo, 2k bits, first base in the top bit pair
+};
+__device__ inline bool k128_eq(K128 a, K128 b) { return a.lo == b.lo && a.hi == b.hi; }
+__device__ inline uint64_t k128_hash(K128 a) { return mix64(a.lo ^ (mix64(a.hi + 0x9E3779B97F4A7C15ull) * 0xD6E8FEB86659FD93ull)); }
+
+// A = bases 0..31, B = bases 32..63 of a 64-base window (first base in bits 63:62): the first k bases
+__device__ inline K128 k128_from_windows(uint64_t A, uint64_t B, int k) {
+    const int s = 128 - 2 * k;  // 2 .. 64
+    if (s == 64) return K128{0ull, A};
+    return K128{A >> s, (A << (64 - s)) | (B >> s)};
+}
+// base k (0-based) of the window, 32 <= k <= 63
+__device__ inline uint32_t base_after_kmer(uint64_t B, int k) { return (uint32_t)(B >> (62 - 2 * (k - 32))) & 3u; }
+// successor k-mer: drop the first base, append b
+__device__ inline K128 k128_append(K128 key, uint32_t b, int k) {
+    K128 r{(key.hi << 2) | (key.lo >> 62), (key.lo << 2) | (uint64_t)b};
+    const int hb = 2 * k - 64;  // 0 .. 62
+    r.hi = hb ? (r.hi & ((1ull << hb) - 1)) : 0ull;
+    return r;
+}
+
+constexpr uint64_t W_STAMP_MASK = (1ull << 48) - 1;  // slot = fingerprint << 48 | stamp (later: node id)
+constexpr uint64_t W_EMPTY = ~0ull;
+
+// 64 bases starting at base p of the packed reads (the array is padded with three zero words)
+__device__ inline void packed_windows(const uint64_t *__restrict__ pk, uint64_t p, uint64_t &A, uint64_t &B) {
+    const uint64_t w = p >> 5;
+    const int s = (int)(p & 31) * 2;
+    const uint64_t a = pk[w], b = pk[w + 1], c = pk[w + 2];
+    A = s ? (a << s) | (b >> (64 - s)) : a;
+    B = s ? (b << s) | (c >> (64 - s)) : b;
+}
+__device__ inline K128 packed_kmer(const uint64_t *__restrict__ pk, uint64_t p, int k) {
+    uint64_t A, B;
+    packed_windows(pk, p, A, B);
+    return k128_from_windows(A, B, k);
+}
+
+// read-start bits of positions j .. j+63 (bit 0 = position j)
+__device__ inline uint64_t startwin64(const TileLds &t, int j) {
+    const int w = j >> 5, sh = j & 31;
+    const uint64_t lo = ((uint64_t)t.sb[w + 1] << 32) | t.sb[w];
+    const uint64_t hi = t.sb[w + 2];
+    return sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+}
+
+__global__ __launch_bounds__(256) void k_wpack(const char *__restrict__ bases, uint64_t n_bytes, uint64_t n_words,
+                                               uint64_t *__restrict__ pk) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint64_t word = 0;
+    const uint64_t off = w * 32;
+    if (off + 32 <= n_bytes) {
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(bases + off);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(bases + off + 16);
+        const uint32_t h = (pack4(q0.x) << 24) | (pack4(q0.y) << 16) | (pack4(q0.z) << 8) | pack4(q0.w);
+        const uint32_t l = (pack4(q1.x) << 24) | (pack4(q1.y) << 16) | (pack4(q1.z) << 8) | pack4(q1.w);
+        word = ((uint64_t)h << 32) | l;
+    } else {
+        for (int b = 0; b < 32 && off + b < n_bytes; ++b)
+            word |= (uint64_t)(((uint8_t)bases[off + b] >> 1) & 3u) << (62 - 2 * b);
+    }
+    pk[w] = word;
+}
+
+// the tile-side view of one k-mer instance, shared by every kernel that streams the reads
+struct WInst {
+    K128 key;
+    uint32_t next;   // base after the k-mer (valid when !at_end)
+    uint32_t s0;     // the k-mer sits at position 0 of its read
+    uint32_t at_end; // position p + k starts another read (or is the end of the data)
+};
+// false: no k-mer of one read starts at tile position j
+__device__ inline bool tile_inst(const TileLds &t, int j, int k, WInst &o) {
+    const uint64_t sw = startwin64(t, j);
+    if ((sw >> 1) & ((1ull << (k - 1)) - 1)) return false;  // a read boundary inside the k-mer
+    o.s0 = (uint32_t)(sw & 1ull);
+    o.at_end = (uint32_t)(sw >> k) & 1u;
+    const uint64_t A = window32(t, j), B = window32(t, j + 32);
+    o.key = k128_from_windows(A, B, k);
+    o.next = base_after_kmer(B, k);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, uint64_t n_bytes,
+                                                const uint32_t *__restrict__ startbits, int k,
+                                                const uint64_t *__restrict__ pk, unsigned long long *tab, uint32_t *tcnt,
+                                                uint64_t cap_mask, int hash_shift, uint32_t *occ,
+                                                unsigned long long *scalars) {
+    __shared__ TileLds t;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    const uint32_t bad = load_tile(t, bases, n_bytes, startbits, tile0);
+    if (bad) atomicOr(&scalars[0], 1ull);
+    __syncthreads();
+    uint64_t n_k = 0, n_e = 0;
+    for (int j = threadIdx.x; j < TILE; j += 256) {
+        const uint64_t p = tile0 + j;
+        if (p >= n_bytes) break;
+        WInst in;
+        if (!tile_inst(t, j, k, in)) continue;
+        if (in.at_end && in.s0) continue;  // read of length exactly k: contributes nothing [:126]
+        const uint64_t stamp = (p << 1) | (in.s0 ^ 1u);
+        n_k += 1;
+        n_e += in.at_end ^ 1u;
+        const uint64_t hv = k128_hash(in.key);
+        const unsigned long long mine = ((hv & 0xFFFFull) << 48) | stamp;
+        uint64_t slot = hv >> hash_shift;
+        bool found = false;
+        for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+            unsigned long long cur = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == W_EMPTY) {
+                cur = atomicCAS(&tab[slot], W_EMPTY, mine);
+                if (cur == W_EMPTY) {
+                    atomicOr(&occ[slot >> 5], 1u << (slot & 31));
+                    found = true;
+                    break;
+                }
+            }
+            if ((cur >> 48) == (mine >> 48) && k128_eq(packed_kmer(pk, (cur & W_STAMP_MASK) >> 1, k), in.key)) {
+                atomicMin(&tab[slot], mine);  // same fingerprint: the smaller value is the earlier instance
+                found = true;
+                break;
+            }
+            slot = (slot + 1) & cap_mask;
+        }
+        if (!found) { atomicOr(&scalars[0], 2ull); continue; }  // table full
+        if (!in.at_end) atomicAdd(&tcnt[slot * 4 + in.next], 1u);
+    }
+    n_k = wave_sum_u64(n_k);
+    n_e = wave_sum_u64(n_e);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_k) atomicAdd(&scalars[1], (unsigned long long)n_k);
+        if (n_e) atomicAdd(&scalars[2], (unsigned long long)n_e);
+    }
+}
+
+// occupied slots -> node arrays (table order); the slot keeps its fingerprint and takes the node id
+__global__ __launch_bounds__(256) void k_wgather(unsigned long long *tab, const uint32_t *__restrict__ tcnt,
+                                                 const uint32_t *occ, const uint32_t *word_rank, uint64_t n_words,
+                                                 const uint64_t *__restrict__ pk, int k, uint64_t *keys_lo, uint64_t *keys_hi,
+                                                 uint64_t *stamps, uint32_t *cnt, uint8_t *flags) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t bits = occ[w];
+    uint32_t node = word_rank[w];
+    while (bits) {
+        const int b = __ffs(bits) - 1;
+        bits &= bits - 1;
+        const uint64_t slot = w * 32 + b;
+        const unsigned long long cur = tab[slot];
+        const uint64_t st = cur & W_STAMP_MASK;
+        const K128 key = packed_kmer(pk, st >> 1, k);
+        keys_lo[node] = key.lo;
+        keys_hi[node] = key.hi;
+        stamps[node] = st;
+        reinterpret_cast<uint4 *>(cnt)[node] = reinterpret_cast<const uint4 *>(tcnt)[slot];
+        flags[node] = (uint8_t)(st & 1);
+        tab[slot] = (cur & ~W_STAMP_MASK) | node;
+        ++node;
+    }
+}
+
+__device__ inline uint32_t wtab_find(const unsigned long long *__restrict__ tab, uint64_t cap_mask, int hash_shift, K128 key,
+                                     const uint64_t *__restrict__ keys_lo, const uint64_t *__restrict__ keys_hi) {
+    const uint64_t hv = k128_hash(key);
+    uint64_t slot = hv >> hash_shift;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        const unsigned long long cur = tab[slot];
+        if (cur == W_EMPTY) return NO_NODE;
+        if ((cur >> 48) == (hv & 0xFFFFull)) {
+            const uint32_t node = (uint32_t)(cur & W_STAMP_MASK);
+            if (keys_lo[node] == key.lo && keys_hi[node] == key.hi) return node;
+        }
+        slot = (slot + 1) & cap_mask;
+    }
+    return NO_NODE;
+}
+
+__global__ __launch_bounds__(256) void k_wsucc(const unsigned long long *__restrict__ tab, uint64_t cap_mask, int hash_shift, int k,
+                                               uint64_t n_nodes, const uint64_t *__restrict__ keys_lo,
+                                               const uint64_t *__restrict__ keys_hi, const uint32_t *__restrict__ cnt,
+                                               uint32_t *succ, uint8_t *order, uint8_t *deg) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const K128 key{keys_hi[i], keys_lo[i]};
+    const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[i];
+    const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+    uint32_t s[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        s[b] = c[b] ? wtab_find(tab, cap_mask, hash_shift, k128_append(key, (uint32_t)b, k), keys_lo, keys_hi) : NO_NODE;
+    reinterpret_cast<uint4 *>(succ)[i] = make_uint4(s[0], s[1], s[2], s[3]);
+    deg[i] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
+    uint32_t code[4] = {0, 1, 3, 2};  // ascii order A, C, G, T as codes; rank by (count desc, ascii asc)
+#pragma unroll
+    for (int a = 1; a < 4; ++a) {
+#pragma unroll
+        for (int b = a; b > 0; --b) {
+            if (c[code[b]] > c[code[b - 1]]) { uint32_t tmp = code[b]; code[b] = code[b - 1]; code[b - 1] = tmp; }
+        }
+    }
+    order[i] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
+}
+
+// ---- small sets of node ids (branch nodes; nodes with two or more successors), keys by reference ----
+struct WSelBranch {
+    const uint8_t *flags;
+    __device__ bool operator()(uint64_t i) const { return (flags[i] & DBG_F_BRANCH) != 0; }
+};
+struct WSelMulti {
+    const uint32_t *cnt;
+    __device__ bool operator()(uint64_t i) const {
+        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
+        return (c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0) >= 2;
+    }
+};
+template <class Sel>
+__global__ __launch_bounds__(256) void k_wset_insert(uint64_t n_nodes, Sel sel, const uint64_t *__restrict__ keys_lo,
+                                                     const uint64_t *__restrict__ keys_hi, uint32_t *set, uint64_t cap_mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || !sel(i)) return;
+    uint64_t slot = k128_hash(K128{keys_hi[i], keys_lo[i]}) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {  // node keys are distinct: claim the first free slot
+        if (atomicCAS(&set[slot], NO_NODE, (uint32_t)i) == NO_NODE) return;
+        slot = (slot + 1) & cap_mask;
+    }
+}
+// slot of `key` in the set, or -1
+__device__ inline int64_t wset_find(const uint32_t *__restrict__ set, uint64_t cap_mask, K128 key,
+                                    const uint64_t *__restrict__ keys_lo, const uint64_t *__restrict__ keys_hi) {
+    uint64_t slot = k128_hash(key) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        const uint32_t node = set[slot];
+        if (node == NO_NODE) return -1;
+        if (keys_lo[node] == key.lo && keys_hi[node] == key.hi) return (int64_t)slot;
+        slot = (slot + 1) & cap_mask;
+    }
+    return -1;
+}
+
+// reads that contain a branch k-mer as a substring (reads of length == k included) [debruijn.py:248-263]
+__global__ __launch_bounds__(256) void k_wpull_reads(const char *__restrict__ bases, uint64_t n_bytes,
+                                                     const uint32_t *__restrict__ startbits, int k,
+                                                     const uint32_t *__restrict__ set, uint64_t cap_mask,
+                                                     const uint64_t *__restrict__ keys_lo, const uint64_t *__restrict__ keys_hi,
+                                                     const uint64_t *offsets, uint64_t n_reads, uint8_t *read_flags) {
+    __shared__ TileLds t;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    (void)load_tile(t, bases, n_bytes, startbits, tile0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < TILE; j += 256) {
+        const uint64_t p = tile0 + j;
+        if (p + k > n_bytes) break;
+        WInst in;
+        if (!tile_inst(t, j, k, in)) continue;
+        if (wset_find(set, cap_mask, in.key, keys_lo, keys_hi) < 0) continue;
+        uint64_t lo = 0, hi = n_reads;  // offsets[lo] <= p < offsets[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (offsets[mid] <= p) lo = mid; else hi = mid;
+        }
+        read_flags[lo] = 1;
+    }
+}
+
+// first occurrence of every out-edge of the nodes in the set (Counter order, debruijn.py:159-165, :215-216)
+__global__ __launch_bounds__(256) void k_wedge_first_seen(const char *__restrict__ bases, uint64_t n_bytes,
+                                                          const uint32_t *__restrict__ startbits, int k,
+                                                          const uint32_t *__restrict__ set, uint64_t cap_mask,
+                                                          const uint64_t *__restrict__ keys_lo,
+                                                          const uint64_t *__restrict__ keys_hi,
+                                                          unsigned long long *estamp /* [slot * 4 + code] */) {
+    __shared__ TileLds t;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    (void)load_tile(t, bases, n_bytes, startbits, tile0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < TILE; j += 256) {
+        const uint64_t p = tile0 + j;
+        if (p + k >= n_bytes) break;  // needs a successor base
+        WInst in;
+        if (!tile_inst(t, j, k, in) || in.at_end) continue;
+        const int64_t slot = wset_find(set, cap_mask, in.key, keys_lo, keys_hi);
+        if (slot >= 0) atomicMin(&estamp[(uint64_t)slot * 4 + in.next], (unsigned long long)p);
+    }
+}
+
+}  // namespace dbgk

@@ -7,9 +7,9 @@ through the C ABI of ``include/dbg.h`` (binding: ``_dbg.py``).  There is no CPU
 path: without the built library and a GPU every call raises.
 
 Differences a caller can observe, all documented in DESIGN.md:
-  * limits of the packed k-mer words: reads of upper-case A/C/G/T only: 1 <= k <= 31; any other alphabet
-    (peptides, lower case, N, ...): at most 32 distinct single-byte characters and 1 <= k <= 11
-    (ValueError otherwise -- never a silent drop or split);
+  * limits of the packed k-mer words: reads of upper-case A/C/G/T only: 1 <= k <= 63 (two 64-bit words
+    per k-mer above 31); any other alphabet (peptides, lower case, N, ...): at most 32 distinct
+    single-byte characters and 1 <= k <= 11 (ValueError otherwise -- never a silent drop or split);
   * ``output_contigs`` needs the objects returned by this module's ``construct_graph``.
 Everything else -- values AND orders (dict insertion order, ``Counter.most_common`` tie order,
 the append order of ``already_pull_out``, contig order) -- equals the reference.
@@ -125,8 +125,8 @@ def construct_graph(reads, k, threshold=3, final=False):
 
     Returns ((vertices, edges), pull_out_read, branch_kmer, already_pull_out, edge_count_table).
     """
-    if not isinstance(k, (int, np.integer)) or not (1 <= int(k) <= 31):
-        raise ValueError("the device path supports 1 <= k <= 31 (1 <= k <= 11 for alphabets other than ACGT)")
+    if not isinstance(k, (int, np.integer)) or not (1 <= int(k) <= 63):
+        raise ValueError("the device path supports 1 <= k <= 63 (1 <= k <= 11 for alphabets other than ACGT)")
     k = int(k)
     if isinstance(reads, DeviceReads):
         g = reads._graph  # reads are resident (alphabet is checked by the kernels: AlphabetError is a ValueError)
@@ -157,7 +157,8 @@ def construct_graph(reads, k, threshold=3, final=False):
     alphabet, bits = g.alphabet()                 # code -> character
     chars = alphabet.decode("latin-1")
     order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
-    labels = _dbg.decode_keys(keys[order], k, alphabet, bits)
+    keys_hi = g.export_keys_hi()[order] if bits * k > 64 else None
+    labels = _dbg.decode_keys(keys[order], k, alphabet, bits, keys_hi)
     counts_o = counts[order]
     rank_mc, rank_fs = rank_mc[order], rank_fs[order]
     flags_o = flags[order]

@@ -82,9 +82,10 @@ def test_golden_case(name):
         assert_same(got, ref, inp["final"], name + " (reference)")
 
 
-@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240)])
+@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240), ("fuzz_wide", 160)])
 def test_fuzz_family_against_reference_vectors(family, n_min):
-    """fuzz_small: sub-alphabets of ACGT (2-bit path); fuzz_peptide: amino acids (generic 5-bit path)."""
+    """fuzz_small: sub-alphabets of ACGT (2-bit path); fuzz_peptide: amino acids (generic 5-bit path);
+    fuzz_wide: 32 <= k <= 63 (two-word k-mers) with repeats longer than k, tips and tandem-repeat cycles."""
     with open(os.path.join(GOLDEN, family + ".json")) as fh:
         cases = json.load(fh)
     n = 0

@@ -32,6 +32,64 @@ def test_one_million_reads_vs_c_oracle():
         assert np.array_equal(keys[succ[has, code]], ((keys[has] << np.uint64(2)) | np.uint64(code)) & mask)
 
 
+@pytest.mark.parametrize("k", [32, 47, 63])
+def test_two_word_kmers_vs_c_oracle(k):
+    """BASELINE.json configs[4] key width (k = 63, 128-bit keys) at a size the C oracle builds in seconds."""
+    n, L = 300_000, 150
+    reads = synth.reads_ascii(3, 1_500_000, n, L, 0.01)
+    off = np.arange(0, reads.size + 1, L, dtype=np.uint64)
+    want = orc_c.build(reads.reshape(-1), off, k)
+    g = _dbg.Graph()
+    g.synth_reads(3, 1_500_000, n, L, 0.01)
+    g.build(k)
+    sz = g.sizes()
+    assert sz["n_nodes"] == want["n_nodes"] and sz["n_kmer_instances"] == want["n_kmer_instances"]
+    assert sz["n_edge_instances"] == want["n_edge_instances"]
+    keys, stamps, counts, flags = g.export_nodes()
+    hi = g.export_keys_hi()
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(hi[o], want["keys_hi"])
+    assert np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(counts[o], want["counts"])
+    assert np.array_equal(flags & 1, (stamps & np.uint64(1)).astype(np.uint8))
+    # successors: (key << 2 | code) mod 4^k, two words
+    succ = g.export_succ()
+    hb = 2 * k - 64
+    hmask = np.uint64((1 << hb) - 1) if hb else np.uint64(0)
+    for code in range(4):
+        has = counts[:, code] != 0
+        s = succ[has, code]
+        assert np.array_equal(keys[s], (keys[has] << np.uint64(2)) | np.uint64(code))
+        assert np.array_equal(hi[s], ((hi[has] << np.uint64(2)) | (keys[has] >> np.uint64(62))) & hmask)
+    rp, col, cnt = g.export_csr()
+    assert rp[-1] == sz["n_edges"] == int((counts != 0).sum())
+
+
+def test_two_word_kmers_full_size_invariants():
+    """10M x 150 bp at k = 63: the sizes and sums that hold whatever the input."""
+    n, L, k, G = 10_000_000, 150, 63, 50_000_000
+    g = _dbg.Graph()
+    g.synth_reads(1, G, n, L, 0.0)
+    g.build(k)
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == n * (L - k + 1) and sz["n_edge_instances"] == n * (L - k)
+    assert sz["n_nodes"] <= G - k + 1  # error-free reads hold only k-mers of the genome
+    keys, stamps, counts, flags = g.export_nodes()
+    assert int(counts.sum(dtype=np.uint64)) == sz["n_edge_instances"]
+    assert np.unique(stamps).size == stamps.size
+    pos = stamps >> np.uint64(1)
+    assert np.array_equal((stamps & np.uint64(1)) == 0, pos % np.uint64(L) == 0)
+    # the first occurrence really holds the k-mer (sample)
+    hi = g.export_keys_hi()
+    reads, _ = g.copy_reads()
+    idx = np.linspace(0, keys.size - 1, 5000).astype(np.int64)
+    for i in idx[::50]:
+        v = 0
+        for ch in reads[int(pos[i]):int(pos[i]) + k]:
+            v = (v << 2) | ((int(ch) >> 1) & 3)
+        assert v == (int(hi[i]) << 64) | int(keys[i])
+
+
 @pytest.mark.parametrize("err", [0.0, 0.01])
 def test_full_size_invariants(err):
     """10M x 150 bp, k = 31: properties that hold whatever the size."""

@@ -9,8 +9,9 @@ from oracle import orc_c
 CODE_CHAR = "ACTG"
 
 
-def decode(key, k):
-    return "".join(CODE_CHAR[(int(key) >> (2 * (k - 1 - i))) & 3] for i in range(k))
+def decode(key, k, hi=0):
+    v = (int(hi) << 64) | int(key)
+    return "".join(CODE_CHAR[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
 
 
 def pack(reads):
@@ -30,7 +31,7 @@ def test_c_oracle_matches_python_oracle(name):
     b, off = pack(reads)
     res = orc_c.build(b, off, k)
     assert res["n_nodes"] == len(V) == case["summary"]["n_vertices"]
-    labels = [decode(x, k) for x in res["keys"]]
+    labels = [decode(x, k, hi) for x, hi in zip(res["keys"], res["keys_hi"])]
     assert labels == list(V.keys())  # dict order
     assert [int(s) & 1 for s in res["stamps"]] == [V[v].indegree for v in V]
     got = {}

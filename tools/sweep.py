@@ -10,6 +10,7 @@ import _dbg
 
 reads = int(os.environ.get("SWEEP_READS", "10000000"))
 err = float(os.environ.get("SWEEP_ERR", "0.01"))
+kk = int(os.environ.get("SWEEP_K", "31"))
 configs = json.loads(sys.argv[1]) if len(sys.argv) > 1 else [{}]
 for cfg in configs:
     g = _dbg.Graph()
@@ -18,13 +19,13 @@ for cfg in configs:
     g.synth_reads(1, int(reads * 150 / 30), reads, 150, err)
     for _ in range(2):
         try:
-            g.build(31)
+            g.build(kk)
         except _dbg.DbgError as e:
             if "ablation" not in str(e):
                 raise
     st = g.stats()
     sz = g.sizes()
-    print(json.dumps({"cfg": cfg, "extract": round(st["ms_extract"], 2), "partition": round(st["ms_partition"], 2),
+    print(json.dumps({"cfg": cfg, "k": kk, "compact": round(st["ms_compact"], 2), "extract": round(st["ms_extract"], 2), "partition": round(st["ms_partition"], 2),
                       "count": round(st["ms_count"], 2), "succ": round(st["ms_succ"], 2), "csr": round(st["ms_csr"], 2),
                       "total": round(st["ms_build_total"], 2), "n_nodes": sz["n_nodes"], "buckets": st["n_buckets"],
                       "records": st["n_records"], "queries": st["n_queries"]}), flush=True)
