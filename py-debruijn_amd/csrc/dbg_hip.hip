@@ -49,7 +49,7 @@ struct dbg {
     uint64_t cap = 0;
     int cap_log2 = 0;
     uint32_t *d_occ = nullptr;  // occupancy bitmap over slots
-    uint64_t *d_scalars = nullptr;  // [0] error flags [1] N_k [2] N_e [3..] scratch
+    uint64_t *d_scalars = nullptr;  // [0] error flags [1] N_k [2] N_e [3..63] scratch [64..127] kernel descriptors
     uint64_t n_kmer_inst = 0, n_edge_inst = 0;
     uint64_t n_nodes = 0, n_edges = 0;
     uint64_t *d_keys = nullptr, *d_stamps = nullptr;
@@ -1156,7 +1156,7 @@ extern "C" int dbg_create(int device, dbg_t **out) {
     if (!h) return DBG_E_NOMEM;
     h->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess ||
-        hipMalloc((void **)&h->d_scalars, 64 * sizeof(uint64_t)) != hipSuccess) {
+        hipMalloc((void **)&h->d_scalars, 128 * sizeof(uint64_t)) != hipSuccess) {
         delete h;
         return DBG_E_HIP;
     }
@@ -2481,8 +2481,12 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             constexpr int NT = CntCfg<ST, CAP>::NT;
             const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(2048 / NT, (160 * 1024) / lds));
             const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu * per_cu);  // persistent
+            // descriptor in device memory (see fresh_args): words 64.. of the scalar block are reserved for it
+            static_assert(sizeof(SkCountOut) <= 64 * 8, "descriptor slot");
+            SkCountOut *d_out = (SkCountOut *)(h->d_scalars + 64);
+            HIPCHK(h, hipMemcpyAsync(d_out, &out, sizeof(out), hipMemcpyHostToDevice, h->stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
-                               st[where], k, m, n_buckets, out, h->phase_limit);
+                               st[where], k, m, n_buckets, (const SkCountOut *)d_out, h->phase_limit);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? 1 : 0;

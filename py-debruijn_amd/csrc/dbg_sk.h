@@ -675,6 +675,17 @@ struct SkCountOut {
     unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | edges (high 32) [5] queries [6] extra ranges
 };
 
+// The output descriptor lives in device memory and is re-read (scalar loads, a few per phase) where a phase
+// needs it: passed by value its ~50 SGPRs stay live across the whole persistent loop, and the compiler
+// spilled them to VGPR lanes -- a third of the node-write phase was v_readlane reloads.
+// (constant address space: uniform scalar loads the stores of the phase cannot alias)
+typedef const SkCountOut __attribute__((address_space(4))) *SkOutConstPtr;
+__device__ inline SkOutConstPtr fresh_args(const SkCountOut *p) {
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));  // a new value for the optimiser: loads through it are not merged with earlier ones
+    return (SkOutConstPtr)v;
+}
+
 // wave-aggregated LDS counter: returns this lane's index, adds popcount(active & pred) once per wave
 __device__ inline uint32_t wave_alloc(uint32_t *counter, bool pred) {
     const unsigned long long mask = __ballot(pred);
@@ -715,7 +726,7 @@ template <class ST, int CAP>
 __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
                                                      const ST *__restrict__ rec_st, int k, int m, uint64_t n_buckets,
-                                                     SkCountOut out, int phase_limit /* ablation only: 0 = run everything */) {
+                                                     const SkCountOut *__restrict__ outp, int phase_limit /* ablation only: 0 = run everything */) {
     // Persistent: one workgroup per CU walks buckets blockIdx.x, blockIdx.x + gridDim.x, ...  The table
     // stays in LDS across buckets: the node write clears exactly the slots it reads (a third of the
     // table), and the next bucket's records are prefetched into registers while this bucket is in
@@ -875,7 +886,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
                 const uint32_t bit = cur_mask + 1;  // masks are 2^j - 1
                 if (stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
-                    if (threadIdx.x == 0) atomicOr(&out.scalars[0], 8ull);  // bucket cannot be split further
+                    if (threadIdx.x == 0) atomicOr(&fresh_args(outp)->scalars[0], 8ull);  // bucket cannot be split further
                     failed = true;
                     break;
                 }
@@ -924,7 +935,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             //      the lookups (its ~1.5 us round trip hides behind them)
             unsigned long long got = 0;
             if (threadIdx.x == 0)
-                got = atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
+                got = atomicAdd(&fresh_args(outp)->scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
             // ---- successor lookups into registers; misses are staged as queries (slot index local for now).
             //      Per node only the bases that occur are looked up (usually one): the wave loops
             //      max-popcount times instead of four.  Result per base, 16 bits: local node index,
@@ -974,22 +985,23 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
             const uint32_t nq = s.n_q;
             unsigned long long qgot = 0;
-            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);  // query cursor
+            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&fresh_args(outp)->scalars[5], (unsigned long long)nq);  // query cursor
             if (threadIdx.x == 0) {
+                const auto &orr = *fresh_args(outp);
                 const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
                 s.gbase = base;
                 s.ebase = eb;
-                if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
-                if (eb + n_edges_local > out.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
+                if (base + n_local > orr.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
+                if (eb + n_edges_local > orr.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
                 uint64_t ri = bucket;
                 if (cur_mask) {
-                    ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
-                    if (ri >= out.range_cap) { atomicOr(&out.scalars[0], 32ull); s.fail = 1; }
+                    ri = orr.n_buckets + atomicAdd(&orr.scalars[6], 1ull);
+                    if (ri >= orr.range_cap) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
                 }
                 if (!s.fail) {
                     SkRange rg;
                     rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
-                    out.ranges[ri] = rg;
+                    orr.ranges[ri] = rg;
                 }
             }
             // minimizer bucket of every staged query (dense, no divergence) while the query cursor is in flight
@@ -999,6 +1011,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             if (phase_limit == 5) { skip_rest = true; break; }  // + reservation + query buckets
             if (s.fail) break;
             const uint64_t gbase = s.gbase, ebase = s.ebase;
+            const auto &ow = *fresh_args(outp);  // loaded here, not kept in SGPRs across the whole bucket loop
             // ---- write nodes and their CSR rows: consecutive lanes -> consecutive nodes; every slot read is
             //      cleared for the next bucket
 #pragma unroll
@@ -1015,10 +1028,10 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 s.keys[i] = EMPTY_KEY;
                 s.stamp[i] = (ST)~(ST)0;
                 reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
-                out.keys[node] = key;
-                out.stamps[node] = stamp;
-                reinterpret_cast<uint4 *>(out.cnt)[node] = c4;
-                out.flags[node] = (uint8_t)(stamp & 1);
+                ow.keys[node] = key;
+                ow.stamps[node] = stamp;
+                reinterpret_cast<uint4 *>(ow.cnt)[node] = c4;
+                ow.flags[node] = (uint8_t)(stamp & 1);
                 uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
 #pragma unroll
                 for (int a = 1; a < 4; ++a) {
@@ -1027,36 +1040,37 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                         if (c[code[b]] > c[code[b - 1]]) { uint32_t t = code[b]; code[b] = code[b - 1]; code[b - 1] = t; }
                     }
                 }
-                out.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
+                ow.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
                 uint32_t sc[4];
                 uint64_t e = ebase + s.eoff[li];
-                out.rowptr[node] = e;
+                ow.rowptr[node] = e;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
-                    sc[b] = v < 0x8000u ? ((uint32_t)(gbase + v) | out.id_tag) : NO_NODE;
+                    sc[b] = v < 0x8000u ? ((uint32_t)(gbase + v) | ow.id_tag) : NO_NODE;
                     if (c[b]) {
-                        out.col[e] = sc[b];
-                        out.ecnt[e] = c[b];
+                        ow.col[e] = sc[b];
+                        ow.ecnt[e] = c[b];
                         ++e;
                     }
                 }
-                reinterpret_cast<uint4 *>(out.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+                reinterpret_cast<uint4 *>(ow.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
             }
             // ---- queries out (the cursor has had the whole node pass to come back)
             if (threadIdx.x == 64 && nq) {
                 s.qbase = qgot;
-                if (qgot + nq > out.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+                if (qgot + nq > (*fresh_args(outp)).q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&(*fresh_args(outp)).scalars[0], 64ull); s.fail = 1; }
             }
             __syncthreads();
             if (s.fail) break;
             if (nq) {
+                const auto &oq = *fresh_args(outp);
                 const uint64_t qbase = s.qbase;
                 for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
                     const unsigned long long meta = s.q_meta[i];
-                    out.q_key[qbase + i] = s.q_key[i];
-                    out.q_meta[qbase + i] = (meta & ~0xFFFFFFFFull) | ((meta & 0xFFFFull) + gbase * 4);
-                    out.q_col[qbase + i] = (uint32_t)(ebase + ((meta >> 16) & 0xFFFFull));
+                    oq.q_key[qbase + i] = s.q_key[i];
+                    oq.q_meta[qbase + i] = (meta & ~0xFFFFFFFFull) | ((meta & 0xFFFFull) + gbase * 4);
+                    oq.q_col[qbase + i] = (uint32_t)(ebase + ((meta >> 16) & 0xFFFFull));
                 }
                 if (nq > (uint32_t)CNT_QBUF) {  // rare: queries that did not fit the staging, straight from the registers
 #pragma unroll
@@ -1070,10 +1084,10 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                             if (v >= 0x8000u && v < 0xFFFEu) {
                                 const uint64_t qi = (uint64_t)(v & 0x7FFFu) + CNT_QBUF;
                                 const uint64_t node = gbase + li;
-                                const uint64_t skey = ((out.keys[node] << 2) | (uint64_t)b) & kmask;
-                                out.q_key[qbase + qi] = skey;
-                                out.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
-                                out.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
+                                const uint64_t skey = ((oq.keys[node] << 2) | (uint64_t)b) & kmask;
+                                oq.q_key[qbase + qi] = skey;
+                                oq.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
+                                oq.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
                             }
                             if (v != 0xFFFFu) ++rank;  // every base that occurs owns one CSR column
                         }
