@@ -1032,15 +1032,17 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 ow.stamps[node] = stamp;
                 reinterpret_cast<uint4 *>(ow.cnt)[node] = c4;
                 ow.flags[node] = (uint8_t)(stamp & 1);
-                uint32_t code[4] = {0, 1, 3, 2};  // ASCII order A, C, G, T as codes
-#pragma unroll
-                for (int a = 1; a < 4; ++a) {
-#pragma unroll
-                    for (int b = a; b > 0; --b) {
-                        if (c[code[b]] > c[code[b - 1]]) { uint32_t t = code[b]; code[b] = code[b - 1]; code[b - 1] = t; }
-                    }
-                }
-                ow.order[node] = (uint8_t)(code[0] | (code[1] << 2) | (code[2] << 4) | (code[3] << 6));
+                // rank of every code by (count descending, ASCII order A C G T = codes 0 1 3 2 ascending): six
+                // pair comparisons, no data-dependent register indexing (the insertion sort compiled to ~80 selects)
+                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                { const uint32_t f = c[0] >= c[1]; r1 += f; r0 += 1u - f; }
+                { const uint32_t f = c[0] >= c[3]; r3 += f; r0 += 1u - f; }
+                { const uint32_t f = c[0] >= c[2]; r2 += f; r0 += 1u - f; }
+                { const uint32_t f = c[1] >= c[3]; r3 += f; r1 += 1u - f; }
+                { const uint32_t f = c[1] >= c[2]; r2 += f; r1 += 1u - f; }
+                { const uint32_t f = c[3] >= c[2]; r2 += f; r3 += 1u - f; }
+                (void)r0;  // code 0 contributes no bits wherever it ranks
+                ow.order[node] = (uint8_t)((1u << (2 * r1)) | (2u << (2 * r2)) | (3u << (2 * r3)));
                 uint32_t sc[4];
                 uint64_t e = ebase + s.eoff[li];
                 ow.rowptr[node] = e;
