@@ -10,11 +10,17 @@ Differences a caller can observe, all documented in DESIGN.md:
   * limits of the packed k-mer words: reads of upper-case A/C/G/T only: 1 <= k <= 63 (two 64-bit words
     per k-mer above 31); any other alphabet (peptides, lower case, N, ...): at most 32 distinct
     single-byte characters and 1 <= k <= 11 (ValueError otherwise -- never a silent drop or split);
-  * ``output_contigs`` needs the objects returned by this module's ``construct_graph``.
+  * ``output_contigs`` needs the objects returned by this module's ``construct_graph``;
+  * graphs of ``LAZY_MIN_NODES`` (2e6, env ``DBG_LAZY_MIN_NODES``) or more nodes come back as read-only
+    ``Mapping`` views over the exported arrays (label lookup, ``len``, ordered iteration; equal to the
+    reference's dicts when materialised) instead of Python dicts.
 Everything else -- values AND orders (dict insertion order, ``Counter.most_common`` tie order,
 the append order of ``already_pull_out``, contig order) -- equals the reference.
 """
 from __future__ import annotations
+
+import os
+from collections.abc import ItemsView, Mapping
 
 import numpy as np
 
@@ -98,6 +104,174 @@ class _Vertices(dict):
     _state = None
 
 
+# Above this many nodes construct_graph returns read-only Mapping views over the exported arrays instead of
+# Python dicts (dicts are infeasible at 10^8 nodes); equal to the dicts when materialised.
+LAZY_MIN_NODES = int(os.environ.get("DBG_LAZY_MIN_NODES", "2000000"))
+
+
+class _NodeStore:
+    """Host arrays of one graph in dict (first-occurrence) order + label <-> index conversion."""
+
+    def __init__(self, k, alphabet, bits, keys, keys_hi, counts, rank_mc, rank_fs, indeg, outdeg, pulled, keep):
+        self.k, self.alphabet, self.bits = k, alphabet, bits
+        self.chars = alphabet.decode("latin-1")
+        self.code_of = {ch: i for i, ch in enumerate(self.chars)}  # alphabet[code] = character
+        self.keys, self.keys_hi, self.counts = keys, keys_hi, counts
+        self.rank_mc, self.rank_fs = rank_mc, rank_fs
+        self.indeg, self.outdeg, self.pulled, self.keep = indeg, outdeg, pulled, keep
+        self.n = int(keys.size)
+        self._sorted = None
+
+    def labels(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        hi = None if self.keys_hi is None else self.keys_hi[idx]
+        return _dbg.decode_keys(self.keys[idx], self.k, self.alphabet, self.bits, hi)
+
+    def label(self, i):
+        return self.labels([i])[0]
+
+    def encode(self, lab):
+        """(hi, lo) words of a k-character label, or None if it is not a k-mer over the alphabet."""
+        if not isinstance(lab, str) or len(lab) != self.k:
+            return None
+        v = 0
+        for ch in lab:
+            c = self.code_of.get(ch)
+            if c is None:
+                return None
+            v = (v << self.bits) | c
+        return v >> 64, v & 0xFFFFFFFFFFFFFFFF
+
+    def find(self, lab):
+        """Index (dict order) of a label, or -1."""
+        e = self.encode(lab)
+        if e is None:
+            return -1
+        if self._sorted is None:  # one sort, on the first lookup
+            if self.keys_hi is None:
+                perm = np.argsort(self.keys, kind="stable")
+            else:
+                perm = np.lexsort((self.keys, self.keys_hi))
+            self._sorted = (perm, self.keys[perm], None if self.keys_hi is None else self.keys_hi[perm])
+        perm, lo_s, hi_s = self._sorted
+        hi, lo = e
+        if hi_s is None:
+            if hi:
+                return -1
+            a = int(np.searchsorted(lo_s, np.uint64(lo), side="left"))
+            return int(perm[a]) if a < self.n and int(lo_s[a]) == lo else -1
+        a = int(np.searchsorted(hi_s, np.uint64(hi), side="left"))
+        b = int(np.searchsorted(hi_s, np.uint64(hi), side="right"))
+        c = a + int(np.searchsorted(lo_s[a:b], np.uint64(lo), side="left"))
+        return int(perm[c]) if c < b and int(lo_s[c]) == lo else -1
+
+    def successors(self, i, pruned):
+        """Successor labels of node i: Counter.most_common order; only the kept ones when `pruned`."""
+        lab = self.label(i)
+        c = self.counts[i]
+        nd = int(self.outdeg[i])
+        ranked = [int(code) for code in self.rank_mc[i] if code != 0xFF and c[code]][:nd]
+        kp = int(self.keep[i])
+        return [lab[1:] + self.chars[code] for code in ranked if not pruned or (kp >> code) & 1]
+
+    def edge_names(self, i):
+        lab = self.label(i)
+        c = self.counts[i]
+        return [(lab + self.chars[code], int(c[code])) for code in self.rank_fs[i] if code != 0xFF and c[code]]
+
+
+class _LazyVertices(Mapping):
+    """``vertices``: label -> Node, dict order; nothing is materialised until it is asked for."""
+
+    def __init__(self, store):
+        self._s = store
+        self._graph = None
+        self._state = None
+
+    def __len__(self):
+        return self._s.n
+
+    def __iter__(self):
+        for lo in range(0, self._s.n, 1 << 16):
+            yield from self._s.labels(np.arange(lo, min(lo + (1 << 16), self._s.n)))
+
+    def __contains__(self, lab):
+        return self._s.find(lab) >= 0
+
+    def __getitem__(self, lab):
+        i = self._s.find(lab)
+        if i < 0:
+            raise KeyError(lab)
+        return Node(lab, int(self._s.indeg[i]), int(self._s.outdeg[i]))
+
+
+class _LazyEdges(Mapping):
+    """``edges``: label -> surviving successor labels, for every node that was not pulled out."""
+
+    def __init__(self, store):
+        self._s = store
+        self._alive = np.nonzero(~store.pulled)[0]
+
+    def __len__(self):
+        return int(self._alive.size)
+
+    def __iter__(self):
+        for lo in range(0, self._alive.size, 1 << 16):
+            yield from self._s.labels(self._alive[lo:lo + (1 << 16)])
+
+    def __contains__(self, lab):
+        i = self._s.find(lab)
+        return i >= 0 and not self._s.pulled[i]
+
+    def __getitem__(self, lab):
+        i = self._s.find(lab)
+        if i < 0 or self._s.pulled[i]:
+            raise KeyError(lab)
+        return self._s.successors(i, True)
+
+
+class _LazyEdgeCounts(Mapping):
+    """``edge_count_table``: (k+1)-mer -> multiplicity, in the reference's insertion order."""
+
+    def __init__(self, store):
+        self._s = store
+        self._n = int((store.counts != 0).sum())
+
+    def __len__(self):
+        return self._n
+
+    def __iter__(self):
+        for i in range(self._s.n):
+            for name, _ in self._s.edge_names(i):
+                yield name
+
+    def items(self):
+        return _EdgeItems(self)
+
+    def __contains__(self, name):
+        try:
+            self[name]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, name):
+        if not isinstance(name, str) or len(name) != self._s.k + 1:
+            raise KeyError(name)
+        i = self._s.find(name[:-1])
+        code = self._s.code_of.get(name[-1])
+        if i < 0 or code is None or code >= self._s.counts.shape[1] or not self._s.counts[i, code]:
+            raise KeyError(name)
+        return int(self._s.counts[i, code])
+
+
+class _EdgeItems(ItemsView):
+    def __iter__(self):
+        s = self._mapping._s
+        for i in range(s.n):
+            yield from s.edge_names(i)
+
+
 class _Tracked(list):
     """list that remembers which construct_graph call produced it."""
     _token = None
@@ -158,7 +332,6 @@ def construct_graph(reads, k, threshold=3, final=False):
     chars = alphabet.decode("latin-1")
     order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
     keys_hi = g.export_keys_hi()[order] if bits * k > 64 else None
-    labels = _dbg.decode_keys(keys[order], k, alphabet, bits, keys_hi)
     counts_o = counts[order]
     rank_mc, rank_fs = rank_mc[order], rank_fs[order]
     flags_o = flags[order]
@@ -168,10 +341,16 @@ def construct_graph(reads, k, threshold=3, final=False):
     keep_o = g.export_keepmask()[order]
     n_ranks = rank_mc.shape[1]
 
-    vertices = _Vertices()
-    edges = {}
-    ect = {}
-    for i, lab in enumerate(labels):
+    lazy = len(order) >= LAZY_MIN_NODES
+    if lazy:
+        store = _NodeStore(k, alphabet, bits, keys[order], keys_hi, counts_o, rank_mc, rank_fs, indeg, outdeg, pulled_o, keep_o)
+        vertices, edges, ect = _LazyVertices(store), _LazyEdges(store), _LazyEdgeCounts(store)
+        take = store.labels
+    else:
+        labels = _dbg.decode_keys(keys[order], k, alphabet, bits, keys_hi)
+        vertices, edges, ect = _Vertices(), {}, {}
+        take = lambda idx: [labels[i] for i in idx]
+    for i, lab in enumerate(labels if not lazy else ()):
         vertices[lab] = Node(lab, int(indeg[i]), int(outdeg[i]))
         c = counts_o[i]
         tail = lab[1:]
@@ -188,7 +367,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     ranks = g.export_pull_ranks()[order]
     pulled_idx = np.nonzero(pulled_o)[0]
     pulled_idx = pulled_idx[np.argsort(ranks[pulled_idx], kind="stable")]
-    already_pull_out = _Tracked(labels[i] for i in pulled_idx)
+    already_pull_out = _Tracked(take(pulled_idx))
 
     if final:  # debruijn.py:281-283
         pull_out_read = []
@@ -196,7 +375,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     else:
         rf = g.export_pull_reads()
         pull_out_read = [reads[i] for i in np.nonzero(rf)[0]]
-        branch_kmer = _Tracked(labels[i] for i in np.nonzero(flags_o & _dbg.F_BRANCH)[0])
+        branch_kmer = _Tracked(take(np.nonzero(flags_o & _dbg.F_BRANCH)[0]))
 
     token = object()
     vertices._graph = g

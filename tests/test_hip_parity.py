@@ -100,6 +100,43 @@ def test_fuzz_family_against_reference_vectors(family, n_min):
     assert n >= n_min
 
 
+@pytest.mark.parametrize("name", [n for n in golden_case_names()
+                                  if n.startswith(("peptide_k3", "hand_tips_order_t2", "hand_cycle_t2", "dna_small", "dna_med_k31_e1_t2",
+                                                   "dna_med_k63_e1"))])
+def test_lazy_views_equal_the_dicts(name, monkeypatch):
+    """Above LAZY_MIN_NODES construct_graph returns Mapping views over the exported arrays (dicts are
+    infeasible at 10^8 nodes); materialised they equal the reference's dicts, order included."""
+    import debruijn as prod
+    monkeypatch.setattr(prod, "LAZY_MIN_NODES", 0)
+    case = load_golden(name)
+    reads = case_reads(case)
+    inp = case["inputs"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        (V, E), pull, branch, pulled, ect = prod.construct_graph(list(reads), inp["k"], threshold=inp["threshold"],
+                                                                final=inp["final"])
+        contigs = prod.output_contigs((V, E), branch, pulled)
+    assert not isinstance(V, dict) and not isinstance(E, dict) and not isinstance(ect, dict)
+    got = canonical((V, E), pull, branch, pulled, ect, contigs)
+    got["stdout"], got["scores"] = None, list(contigs.scores)
+    want = run_oracle(reads, inp["k"], inp["threshold"], inp["final"])
+    want["stdout"] = None
+    assert_same(got, want, inp["final"], name + " (lazy)")
+    # the Mapping protocol
+    wV = dict((v, (i, o)) for v, i, o in want["vertices"])
+    assert len(V) == len(wV) and len(E) == len(want["edges"]) and len(ect) == len(want["edge_count_table"])
+    assert E == dict((v, s) for v, s in want["edges"]) and ect == dict(map(tuple, want["edge_count_table"]))
+    assert list(ect.items()) == list(map(tuple, want["edge_count_table"]))
+    k = inp["k"]
+    for bogus in ("", "?" * k, "A" * (k + 1), None, 7):
+        assert bogus not in V and bogus not in E and bogus not in ect
+        with pytest.raises(KeyError):
+            V[bogus]
+    for v in list(wV)[:50]:
+        assert v in V and (V[v].label, V[v].indegree, V[v].outdegree) == (v, *wV[v])
+    for v in pulled:
+        assert v in V and v not in E
+
+
 def test_other_alphabets_take_the_generic_path():
     """N, lower case, digits ...: distinct characters like in the reference (str slices), never dropped."""
     for reads, k in ((["ACGTN", "ACGTA", "NNACG"], 3), (["acgtacgt", "ACGTacgt"], 3), (["0120120", "1201"], 2)):

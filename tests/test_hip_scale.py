@@ -10,6 +10,75 @@ from oracle import orc_c
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("err,final", [(0.0, False), (0.01, False), (0.0, True)])  # final mode with errors: all simple paths, exponential
+def test_config1_whole_path_vs_oracle(err, final):
+    """BASELINE.json configs[0]: 10k x 100 bp, k = 21 (10x coverage of a 100 kbp genome): the whole drop-in
+    surface against the Python oracle, orders included."""
+    import contextlib
+    import io
+    import debruijn as prod
+    from golden_util import canonical
+    from oracle import dbg_oracle as orc
+    reads = synth.reads_list(1, 100_000, 10_000, 100, err)
+    res = []
+    for mod in (prod, orc):
+        with contextlib.redirect_stdout(io.StringIO()) as buf:
+            g, pull, branch, pulled, ect = mod.construct_graph(list(reads), 21, threshold=2, final=final)
+            contigs = mod.output_contigs(g, branch, pulled)
+        r = canonical(g, pull, branch, pulled, ect, contigs)
+        r["stdout"] = buf.getvalue()
+        res.append(r)
+    for field in res[1]:
+        assert res[0][field] == res[1][field], field
+    assert len(res[0]["vertices"]) > 90_000 and res[0]["contigs"]
+
+
+def test_drop_in_surface_at_two_million_reads():
+    """construct_graph on 2M x 150 bp (6.7e7 nodes): the Python surface stays usable through the lazy views."""
+    import contextlib
+    import io
+    import debruijn as prod
+    n, L, k, G = 2_000_000, 150, 31, 10_000_000
+    g0 = _dbg.Graph()
+    g0.synth_reads(1, G, n, L, 0.01)
+    bases, off = g0.copy_reads()
+    g0.close()
+    text = bases.tobytes().decode("ascii")
+
+    class Reads:  # a list-like over the packed buffer (2M Python strings would work too, this is cheaper)
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return text[int(off[i]):int(off[i + 1])]
+
+        def __iter__(self):
+            return (self[i] for i in range(n))
+
+    dev = _dbg.Graph()
+    dev.set_reads(bases, off)
+    reads = prod.DeviceReads.__new__(prod.DeviceReads)  # adopt the resident reads
+    reads._graph, reads._n, reads._host = dev, n, (text, off)
+    with contextlib.redirect_stdout(io.StringIO()) as buf:
+        (V, E), pull, branch, pulled, ect = prod.construct_graph(reads, k, threshold=2)
+    assert not isinstance(V, dict) and len(V) > 5 * 10**7
+    assert buf.getvalue().startswith("number of 31mer:  %d\n" % len(V))
+    it = iter(V)
+    first = [next(it) for _ in range(1000)]
+    assert first[0] == text[:k] and V[first[0]].indegree == 0          # dict order starts at read 0, position 0
+    for lab in first[:200]:
+        nd = V[lab]
+        assert nd.label == lab and nd.outdegree == sum((lab + c) in ect for c in "ACGT")
+        if lab in E:
+            assert all(s in V and s[:-1] == lab[1:] for s in E[lab])
+    assert len(E) == len(V) - len(pulled)
+    assert len(branch) and all(len(E[b]) > 1 for b in branch[:200])   # branch nodes are never pulled out
+    bs = set(branch)
+    assert len(pull) and all(any(r[i:i + k] in bs for i in range(len(r) - k + 1)) for r in pull[:20])
+    some = text[150 * 777:150 * 777 + k + 1]                           # an edge that certainly exists
+    assert ect[some] >= 1 and some in ect
+
+
 def test_one_million_reads_vs_c_oracle():
     n, L, k = 1_000_000, 150, 31
     reads = synth.reads_ascii(1, 5_000_000, n, L, 0.01)
