@@ -105,7 +105,7 @@ void dbg_destroy(dbg_t *h);
 const char *dbg_last_error(const dbg_t *h);
 int dbg_abi_version(void);
 /* Tunables (no reference counterpart): "engine" 0 = partitioned super-k-mer build (default),
- * 1 = single global hash table; "bucket_bits" 0 = auto, else log2 of the bucket count (<= 18);
+ * 1 = single global hash table; "bucket_bits" 0 = auto, else log2 of the bucket count (<= 20);
  * "lds_slots" 2048 or 4096 slots of the per-bucket LDS table; "walk_jump_min_nodes" see dbg_walk;
  * "phase_limit" timing ablation of the count kernel (the build then fails on purpose). */
 int dbg_set_option(dbg_t *h, const char *name, int64_t value);

@@ -1501,7 +1501,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (!h || !name) return DBG_E_ARG;
     const std::string n(name);
     if (n == "engine" && (value == 0 || value == 1)) { h->engine = (int)value; return DBG_OK; }
-    if (n == "bucket_bits" && value >= 0 && value <= 19) { h->bucket_bits = (int)value; return DBG_OK; }
+    if (n == "bucket_bits" && value >= 0 && value <= 20) { h->bucket_bits = (int)value; return DBG_OK; }
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
@@ -2302,7 +2302,10 @@ static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2]
     uint64_t n_rec = 0;
     Timer t(h->stream);
     const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
-    uint64_t seg_cap = (w == 1) ? tiles_per_wg * TILE : tiles_per_wg * (TILE / 3 + 8) + 256;
+    // records per position: a window of w k-mers changes its minimizer about every (w + 1) / 2 positions, plus one
+    // record per read; sized at 1.3x that, and the second attempt (one record per position) cannot overflow
+    const double density = std::min(1.0, 2.6 / (double)(w + 1) + 1.3 * (double)(h->n_reads + 1) / (double)(h->n_bytes + 1) + 0.01);
+    uint64_t seg_cap = (w == 1) ? tiles_per_wg * TILE : (uint64_t)((double)(tiles_per_wg * TILE) * density) + 256;
     for (int attempt = 0; attempt < 2; ++attempt) {
         const uint64_t rec_cap = seg_cap * n_wg;
         for (int set = 0; set < 2; ++set) {
@@ -2371,7 +2374,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     // ---- bucket geometry.  Level 1 takes up to 9 bits of the bucket hash; the remaining bits are
     //      chosen after level 1 from a distinct-k-mer estimate on one level-1 bucket (auto mode).
     constexpr double TARGET_DISTINCT = CAP * 0.36;  // mean distinct k-mers per final bucket (table ~1/3 full: measured optimum)
-    constexpr int T_MAX = 19;                       // 9 + 10 bits over the two multisplit levels
+    constexpr int T_MAX = 20;                       // up to 10 + 10 bits over the two multisplit levels
     const double own = shard_bits ? (double)(1 << shard_bits) : 1.0;  // buckets are spread over `own` shards
     int T = h->bucket_bits;
     const bool auto_T = (T == 0);
@@ -2380,18 +2383,19 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         while (T < T_MAX && (double)(1ull << T) < want) ++T;
     }
     if (T < shard_bits) T = shard_bits;
-    int l1 = T < 9 ? T : 9, l2 = T - l1;
+    int l1 = T < 9 ? T : (T >= 20 ? 10 : 9), l2 = T - l1;  // level 1 is fixed before the estimate refines T
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
     int where = 0;
+    double est_distinct = 0.0;  // distinct k-mers of this shard, from the level-1 sample (0 = unknown)
     const int top = 6 + SK_BUCKET_BITS;
     Timer t_part(h->stream);
     CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, true, n_rec, in_w0, in_w1, in_st, w0[1], w1[1], st[1],
                                     top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
     where = 1;
-    if (auto_T && l1 == 9 && n_rec) {  // refine T from a sample: the first level-1 bucket this shard owns
-        const uint32_t probe_bucket = shard_bits ? (uint32_t)my_shard << (9 - shard_bits) : 0u;
+    if (auto_T && l1 >= 9 && n_rec) {  // refine T from a sample: the first level-1 bucket this shard owns
+        const uint32_t probe_bucket = shard_bits ? (uint32_t)my_shard << (l1 - shard_bits) : 0u;
         const uint64_t inst_bucket = (uint64_t)((double)n_inst * own / nb1) * 2 + 1024;
         uint64_t set_cap = 1024;
         while (set_cap < inst_bucket * 2) set_cap <<= 1;
@@ -2406,8 +2410,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (est[0]) {
             const double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
-            T = 9;
-            while (T < T_MAX && (double)(1ull << T) < distinct / TARGET_DISTINCT) ++T;
+            est_distinct = distinct / own;
+            T = l1;  // a fuller table (up to 1.2x the target) beats twice the buckets: the per-bucket cost is fixed
+            while (T < l1 + 10 && (double)(1ull << T) * 1.2 < distinct / TARGET_DISTINCT) ++T;
             l2 = T - l1;
         }
     }
@@ -2426,38 +2431,46 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     h->stats.ms_partition = t_part.stop();
     h->stats.n_buckets = n_buckets;
 
-    // ---- K5: per-bucket counting
-    uint64_t node_cap = node_capacity_hint ? node_capacity_hint : n_inst;
+    // ---- K5: per-bucket counting.  Node and edge arrays are sized from the distinct-k-mer estimate (58 B per node:
+    //      the worst case "every instance distinct" would not fit the HBM beyond ~3e9 instances); if the estimate
+    //      was low the kernel reports it and the second attempt takes the worst case.
     const uint64_t id_limit = shard_bits ? ((1ull << 29) - 16) : 0xFFFFFFF0ull;  // sharded ids carry the owner in bits 31:29
-    if (node_cap > id_limit) node_cap = id_limit;
-    CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
-    CHK(buf_ensure(h, h->ar_node[1], node_cap * 8));
-    CHK(buf_ensure(h, h->ar_node[2], node_cap * 16));
-    CHK(buf_ensure(h, h->ar_node[3], node_cap));
-    CHK(buf_ensure(h, h->ar_node[4], node_cap));
-    CHK(buf_ensure(h, h->ar_node[5], node_cap * 16));
-    h->d_keys = (uint64_t *)h->ar_node[0].p;
-    h->d_stamps = (uint64_t *)h->ar_node[1].p;
-    h->d_cnt = (uint32_t *)h->ar_node[2].p;
-    h->d_flags = (uint8_t *)h->ar_node[3].p;
-    h->d_order = (uint8_t *)h->ar_node[4].p;
-    h->d_succ = (uint32_t *)h->ar_node[5].p;
-    h->nodes_in_arena = true;
-    uint64_t edge_cap = n_edge_inst + 16;
-    if (edge_cap > 0xFFFFFFF0ull) edge_cap = 0xFFFFFFF0ull;
-    CHK(buf_ensure(h, h->ar_csr[0], (node_cap + 1) * 8));
-    CHK(buf_ensure(h, h->ar_csr[1], edge_cap * 4));
-    CHK(buf_ensure(h, h->ar_csr[2], edge_cap * 4));
-    h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
-    h->d_col = (uint32_t *)h->ar_csr[1].p;
-    h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
+    const uint64_t node_cap_max = std::min<uint64_t>(n_inst, id_limit);
+    const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
+    uint64_t node_cap = node_capacity_hint ? std::min<uint64_t>(node_capacity_hint, id_limit) : node_cap_max;
+    if (!node_capacity_hint && est_distinct > 0.0)
+        node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2) + (1u << 20));
+    uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
+    auto ensure_node_arrays = [&]() -> int {
+        CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
+        CHK(buf_ensure(h, h->ar_node[1], node_cap * 8));
+        CHK(buf_ensure(h, h->ar_node[2], node_cap * 16));
+        CHK(buf_ensure(h, h->ar_node[3], node_cap));
+        CHK(buf_ensure(h, h->ar_node[4], node_cap));
+        CHK(buf_ensure(h, h->ar_node[5], node_cap * 16));
+        h->d_keys = (uint64_t *)h->ar_node[0].p;
+        h->d_stamps = (uint64_t *)h->ar_node[1].p;
+        h->d_cnt = (uint32_t *)h->ar_node[2].p;
+        h->d_flags = (uint8_t *)h->ar_node[3].p;
+        h->d_order = (uint8_t *)h->ar_node[4].p;
+        h->d_succ = (uint32_t *)h->ar_node[5].p;
+        h->nodes_in_arena = true;
+        CHK(buf_ensure(h, h->ar_csr[0], (node_cap + 1) * 8));
+        CHK(buf_ensure(h, h->ar_csr[1], edge_cap * 4));
+        CHK(buf_ensure(h, h->ar_csr[2], edge_cap * 4));
+        h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
+        h->d_col = (uint32_t *)h->ar_csr[1].p;
+        h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
+        return DBG_OK;
+    };
     uint64_t q_cap = n_rec + 1024;
     uint64_t *qk[2], *qm[2];
     uint32_t *qc[2];
     const uint64_t range_cap = n_buckets + 4096 + n_inst / (CAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        CHK(ensure_node_arrays());
         for (int set = 0; set < 2; ++set) {
             CHK(buf_ensure(h, h->ar_q[set][0], q_cap * 8));
             CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
@@ -2495,8 +2508,15 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (h->phase_limit) { h->err = "ablation run (phase_limit set): timing only"; return DBG_E_ARG; }
         // buckets that had to be split by hash sub-range turn in-bucket successors into queries:
         // the usual bound (one query per record) no longer holds, retry with the safe one
-        if ((sc[0] & 64) && !(sc[0] & (8 | 16 | 32)) && attempt == 0) { q_cap = n_edge_inst + 1024; continue; }
-        break;
+        if (sc[0] & (8 | 32)) break;  // not a sizing problem
+        bool again = false;
+        if ((sc[0] & 16) && (node_cap < node_cap_max || edge_cap < edge_cap_max) && !node_capacity_hint) {
+            node_cap = node_cap_max;  // the estimate was low
+            edge_cap = edge_cap_max;
+            again = true;
+        }
+        if ((sc[0] & 64) && q_cap < n_edge_inst + 1024) { q_cap = n_edge_inst + 1024; again = true; }
+        if (!again || attempt == 2) break;
     }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
                 }
             }
             if ((cur >> 48) == (mine >> 48) && k128_eq(packed_kmer(pk, (cur & W_STAMP_MASK) >> 1, k), in.key)) {
-                atomicMin(&tab[slot], mine);  // same fingerprint: the smaller value is the earlier instance
+                // same fingerprint: the smaller value is the earlier instance.  Most instances are not the first
+                // of their k-mer (30x coverage) and skip the atomic: the slot only ever decreases
+                if (mine < cur) atomicMin(&tab[slot], mine);
                 found = true;
                 break;
             }

@@ -200,6 +200,28 @@ def test_full_size_invariants(err):
     assert np.array_equal(counts[a], counts2[b])
 
 
+def test_twenty_five_million_reads_fit_one_gpu():
+    """2.5x BASELINE configs[1]: node and edge arrays are sized from the distinct-k-mer estimate (the worst case
+    would need 3e9 x 58 B), 2^19..2^20 buckets.  Sizes and CSR sums only: the node exports would be 50 GB."""
+    n, L, k = 25_000_000, 150, 31
+    g = _dbg.Graph()
+    g.synth_reads(1, n * 5, n, L, 0.01)
+    g.build(k)
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == n * (L - k + 1) and sz["n_edge_instances"] == n * (L - k)
+    assert 8.5e8 < sz["n_nodes"] < 9.5e8 and sz["n_nodes"] <= sz["n_edges"] + n  # only read-final k-mers lack a successor
+    rp, col, cnt = g.export_csr()
+    assert rp[-1] == sz["n_edges"] == col.size
+    assert int(cnt.sum(dtype=np.uint64)) == sz["n_edge_instances"]  # every (k+1)-mer instance counted exactly once
+    assert int(col.max()) < sz["n_nodes"] and np.all(np.diff(rp.astype(np.int64)) <= 4)
+    g.prune(2)
+    g.remove_tips()
+    g.mark_pull_reads()
+    g.walk(False, 1 << 20)
+    sz = g.sizes()
+    assert sz["n_contigs"] == sz["n_starts"] > 0 and sz["n_branch"] > 0
+
+
 def test_reads_beyond_2_gib_use_64bit_stamps():
     """15M x 150 bp = 2.25 GB of reads: byte offsets no longer fit the 32-bit stamp, the build switches to
     64-bit stamps (smaller LDS staging); same invariants as at the BASELINE size."""
