@@ -2578,9 +2578,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
                 HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
             }
             auto kern = k_q_answer<CAP>;
-            const size_t lds = sizeof(AnsLds<CAP>);
-            HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt,
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), 0, h->stream, ranges, q_start, q_cnt,
                                qk2[qwhere], qm2[qwhere], qc2[qwhere], h->d_keys, h->d_succ, h->d_col,
                                shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev);
             HIPCHK(h, hipGetLastError());
@@ -2804,9 +2802,7 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     }
     const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;
     auto kern = k_q_answer<4096>;
-    const size_t lds = sizeof(AnsLds<4096>);
-    HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)h->sk_n_ranges), dim3(256), lds, h->stream, ranges, q_start, q_cnt, qk[qwhere],
+    hipLaunchKernelGGL(kern, dim3((unsigned)h->sk_n_ranges), dim3(256), 0, h->stream, ranges, q_start, q_cnt, qk[qwhere],
                        qm[qwhere], (const uint32_t *)nullptr, h->d_keys, (uint32_t *)d_answers, (uint32_t *)nullptr, 0u, sc_dev);
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;

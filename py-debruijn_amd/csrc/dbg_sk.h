@@ -1106,45 +1106,73 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
 // ------------------------------------------------------------------------------------------------
 // K8: answer the cross-bucket successor queries of one counted range
 // ------------------------------------------------------------------------------------------------
-template <int CAP>
+// The LDS table holds the QUERIES of the range's bucket (about a tenth of its node count) and the range's
+// node keys stream past it: a node that nobody asks for costs one LDS read (its home slot is empty), the
+// table is 10 KB instead of 40 KB (8 workgroups per CU instead of 4: this kernel is a chain of dependent
+// global loads, occupancy is what hides them) and there is no 4096-slot clear per range.
+constexpr int ANS_SLOTS = 1024;  // query slots per pass
+constexpr int ANS_CHUNK = 512;   // queries per pass: the table stays at most half full, probes always end
 struct AnsLds {
-    unsigned long long keys[CAP];
-    uint16_t idx[CAP];
+    unsigned long long keys[ANS_SLOTS];
+    uint16_t qi[ANS_SLOTS];  // slot -> query index within the pass (equal keys take separate slots)
+    uint32_t n_want, n_hit;
 };
 
-template <int CAP>
+template <int CAP /* table size of the count kernel: not used here */>
 __global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ q_start,
                                                   const uint64_t *__restrict__ q_cnt, const uint64_t *__restrict__ q_key,
                                                   const uint64_t *__restrict__ q_meta, const uint32_t *__restrict__ q_col,
                                                   const uint64_t *__restrict__ keys, uint32_t *succ, uint32_t *col,
                                                   uint32_t id_tag, unsigned long long *scalars) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ans_raw[];
-    AnsLds<CAP> &s = *reinterpret_cast<AnsLds<CAP> *>(ans_raw);
+    __shared__ AnsLds s;
     const SkRange rg = ranges[blockIdx.x];
     if (rg.node_cnt == 0) return;  // bucket that was empty or was split into sub-ranges
     const uint64_t qn = q_cnt[rg.bucket];
     if (qn == 0) return;
-    for (int i = threadIdx.x; i < CAP; i += 256) s.keys[i] = EMPTY_KEY;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < rg.node_cnt; i += 256) {
-        const unsigned long long key = keys[rg.node_base + i];
-        uint32_t slot = slot_of<CAP>(key);
-        for (int probe = 0; probe < CAP; ++probe) {
-            const unsigned long long cur = atomicCAS(&s.keys[slot], EMPTY_KEY, key);
-            if (cur == EMPTY_KEY) { s.idx[slot] = (uint16_t)i; break; }
-            slot = (slot + 1) & (CAP - 1);
-        }
-    }
-    __syncthreads();
     const uint64_t qb = q_start[rg.bucket];
-    for (uint64_t i = threadIdx.x; i < qn; i += 256) {
-        const uint64_t skey = q_key[qb + i];
-        if (rg.mask && (sub_hash(skey) & rg.mask) != rg.val) continue;
-        const int f = lds_find<CAP>(s.keys, skey);
-        if (f < 0) { atomicOr(&scalars[0], 128ull); continue; }  // every successor exists as a node
-        const uint32_t id = (uint32_t)(rg.node_base + s.idx[f]) | id_tag;
-        succ[q_meta[qb + i] & ((1ull << 40) - 1)] = id;
-        if (col) col[q_col[qb + i]] = id;
+    for (uint64_t c0 = 0; c0 < qn; c0 += ANS_CHUNK) {
+        const uint32_t nc = (uint32_t)min((uint64_t)ANS_CHUNK, qn - c0);
+        __syncthreads();  // the previous pass is done with the table
+        for (int i = threadIdx.x; i < ANS_SLOTS; i += 256) s.keys[i] = EMPTY_KEY;
+        if (threadIdx.x == 0) { s.n_want = 0; s.n_hit = 0; }
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < nc; i0 += 256) {  // uniform trip count
+            const uint32_t i = i0 + threadIdx.x;
+            unsigned long long skey = 0;
+            bool mine = i < nc;
+            if (mine) {
+                skey = q_key[qb + c0 + i];
+                if (rg.mask && (sub_hash(skey) & rg.mask) != rg.val) mine = false;  // another sub-range of the bucket
+            }
+            const unsigned long long m = __ballot(mine);
+            if (m && lanes_below(m) == 0 && mine) atomicAdd(&s.n_want, (uint32_t)__popcll(m));
+            if (mine) {
+                uint32_t slot = slot_hash(skey) >> 22;
+                while (atomicCAS(&s.keys[slot], EMPTY_KEY, skey) != EMPTY_KEY) slot = (slot + 1) & (ANS_SLOTS - 1);
+                s.qi[slot] = (uint16_t)i;
+            }
+        }
+        __syncthreads();
+        if (s.n_want) {  // uniform
+            for (uint32_t j = threadIdx.x; j < rg.node_cnt; j += 256) {
+                const unsigned long long key = keys[rg.node_base + j];
+                uint32_t slot = slot_hash(key) >> 22;
+                for (;;) {
+                    const unsigned long long cur = s.keys[slot];
+                    if (cur == EMPTY_KEY) break;
+                    if (cur == key) {  // every query for this k-mer sits in the same probe run
+                        const uint64_t q = qb + c0 + s.qi[slot];
+                        const uint32_t id = (uint32_t)(rg.node_base + j) | id_tag;
+                        succ[q_meta[q] & ((1ull << 40) - 1)] = id;
+                        if (col) col[q_col[q]] = id;
+                        atomicAdd(&s.n_hit, 1u);
+                    }
+                    slot = (slot + 1) & (ANS_SLOTS - 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s.n_hit != s.n_want) atomicOr(&scalars[0], 128ull);  // every successor exists as a node
     }
 }
 
