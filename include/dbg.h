@@ -126,6 +126,8 @@ int dbg_synth_reads(dbg_t *h, uint64_t seed, uint64_t genome_len, uint64_t first
                     uint32_t read_len, uint32_t err_thr24);
 int dbg_reads_checksum(dbg_t *h, uint64_t *out);              /* synth.checksum twin */
 int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets); /* D2H of the current read set */
+/* device pointers of the current read set (bases: n_bytes chars; offsets: u64[n_reads + 1]); valid until the reads change */
+int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_bytes, const void **d_offsets, uint64_t *n_reads);
 
 /* ---- a3 + a4: get_graph_from_reads (debruijn.py:98-147) + edge-count table (:213-222)
  *      -> node table, 4-way successor edges, CSR ------------------------------------ */
@@ -214,6 +216,14 @@ int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w
 int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void *d_answers);
 /* step 4: d_answers (uint32, device) laid out like *d_q_keys of step 2; completes successors + CSR */
 int dbg_shard_apply(dbg_t *h, const void *d_answers);
+/* Traversal after a sharded build ("gather first"): the shards' node arrays, concatenated in shard
+ * order on one GPU (device pointers: keys u64[n], stamps u64[n], counts u32[n][4], succ u32[n][4] with ids
+ * (owner << 29) | id), become the graph of handle `h`, whose reads must be the rank-major concatenation of all
+ * ranks' reads (the global stamps index into it).  Successor ids are rewritten to positions in the concatenation;
+ * afterwards the handle is what dbg_build would have produced on the whole read set (node order aside):
+ * dbg_refine_edge_order, dbg_prune, dbg_remove_tips, dbg_mark_pull_reads, dbg_walk and the exports apply. */
+int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *shard_nodes, const void *d_keys,
+                     const void *d_stamps, const void *d_counts, const void *d_succ);
 
 #ifdef __cplusplus
 }

@@ -23,13 +23,14 @@ ABI_VERSION = 1
 SYMBOLS = (
     "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_fasta",
     "dbg_set_reads_device",
-    "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
+    "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_reads_device", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
     "dbg_get_alphabet", "dbg_export_keepmask",
     "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_keys_hi",
     "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
+    "dbg_import_graph",
 )
 
 
@@ -115,6 +116,8 @@ def load_library():
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_shard_apply": (C.c_int, [H, vp]),
+        "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp]),
+        "dbg_reads_device": (C.c_int, [H, C.POINTER(vp), u64p, C.POINTER(vp), u64p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -370,6 +373,34 @@ class Graph:
     def shard_apply(self, answers):
         self._chk(self._lib.dbg_shard_apply(self._h, C.c_void_p(answers.data_ptr()) if answers.numel() else None))
 
+    # ---- gather for traversal (multi_gpu.gather_graph)
+    def node_tensors(self):
+        """Zero-copy torch views of this handle's node arrays: keys, stamps (int64 [n]), counts, succ (int32 [4 n])."""
+        p = [C.c_void_p() for _ in range(5)]
+        self._chk(self._lib.dbg_device_views(self._h, *[C.byref(x) for x in p]))
+        n, dev = self.sizes()["n_nodes"], self.sizes_device()
+        return {"keys": device_tensor(p[0].value, n, "int64", dev), "stamps": device_tensor(p[2].value, n, "int64", dev),
+                "counts": device_tensor(p[1].value, 4 * n, "int32", dev), "succ": device_tensor(p[4].value, 4 * n, "int32", dev)}
+
+    def reads_tensors(self):
+        """Zero-copy torch views of the resident reads: (bases uint8 [n_bytes], offsets int64 [n_reads + 1])."""
+        pb, po, nb, nr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.dbg_reads_device(self._h, C.byref(pb), C.byref(nb), C.byref(po), C.byref(nr)))
+        dev = self.sizes_device()
+        return device_tensor(pb.value, nb.value, "uint8", dev), device_tensor(po.value, nr.value + 1, "int64", dev)
+
+    def set_reads_tensors(self, bases, offsets):
+        """Adopt reads held in torch tensors on this handle's device (kept alive by the handle)."""
+        self.set_reads_device(bases.data_ptr(), bases.numel(), offsets.data_ptr(), offsets.numel() - 1,
+                              keepalive=(bases, offsets))
+
+    def import_graph(self, k, shard_nodes, keys, stamps, counts, succ):
+        """Install the concatenated shard arrays (torch tensors on this device) as this handle's graph."""
+        sn = (C.c_uint64 * len(shard_nodes))(*[int(x) for x in shard_nodes])
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t.numel() else None
+        self._chk(self._lib.dbg_import_graph(self._h, int(k), len(shard_nodes), sn, ptr(keys), ptr(stamps), ptr(counts),
+                                             ptr(succ)))
+
 
 class _DevView:
     """Zero-copy torch view of library-owned device memory (``__cuda_array_interface__``)."""
@@ -380,10 +411,10 @@ class _DevView:
 
 def device_tensor(ptr, n, dtype, device_index):
     import torch
-    tdtype = {"int64": torch.int64, "int32": torch.int32}[dtype]
+    tdtype = {"int64": torch.int64, "int32": torch.int32, "uint8": torch.uint8}[dtype]
     if n == 0 or not ptr:
         return torch.empty(0, dtype=tdtype, device=f"cuda:{device_index}")
-    return torch.as_tensor(_DevView(ptr, n, {"int64": "<i8", "int32": "<i4"}[dtype]), device=f"cuda:{device_index}")
+    return torch.as_tensor(_DevView(ptr, n, {"int64": "<i8", "int32": "<i4", "uint8": "|u1"}[dtype]), device=f"cuda:{device_index}")
 
 
 # ---- 2-bit key <-> str helpers (host side of the boundary) -------------------------------

@@ -2192,6 +2192,15 @@ extern "C" int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint
     return DBG_OK;
 }
 
+extern "C" int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_bytes, const void **d_offsets, uint64_t *n_reads) {
+    if (!h || !h->d_offsets) { if (h) h->err = "no reads set"; return DBG_E_ARG; }
+    if (d_bases) *d_bases = h->d_bases;
+    if (n_bytes) *n_bytes = h->n_bytes;
+    if (d_offsets) *d_offsets = h->d_offsets;
+    if (n_reads) *n_reads = h->n_reads;
+    return DBG_OK;
+}
+
 extern "C" int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const void **d_stamps,
                                 const void **d_flags, const void **d_succ) {
     if (!h || !h->k) return DBG_E_ARG;
@@ -2809,6 +2818,105 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (sc0 & 128) { h->err = "a queried successor k-mer is not a node of this shard"; return DBG_E_HIP; }
+    return DBG_OK;
+}
+
+// ---- gathered graph: node arrays of all shards, concatenated in shard order, become this handle's graph
+__global__ __launch_bounds__(256) void k_import_fix(uint64_t n_nodes, const uint64_t *__restrict__ stamps,
+                                                    const uint32_t *__restrict__ cnt, uint32_t *succ,
+                                                    const uint64_t *__restrict__ shard_base /* [8] */, uint8_t *flags,
+                                                    uint8_t *order, uint8_t *deg, unsigned long long *scalars) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint4 c4 = reinterpret_cast<const uint4 *>(cnt)[i];
+    const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+    uint4 s4 = reinterpret_cast<const uint4 *>(succ)[i];
+    uint32_t s[4] = {s4.x, s4.y, s4.z, s4.w};
+    unsigned long long edges = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        edges += c[b];
+        if (s[b] == NO_NODE) {
+            if (c[b]) atomicOr(&scalars[0], 512ull);  // a counted successor without a node
+            continue;
+        }
+        const uint64_t id = shard_base[s[b] >> 29] + (s[b] & ((1u << 29) - 1));
+        if (id >= n_nodes) { atomicOr(&scalars[0], 512ull); s[b] = NO_NODE; continue; }
+        s[b] = (uint32_t)id;
+    }
+    reinterpret_cast<uint4 *>(succ)[i] = make_uint4(s[0], s[1], s[2], s[3]);
+    flags[i] = (uint8_t)(stamps[i] & 1);
+    deg[i] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
+    uint32_t r1 = 0, r2 = 0, r3 = 0;  // rank by (count desc, ASCII order A C G T = codes 0 1 3 2), as in k_sk_count
+    { const uint32_t f = c[0] >= c[1]; r1 += f; }
+    { const uint32_t f = c[0] >= c[3]; r3 += f; }
+    { const uint32_t f = c[0] >= c[2]; r2 += f; }
+    { const uint32_t f = c[1] >= c[3]; r3 += f; r1 += 1u - f; }
+    { const uint32_t f = c[1] >= c[2]; r2 += f; r1 += 1u - f; }
+    { const uint32_t f = c[3] >= c[2]; r2 += f; r3 += 1u - f; }
+    order[i] = (uint8_t)((1u << (2 * r1)) | (2u << (2 * r2)) | (3u << (2 * r3)));
+    edges = wave_sum_u64(edges);
+    if ((threadIdx.x & 63) == 0 && edges) atomicAdd(&scalars[2], edges);
+}
+
+extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *shard_nodes, const void *d_keys,
+                                const void *d_stamps, const void *d_counts, const void *d_succ) {
+    if (!h || !shard_nodes || n_shards < 1 || n_shards > 8) return DBG_E_ARG;
+    if (k < 1 || k > 31) { h->err = "k must be in 1..31"; return DBG_E_ARG; }
+    if (!h->d_offsets) { h->err = "set the gathered reads first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    free_build(h);
+    CHK(compute_alphabet(h));
+    if (!h->is_dna) { h->err = "gathered graphs are ACGT graphs"; return DBG_E_ALPHABET; }
+    uint64_t base[8] = {0}, n = 0;
+    for (int s = 0; s < n_shards; ++s) {
+        base[s] = n;
+        if (shard_nodes[s] >= (1ull << 29)) { h->err = "a shard holds at most 2^29 nodes"; return DBG_E_ARG; }
+        n += shard_nodes[s];
+    }
+    if (n >= 0xFFFFFFF0ull) { h->err = "more than 2^32-16 nodes"; return DBG_E_CAPACITY; }
+    if (n && (!d_keys || !d_stamps || !d_counts || !d_succ)) return DBG_E_ARG;
+    h->k = k;
+    h->stats = dbg_stats_t{};
+    Timer t(h->stream);
+    CHK(buf_ensure(h, h->ar_node[0], n * 8));
+    CHK(buf_ensure(h, h->ar_node[1], n * 8));
+    CHK(buf_ensure(h, h->ar_node[2], n * 16));
+    CHK(buf_ensure(h, h->ar_node[3], n));
+    CHK(buf_ensure(h, h->ar_node[4], n));
+    CHK(buf_ensure(h, h->ar_node[5], n * 16));
+    CHK(buf_ensure(h, h->ar_node[6], n));
+    h->d_keys = (uint64_t *)h->ar_node[0].p;
+    h->d_stamps = (uint64_t *)h->ar_node[1].p;
+    h->d_cnt = (uint32_t *)h->ar_node[2].p;
+    h->d_flags = (uint8_t *)h->ar_node[3].p;
+    h->d_order = (uint8_t *)h->ar_node[4].p;
+    h->d_succ = (uint32_t *)h->ar_node[5].p;
+    h->d_deg = (uint8_t *)h->ar_node[6].p;
+    h->nodes_in_arena = true;
+    h->n_nodes = n;
+    if (n) {
+        HIPCHK(h, hipMemcpyAsync(h->d_keys, d_keys, n * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_stamps, d_stamps, n * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_cnt, d_counts, n * 16, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->d_succ, d_succ, n * 16, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_scalars + 48, base, sizeof(base), hipMemcpyHostToDevice, h->stream));
+    if (n) {
+        hipLaunchKernelGGL(k_import_fix, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_stamps, h->d_cnt, h->d_succ,
+                           h->d_scalars + 48, h->d_flags, h->d_order, h->d_deg, (unsigned long long *)h->d_scalars);
+        HIPCHK(h, hipGetLastError());
+    }
+    uint64_t sc[4] = {0, 0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (sc[0] & 512) { h->err = "gathered successor ids do not fit the shard sizes"; free_build(h); return DBG_E_ARG; }
+    h->n_edge_inst = sc[2];
+    h->n_kmer_inst = 0;  // not carried by the shards
+    int rc = finish_graph(h);
+    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+    h->stats.ms_build_total = t.stop();
     return DBG_OK;
 }
 

@@ -14,6 +14,8 @@ link of a rank at once (a ring collective would be bound by one link):
   5. all-to-all of the answers (uint32 node ids) back                 -- dbg_shard_apply
 
 After step 5 every rank holds its shard: node ids are (owner << 29) | local id, stamps are global.
+Traversal (prune / tips / pull-out reads / contig walk) crosses ranks; ``gather_graph`` moves the shards
+and the reads to one rank, whose handle then behaves like a single-GPU build (gather first).
 The graph object may be an ``_dbg.Graph`` or anything with the same four shard_* methods
 (the CPU test uses a numpy stand-in), and the process group may be gloo (tensors are staged
 through the host) or nccl.
@@ -95,3 +97,53 @@ def sharded_build(g, k, dist):
         torch.cuda.synchronize(device)
     g.shard_apply(answers)
     return g
+
+
+def _all_gather_ints(dist, vals, device):
+    w = dist.get_world_size()
+    mine = torch.tensor(vals, dtype=torch.int64, device="cpu" if _is_gloo(dist) else device)
+    out = [torch.empty_like(mine) for _ in range(w)]
+    dist.all_gather(out, mine)
+    return [[int(x) for x in t.tolist()] for t in out]
+
+
+def gather_graph(g, k, dist, dst=0, make_graph=None):
+    """After ``sharded_build``: every rank sends its shard (node arrays) and its reads to rank ``dst``.
+
+    Returns, on ``dst``, a fresh handle holding the whole graph over the rank-major concatenation of the
+    reads -- successor ids rewritten to positions in the concatenated node arrays (dbg_import_graph) -- ready
+    for refine_edge_order / prune / remove_tips / mark_pull_reads / walk; ``None`` on the other ranks.
+    The gather is an all-to-all in which only ``dst`` receives (variable sizes, one call per array).
+    """
+    w, me = dist.get_world_size(), dist.get_rank()
+    nodes = g.node_tensors()
+    bases, offsets = g.reads_tensors()
+    device = bases.device
+    n, nb, nr = nodes["keys"].numel(), bases.numel(), offsets.numel() - 1
+    sizes = _all_gather_ints(dist, [n, nb, nr], device)
+    byte_base = [sum(s[1] for s in sizes[:r]) for r in range(w)]
+
+    def to_dst(x, which, width=1):
+        send = [x.numel() if r == dst else 0 for r in range(w)]
+        recv = [sizes[r][which] * width if me == dst else 0 for r in range(w)]
+        return alltoallv(dist, x, send, recv)
+
+    keys = to_dst(nodes["keys"], 0)
+    stamps = to_dst(nodes["stamps"], 0)
+    counts = to_dst(nodes["counts"], 0, 4)
+    succ = to_dst(nodes["succ"], 0, 4)
+    all_bases = to_dst(bases, 1)
+    ends = to_dst(offsets[1:] + byte_base[me], 2)  # read ends in the concatenation
+    if me != dst:
+        return None
+    all_offsets = torch.cat([torch.zeros(1, dtype=torch.int64, device=ends.device), ends])
+    if not _is_gloo(dist) and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    if make_graph is None:
+        import _dbg
+        merged = _dbg.Graph(device=g.sizes_device())
+    else:
+        merged = make_graph()
+    merged.set_reads_tensors(all_bases, all_offsets)
+    merged.import_graph(k, [s[0] for s in sizes], keys, stamps, counts, succ)
+    return merged

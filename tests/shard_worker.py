@@ -109,6 +109,37 @@ class NumpyShardGraph:
     def export(self):
         return np.array(self.node_keys, dtype=np.uint64), self.stamps, self.counts, self.succ
 
+    # ---- gather protocol (multi_gpu.gather_graph)
+    def sizes_device(self):
+        return "cpu"
+
+    def node_tensors(self):
+        return {"keys": as_i64(self.node_keys), "stamps": torch.from_numpy(self.stamps.view(np.int64).copy()),
+                "counts": torch.from_numpy(self.counts.astype(np.int32).reshape(-1).copy()),
+                "succ": torch.from_numpy(self.succ.view(np.int32).reshape(-1).copy())}
+
+    def reads_tensors(self):
+        blob = np.frombuffer("".join(self.reads).encode(), dtype=np.uint8).copy()
+        off = np.zeros(len(self.reads) + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in self.reads], out=off[1:])
+        return torch.from_numpy(blob), torch.from_numpy(off)
+
+
+class NumpyMergedGraph:
+    """Model of dbg_import_graph: concatenated shard arrays, successor ids rewritten to global positions."""
+
+    def set_reads_tensors(self, bases, offsets):
+        self.bases, self.offsets = bases.numpy(), offsets.numpy()
+
+    def import_graph(self, k, shard_nodes, keys, stamps, counts, succ):
+        base = np.concatenate([[0], np.cumsum(shard_nodes)]).astype(np.uint64)
+        s = succ.numpy().view(np.uint32).astype(np.uint64)
+        none = s == 0xFFFFFFFF
+        glob = base[(s >> np.uint64(29)).astype(np.int64) % len(base)] + (s & np.uint64((1 << 29) - 1))
+        self.succ = np.where(none, np.uint64(0xFFFFFFFF), glob).astype(np.uint32).reshape(-1, 4)
+        self.keys, self.stamps = keys.numpy().view(np.uint64), stamps.numpy().view(np.uint64)
+        self.counts = counts.numpy().view(np.uint32).reshape(-1, 4)
+
 
 def main():
     mode, out_dir, k, n_reads, read_len = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
@@ -130,6 +161,44 @@ def main():
         rp, col, cnt = g.export_csr()
         assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, stamps=stamps, counts=counts, succ=succ)
+    # ---- traversal after the sharded build: gather to rank 0, then the single-GPU path
+    if mode == "fake":
+        merged = multi_gpu.gather_graph(g, k, dist, dst=0, make_graph=NumpyMergedGraph)
+        if rank == 0:
+            np.savez(os.path.join(out_dir, "merged.npz"), keys=merged.keys, stamps=merged.stamps, counts=merged.counts,
+                     succ=merged.succ, bases=merged.bases, offsets=merged.offsets)
+    else:
+        merged = multi_gpu.gather_graph(g, k, dist, dst=0)
+        if rank == 0:
+            def rest_of_path(h):
+                h.refine_edge_order()
+                h.prune(2)
+                h.remove_tips()
+                h.mark_pull_reads()
+                h.walk(False)
+                kk, st, cn, fl = h.export_nodes()
+                o = np.argsort(st, kind="stable")
+                mc, fs = h.export_orders()
+                ranks = h.export_pull_ranks()
+                off, chars, score, stamp, seq = h.export_contigs()
+                co = np.lexsort((seq, stamp))
+                text = chars.tobytes()
+                return {"keys": kk[o], "stamps": st[o], "counts": cn[o], "flags": fl[o], "order": mc[o], "fsorder": fs[o],
+                        "pull_ranks": ranks[o], "pull_reads": h.export_pull_reads(),
+                        "contigs": [text[int(off[i]):int(off[i + 1])] for i in co], "scores": score[co],
+                        "sizes": {key: h.sizes()[key] for key in ("n_nodes", "n_edges", "n_branch", "n_pulled", "n_pull_reads",
+                                                                  "n_starts", "n_contigs")}}
+            got = rest_of_path(merged)
+            allb, allo = merged.copy_reads()
+            single = _dbg.Graph(device=0)      # the same reads through the single-GPU build
+            single.set_reads(allb, allo)
+            single.build(k)
+            want = rest_of_path(single)
+            assert got["sizes"] == want["sizes"], (got["sizes"], want["sizes"])
+            for key in ("keys", "stamps", "counts", "flags", "order", "fsorder", "pull_ranks", "pull_reads", "scores"):
+                assert np.array_equal(got[key], want[key]), key
+            assert got["contigs"] == want["contigs"] and len(want["contigs"]) > 0
+            assert allb.size == n_reads * read_len
     dist.barrier()
     dist.destroy_process_group()
 

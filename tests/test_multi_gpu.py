@@ -1,7 +1,9 @@
 """Sharded (multi-rank) build: union of the shards == the single-rank oracle result.
 
-CPU (gloo, world_size 2 and 4): multi_gpu.py's exchange logic around a numpy model of the device steps.
-GPU (-m gpu): the real library, two ranks sharing the test box's single GPU over gloo.
+CPU (gloo, world_size 2 and 4): multi_gpu.py's exchange logic around a numpy model of the device steps,
+then the gather for traversal.
+GPU (-m gpu): the real library, two ranks sharing the test box's single GPU over gloo: sharded build, gather to
+rank 0, and the whole rest of the path (refine, prune, tips, pull-out reads, walk) equal to a single-GPU build.
 """
 import os
 import socket
@@ -68,6 +70,20 @@ def check(shards, world, k, n_reads, read_len):
 def test_exchange_logic_on_cpu_gloo(world, tmp_path):
     shards = run_ranks("fake", world, tmp_path, 9, 64, 40)
     check(shards, world, 9, 64, 40)
+    # gather for traversal: rank 0 holds the whole graph over the rank-major concatenation of the reads
+    m = np.load(os.path.join(tmp_path, "merged.npz"))
+    k, per = 9, 64 // world
+    reads = np.concatenate([synth.reads_ascii(77, max(4 * 40, 64 * 40 // 20), per, 40, 0.01, first_read=r * per)
+                            for r in range(world)])
+    assert np.array_equal(m["bases"], reads.reshape(-1)) and np.array_equal(m["offsets"], np.arange(0, reads.size + 1, 40))
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, 40, dtype=np.uint64), k)
+    o = np.argsort(m["stamps"], kind="stable")
+    assert np.array_equal(m["keys"][o], want["keys"]) and np.array_equal(m["counts"][o], want["counts"])
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for code in range(4):  # successor ids are positions in the merged arrays
+        has = m["counts"][:, code] != 0
+        assert np.array_equal(m["keys"][m["succ"][has, code]], ((m["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+        assert np.all(m["succ"][~has, code] == 0xFFFFFFFF)
 
 
 @pytest.mark.gpu
