@@ -748,19 +748,24 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
     uint64_t pf_w0 = 0, pf_w1 = 0;
     ST pf_st = 0;
     uint64_t nx_beg = 0, nx_n = 0;  // record range of the prefetched bucket (uniform)
-    auto prefetch = [&](uint64_t bucket) {
-        nx_n = 0;
-        if (bucket < n_buckets) {
-            nx_beg = b_start[bucket];
-            nx_n = b_cnt[bucket];
-            if (threadIdx.x < min(nx_n, (uint64_t)STAGE)) {
-                pf_w0 = rec_w0[nx_beg + threadIdx.x];
-                pf_w1 = rec_w1[nx_beg + threadIdx.x];
-                pf_st = rec_st[nx_beg + threadIdx.x];
-            }
+    uint64_t r2_beg = 0, r2_n = 0;  // ... and of the one after it: loaded a whole bucket ahead, so the record
+                                    // prefetch never waits for the (scalar, L2-latency) load of its own address
+    auto load_range = [&](uint64_t bucket, uint64_t &beg, uint64_t &n) {
+        n = 0;
+        if (bucket < n_buckets) { beg = b_start[bucket]; n = b_cnt[bucket]; }
+    };
+    auto prefetch = [&](uint64_t bucket) {  // records of `bucket` (its range is in r2_*), then the range after it
+        nx_beg = r2_beg;
+        nx_n = r2_n;
+        if (threadIdx.x < min(nx_n, (uint64_t)STAGE)) {
+            pf_w0 = rec_w0[nx_beg + threadIdx.x];
+            pf_w1 = rec_w1[nx_beg + threadIdx.x];
+            pf_st = rec_st[nx_beg + threadIdx.x];
         }
+        load_range(bucket + gridDim.x, r2_beg, r2_n);
     };
     if (threadIdx.x == 0) s.fail = 0;
+    load_range(blockIdx.x, r2_beg, r2_n);
     prefetch(blockIdx.x);
 
     for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
