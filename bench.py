@@ -66,8 +66,10 @@ def extras(g, args, k, L, genome_len):
         for _ in range(3):
             g0.build(k)
         dt = (time.perf_counter() - t0) / 3
+        ms_count = g0.stats()["ms_count"]
         out["error_free_variant"] = {"value": args.reads * (L - k + 1) / dt, "unit": "k-mers/s", "ms_per_step": dt * 1e3,
-                                     "n_nodes": g0.sizes()["n_nodes"]}
+                                     "n_nodes": g0.sizes()["n_nodes"], "count_kernel_ms": round(ms_count, 3),
+                                     "roofline_frac": args.reads * (L - k + 1) * b_alg(L, k) / (ms_count * 1e-3) / 1e9 / HBM_PEAK_GBS}
         g0.close()
     return out
 

@@ -84,9 +84,9 @@ def test_ragged_reads_and_boundaries():
     blob = np.concatenate(reads) if reads else np.zeros(0, np.uint8)
     off = np.zeros(len(lens) + 1, dtype=np.uint64)
     np.cumsum(lens, out=off[1:])
-    for k in (4, 17, 31):
+    for k in (4, 17, 31, 40, 63):   # above 31: the two-word path (the options do not apply)
         want = orc_c.build(blob, off, k)
-        for opts in (dict(engine=1), dict(engine=0), dict(engine=0, bucket_bits=7)):
+        for opts in ((dict(engine=1), dict(engine=0), dict(engine=0, bucket_bits=7)) if k <= 31 else (dict(),)):
             g = _dbg.Graph()
             for name, v in opts.items():
                 g.set_option(name, v)
@@ -95,6 +95,34 @@ def test_ragged_reads_and_boundaries():
             keys, stamps, counts, flags, succ, keys_raw = table(g, k)
             assert np.array_equal(keys, want["keys"]) and np.array_equal(stamps, want["stamps"])
             assert np.array_equal(counts, want["counts"])
+            if k <= 31:
+                check_succ(keys_raw, g.export_nodes()[2], succ, k)
+            else:
+                assert np.array_equal(g.export_keys_hi()[np.argsort(g.export_nodes()[1], kind="stable")], want["keys_hi"])
+
+
+@pytest.mark.parametrize("k", [9, 31, 47])
+def test_skewed_low_complexity_reads(k):
+    """Homopolymers, tandem repeats and heavy duplication next to ordinary reads: a handful of buckets receive
+    tens of thousands of identical records (several staging chunks, multiplicities far above the coverage)."""
+    L = 120
+    rng = np.random.default_rng(11)
+    rows = [np.frombuffer(("A" * L).encode(), dtype=np.uint8)] * 9000
+    rows += [np.frombuffer(("AC" * L)[:L].encode(), dtype=np.uint8)] * 7000
+    rows += [np.frombuffer(("ACGGT" * L)[:L].encode(), dtype=np.uint8)] * 5000
+    rows += [np.frombuffer(("T" * 50 + "G" * 70).encode(), dtype=np.uint8)] * 3000
+    rows += list(synth.reads_ascii(13, 20000, 4000, L, 0.01))
+    order = rng.permutation(len(rows))
+    reads = np.stack([rows[i] for i in order])
+    off = np.arange(0, reads.size + 1, L, dtype=np.uint64)
+    want = orc_c.build(reads.reshape(-1), off, k)
+    for opts in ((dict(engine=0), dict(engine=0, bucket_bits=2, lds_slots=2048), dict(engine=1)) if k <= 31 else (dict(),)):
+        g = build(reads, k, **opts)
+        keys, stamps, counts, flags, succ, keys_raw = table(g, k)
+        assert np.array_equal(keys, want["keys"]) and np.array_equal(stamps, want["stamps"])
+        assert np.array_equal(counts, want["counts"])
+        assert int(counts.max()) >= 9000 * (L - k)
+        if k <= 31:
             check_succ(keys_raw, g.export_nodes()[2], succ, k)
 
 
