@@ -2637,20 +2637,26 @@ static ShardState &shard_of(dbg *h) {
     return *(ShardState *)h->shard_state;
 }
 
-__global__ __launch_bounds__(256) void k_stamp_globalize(const uint32_t *__restrict__ st32, uint64_t n, uint64_t base2,
-                                                         uint64_t *st64) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st64[i] = base2 + st32[i];  // ((base + p) << 1) | flag == (base << 1) + ((p << 1) | flag)
+// rank-local 32-bit stamps -> global 64-bit ones, and in the same pass the k-mer / edge instance totals of the
+// received records (the shard's table is sized from them)
+__global__ __launch_bounds__(256) void k_stamp_globalize(const uint32_t *__restrict__ st32, const uint64_t *__restrict__ w1,
+                                                         uint64_t n, uint64_t base2, uint64_t *st64,
+                                                         unsigned long long *sums /* [0] instances [1] edges */) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t n_inst = 0, n_edge = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        st64[i] = base2 + st32[i];  // ((base + p) << 1) | flag == (base << 1) + ((p << 1) | flag)
+        const uint64_t x = w1[i];
+        n_inst += ((x >> 1) & 31) + 1;
+        n_edge += ((x >> 1) & 31) + (x & 1);
+    }
+    n_inst = wave_sum_u64(n_inst);
+    n_edge = wave_sum_u64(n_edge);
+    if ((threadIdx.x & 63) == 0) {
+        if (n_inst) atomicAdd(&sums[0], (unsigned long long)n_inst);
+        if (n_edge) atomicAdd(&sums[1], (unsigned long long)n_edge);
+    }
 }
-
-struct RecLen {
-    const uint64_t *w1;
-    __device__ uint64_t operator()(uint64_t i) const { return ((w1[i] >> 1) & 31) + 1; }
-};
-struct RecEdges {
-    const uint64_t *w1;
-    __device__ uint64_t operator()(uint64_t i) const { return ((w1[i] >> 1) & 31) + (w1[i] & 1); }
-};
 
 __global__ __launch_bounds__(256) void k_q_prepare(const uint64_t *__restrict__ keys, uint64_t n, int k, int m,
                                                    uint64_t *meta) {
@@ -2749,15 +2755,19 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
     }
     CHK(buf_ensure(h, h->ar_shard[2], (n_rec + 16) * 8));
     uint64_t *st64 = (uint64_t *)h->ar_shard[2].p;
+    HIPCHK(h, hipMemsetAsync(h->d_scalars + 56, 0, 16, h->stream));
     for (int r = 0; r < n_shards; ++r) {
         if (!recv_counts[r]) continue;
-        hipLaunchKernelGGL(k_stamp_globalize, dim3(grid_for(recv_counts[r], 256)), dim3(256), 0, h->stream,
-                           (const uint32_t *)d_st32 + seg[r], recv_counts[r], stamp_base[r] << 1, st64 + seg[r]);
+        const unsigned grid = (unsigned)std::min<uint64_t>(grid_for(recv_counts[r], 256), 8192);
+        hipLaunchKernelGGL(k_stamp_globalize, dim3(grid), dim3(256), 0, h->stream, (const uint32_t *)d_st32 + seg[r],
+                           (const uint64_t *)d_w1 + seg[r], recv_counts[r], stamp_base[r] << 1, st64 + seg[r],
+                           (unsigned long long *)(h->d_scalars + 56));
     }
     HIPCHK(h, hipGetLastError());
-    uint64_t n_inst = 0, n_edge = 0;
-    CHK(reduce_sum(h, n_rec, RecLen{(const uint64_t *)d_w1}, &n_inst));
-    CHK(reduce_sum(h, n_rec, RecEdges{(const uint64_t *)d_w1}, &n_edge));
+    uint64_t sums[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(sums, h->d_scalars + 56, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint64_t n_inst = sums[0], n_edge = sums[1];
     h->k = k;
     h->stats.n_records = n_rec;
     Timer t_total(h->stream);
