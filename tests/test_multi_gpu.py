@@ -91,3 +91,10 @@ def test_exchange_logic_on_cpu_gloo(world, tmp_path):
 def test_two_ranks_on_one_gpu(k, n_reads, read_len, tmp_path):
     shards = run_ranks("gpu", 2, tmp_path, k, n_reads, read_len)
     check(shards, 2, k, n_reads, read_len)
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_one_gpu(tmp_path):
+    """Two owner bits (the box allows at most six processes on its GPU, so eight ranks run only on the real node)."""
+    shards = run_ranks("gpu", 4, tmp_path, 21, 8000, 100)
+    check(shards, 4, 21, 8000, 100)
