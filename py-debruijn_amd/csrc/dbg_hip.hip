@@ -107,7 +107,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[2], ar_wide[6];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -654,14 +654,51 @@ __global__ __launch_bounds__(256) void k_tip_commit(G g, uint8_t *flags_rw, cons
     }
 }
 
-__global__ __launch_bounds__(256) void k_collect_flagged(uint64_t n_nodes, const uint8_t *flags, uint8_t mask,
-                                                         uint8_t want, uint32_t *out, unsigned long long *counter) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    if ((flags[i] & mask) == want) {
-        const unsigned long long slot = atomicAdd(counter, 1ull);
-        out[slot] = (uint32_t)i;
+// ---- ordered compaction: ids i < n with pred(i), ascending.  Two streaming passes over contiguous chunks (count, then
+//      write at the chunk's offset) -- one shared cursor would cost a same-address atomic (~12 ns, serialised chip-wide)
+//      per wave: 65 ms for the 12 M splitters of a 3.6e8-node graph.
+constexpr unsigned COMPACT_WGS = 4096;
+template <class Pred>
+__global__ __launch_bounds__(256) void k_compact_count(uint64_t n, Pred pred, uint64_t *wg_count) {
+    const uint64_t beg = n * blockIdx.x / gridDim.x, end = n * (blockIdx.x + 1) / gridDim.x;
+    uint64_t c = 0;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += 256) c += pred(i) ? 1 : 0;
+    uint64_t tot;
+    (void)block_exscan_256(c, &tot);
+    if (threadIdx.x == 0) wg_count[blockIdx.x] = tot;
+}
+template <class Pred>
+__global__ __launch_bounds__(256) void k_compact_write(uint64_t n, Pred pred, const uint64_t *__restrict__ wg_offset, uint32_t *out) {
+    const uint64_t beg = n * blockIdx.x / gridDim.x, end = n * (blockIdx.x + 1) / gridDim.x;
+    uint64_t base = wg_offset[blockIdx.x];
+    for (uint64_t i0 = beg; i0 < end; i0 += 256) {  // uniform trip count
+        const uint64_t i = i0 + threadIdx.x;
+        const bool p = i < end && pred(i);
+        uint64_t tot;
+        const uint64_t ex = block_exscan_256(p ? 1 : 0, &tot);
+        if (p) out[base + ex] = (uint32_t)i;
+        base += tot;
     }
+}
+struct PredFlags {
+    const uint8_t *flags;
+    uint8_t mask, want;
+    __device__ bool operator()(uint64_t i) const { return (flags[i] & mask) == want; }
+};
+// out (capacity >= the number of hits; nullptr: count only) receives the ids in ascending order
+template <class Pred>
+static int compact_ids(dbg *h, uint64_t n, Pred pred, uint32_t *out, uint64_t *h_total) {
+    const unsigned g = (unsigned)std::min<uint64_t>(COMPACT_WGS, std::max<uint64_t>(1, (n + 255) / 256));
+    CHK(buf_ensure(h, h->ar_scan, (uint64_t)(g + 1) * 8));
+    uint64_t *cnt = (uint64_t *)h->ar_scan.p, *d_total = cnt + g;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact_count<Pred>), dim3(g), dim3(256), 0, h->stream, n, pred, cnt);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, h->stream, cnt, (uint64_t)g, d_total);
+    if (out) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_compact_write<Pred>), dim3(g), dim3(256), 0, h->stream, n, pred, cnt, out);
+    hipError_t e = hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("compact_ids: ") + hipGetErrorString(e); return DBG_E_HIP; }
+    return DBG_OK;
 }
 
 template <class T>
@@ -1032,36 +1069,81 @@ struct MultiSucc {
 // steps in total).  Doubling resolves (end node, hops, score) of EVERY node's chain in
 // ceil(log2 n) rounds; a chain that never terminates is a cycle and emits nothing (debruijn.py:289-290).
 // ------------------------------------------------------------------------------------------
-struct Jump {
+struct alignas(16) Jump {      // 16 bytes: one 128-bit load per (random) lookup, one 32-byte sector
     uint32_t target;
-    uint32_t pad;
-    unsigned long long hops;   // bit 63: chain is resolved (target is its last node)
-    unsigned long long score;  // sum of edge counts over the hops (getScore, II_assembleFromReads.py:14-18)
+    uint32_t hops;             // <= number of nodes
+    unsigned long long score;  // bit 63: chain is resolved (target is its last node); below: sum of edge counts over the
+                               // hops (getScore, II_assembleFromReads.py:14-18)
 };
 constexpr unsigned long long JUMP_TERM = 1ull << 63;
+constexpr uint32_t JUMP_START = 1u << 31;  // in hops of the ONE-STEP table (k_jump_init) only: the node has indegree 0
+static_assert(sizeof(Jump) == 16, "jump table entry");
 
 template <class G>
 __global__ __launch_bounds__(256) void k_jump_init(uint64_t n_nodes, G g, Jump *J) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n_nodes) return;
     const uint8_t f = g.flags[v];
-    Jump j{(uint32_t)v, 0, JUMP_TERM, 0};
+    Jump j{(uint32_t)v, 0u, JUMP_TERM};
     if (!(f & (DBG_F_PULLED | DBG_F_BRANCH)) && g.keep_count((uint32_t)v)) {  // chain node: exactly one surviving successor
         const uint32_t code = g.first_kept((uint32_t)v);
         const uint32_t nxt = g.succ_of((uint32_t)v, code);
         if (!(g.flags[nxt] & DBG_F_PULLED)) { j.target = nxt; j.hops = 1; j.score = g.cnt_of((uint32_t)v, code); }
     }
+    if (!(f & DBG_F_INDEG)) j.hops |= JUMP_START;  // one-step table only: lets the splitter walk test "is a start" without flags[]
     J[v] = j;
 }
 
-__global__ __launch_bounds__(256) void k_jump_step(uint64_t n_nodes, const Jump *__restrict__ in, Jump *__restrict__ out) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n_nodes) return;
+// ---- list ranking by splitters: O(n) chain steps instead of O(n log n).  Splitters = every node whose chain ends
+// in itself (branch node, dead end, before a pulled node), every start, and a pseudo-random 1/64 of the rest.
+// Each splitter walks its chain to the next splitter (64 steps expected; a walk that closes on itself without
+// meeting one is a cycle: Brent's test, exact); doubling then runs over the splitters only.
+__device__ inline bool jump_is_splitter(uint32_t v, const Jump &j /* one-step entry */) {
+    return (j.score & JUMP_TERM) || (j.hops & JUMP_START) || ((v * 0x9E3779B1u) >> 26) == 0u;  // 1/64 by hash
+}
+
+struct PredSplitter {
+    const Jump *J0;
+    __device__ bool operator()(uint64_t v) const { return jump_is_splitter((uint32_t)v, J0[v]); }
+};
+
+// R[s] = (next splitter on s's chain, hops and score up to it), unresolved; a splitter whose own chain ends in itself
+// keeps its resolved entry.  A chain that cycles without a splitter leaves R[s] pointing at s: never resolved.
+__global__ __launch_bounds__(256) void k_jump_walk(const uint32_t *__restrict__ list, uint64_t n_list, const Jump *__restrict__ J0,
+                                                   Jump *R) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+    const uint32_t s = list[i];
+    Jump acc = J0[s];
+    acc.hops &= ~JUMP_START;
+    if (!(acc.score & JUMP_TERM)) {
+        uint32_t x = acc.target, tortoise = s;
+        uint32_t power = 1, lam = 1;
+        for (;;) {
+            const Jump jx = J0[x];
+            if (jump_is_splitter(x, jx)) break;
+            if (x == tortoise) { acc = Jump{s, 0u, 0ull}; x = s; break; }  // closed on itself: a cycle
+            if (lam == power) { tortoise = x; power <<= 1; lam = 0; }
+            ++lam;
+            acc.hops += jx.hops;  // not a start: the flag bit is clear
+            acc.score += jx.score;
+            x = jx.target;
+        }
+        acc.target = x;
+    }
+    R[s] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_jump_step_list(const uint32_t *__restrict__ list, uint64_t n_list,
+                                                        const Jump *__restrict__ in, Jump *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_list) return;
+    const uint32_t v = list[i];
     Jump a = in[v];
-    if (!(a.hops & JUMP_TERM)) {
+    if (!(a.score & JUMP_TERM)) {
         const Jump b = in[a.target];
         a.target = b.target;
-        a.hops = (a.hops + (b.hops & ~JUMP_TERM)) | (b.hops & JUMP_TERM);
+        a.hops += b.hops;
         a.score += b.score;
     }
     out[v] = a;
@@ -1073,7 +1155,7 @@ struct UnresolvedStart {
     const uint8_t *flags;
     __device__ uint64_t operator()(uint64_t i) const {
         const uint32_t s = starts[i];
-        return !(flags[s] & DBG_F_PULLED) && !(J[s].hops & JUMP_TERM);
+        return !(flags[s] & DBG_F_PULLED) && !(J[s].score & JUMP_TERM);
     }
 };
 
@@ -1084,10 +1166,10 @@ __global__ __launch_bounds__(256) void k_jump_starts(const uint32_t *starts, uin
     if (i >= n_starts) return;
     const uint32_t s = starts[i];
     const Jump a = J[s];
-    const bool emit = !(flags[s] & DBG_F_PULLED) && (a.hops & JUMP_TERM);
+    const bool emit = !(flags[s] & DBG_F_PULLED) && (a.score & JUMP_TERM);
     per_ctg[i] = emit;
-    per_chr[i] = emit ? (uint64_t)k + (a.hops & ~JUMP_TERM) : 0;
-    per_score[i] = emit ? a.score : 0;
+    per_chr[i] = emit ? (uint64_t)k + a.hops : 0;
+    per_score[i] = emit ? (a.score & ~JUMP_TERM) : 0;
 }
 
 __global__ __launch_bounds__(256) void k_walk_desc(const uint32_t *starts, uint64_t n_starts, const uint64_t *per_ctg,
@@ -1864,10 +1946,9 @@ static int remove_tips_impl(dbg *h, const G &g) {
         CHK(dev_alloc(h, &owner, h->n_nodes));
         unsigned long long *ctr = (unsigned long long *)(h->d_scalars + 24);
         HIPCHK(h, hipMemsetAsync(ctr, 0, 16, h->stream));
-        hipLaunchKernelGGL(k_collect_flagged, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
-                           h->d_flags, (uint8_t)DBG_F_BRANCH, (uint8_t)DBG_F_BRANCH, pend[0], ctr);
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        uint64_t n_pending = h->n_branch;
+        uint64_t n_pending = 0;  // branch nodes, ascending id
+        CHK(compact_ids(h, h->n_nodes, PredFlags{h->d_flags, (uint8_t)DBG_F_BRANCH, (uint8_t)DBG_F_BRANCH}, pend[0], &n_pending));
+        if (n_pending != h->n_branch) { h->err = "internal: branch count changed"; return DBG_E_HIP; }
         int cur = 0;
         while (n_pending) {
             ++h->tip_rounds;
@@ -1976,11 +2057,11 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
         if ((rc = dev_alloc(h, &per_chr, ns)) != DBG_OK) break;
         if ((rc = dev_alloc(h, &base_ctg, ns)) != DBG_OK) break;
         if ((rc = dev_alloc(h, &base_chr, ns)) != DBG_OK) break;
-        unsigned long long *ctr = (unsigned long long *)(h->d_scalars + 32);
-        (void)hipMemsetAsync(ctr, 0, 8, h->stream);
-        if (h->n_nodes)
-            hipLaunchKernelGGL(k_collect_flagged, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
-                               h->d_flags, (uint8_t)DBG_F_INDEG, (uint8_t)0, starts, ctr);
+        if (h->n_nodes) {  // nodes with indegree 0, ascending id
+            uint64_t found = 0;
+            if ((rc = compact_ids(h, h->n_nodes, PredFlags{h->d_flags, (uint8_t)DBG_F_INDEG, (uint8_t)0}, starts, &found)) != DBG_OK) break;
+            if (found != ns) { h->err = "internal: start count changed"; rc = DBG_E_HIP; break; }
+        }
         uint64_t n_walkers = 0, stride = 0, bm_words = 0;
         if (final_mode && ns) {
             stride = h->n_nodes + 1;
@@ -2007,20 +2088,29 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
         };
         if (use_jump) {
             if ((rc = dev_alloc(h, &per_score, ns)) != DBG_OK) break;
-            // 24 B per node each: kept in the arena (a fresh 17 GB hipMalloc costs ~0.5 s at the BASELINE size)
+            // 16 B per node each: kept in the arena (a fresh 12 GB hipMalloc costs ~0.4 s at the BASELINE size)
             if ((rc = buf_ensure(h, h->ar_walk[0], h->n_nodes * sizeof(Jump))) != DBG_OK) break;
             if ((rc = buf_ensure(h, h->ar_walk[1], h->n_nodes * sizeof(Jump))) != DBG_OK) break;
             jump[0] = (Jump *)h->ar_walk[0].p;
             jump[1] = (Jump *)h->ar_walk[1].p;
             const dim3 grid(grid_for(h->n_nodes, 256));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_jump_init<G>), grid, dim3(256), 0, h->stream, h->n_nodes, g, jump[0]);
-            int cur = 0, max_rounds = 2;
-            while ((1ull << (max_rounds - 1)) < h->n_nodes) ++max_rounds;  // chains are shorter than n_nodes
+            // splitters (see k_jump_walk): their list, their walks into jump[1], then doubling over the list only;
+            // jump[0] (the one-step table) becomes the second buffer once the walks are done
+            if ((rc = buf_ensure(h, h->ar_walk[2], h->n_nodes * 4)) != DBG_OK) break;
+            uint32_t *slist = (uint32_t *)h->ar_walk[2].p;
+            uint64_t n_split = 0;
+            if ((rc = compact_ids(h, h->n_nodes, PredSplitter{jump[0]}, slist, &n_split)) != DBG_OK) break;
+            const dim3 sgrid(grid_for(n_split, 256));
+            if (n_split)
+                hipLaunchKernelGGL(k_jump_walk, sgrid, dim3(256), 0, h->stream, slist, n_split, jump[0], jump[1]);
+            int cur = 1, max_rounds = 2;
+            while ((1ull << (max_rounds - 1)) < n_split) ++max_rounds;  // a chain holds fewer splitters than there are
             for (int round = 0; round < max_rounds; ++round) {
                 uint64_t open = 0;
                 if ((rc = reduce_sum(h, ns, UnresolvedStart{starts, jump[cur], h->d_flags}, &open)) != DBG_OK) break;
                 if (!open) break;
-                hipLaunchKernelGGL(k_jump_step, grid, dim3(256), 0, h->stream, h->n_nodes, jump[cur], jump[cur ^ 1]);
+                hipLaunchKernelGGL(k_jump_step_list, sgrid, dim3(256), 0, h->stream, slist, n_split, jump[cur], jump[cur ^ 1]);
                 cur ^= 1;
             }
             if (rc != DBG_OK) break;
