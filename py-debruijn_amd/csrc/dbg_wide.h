@@ -150,11 +150,13 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
         if (!found) { atomicOr(&scalars[0], 2ull); continue; }  // table full
         if (!in.at_end) atomicAdd(&tcnt[slot * 4 + in.next], 1u);
     }
-    n_k = wave_sum_u64(n_k);
-    n_e = wave_sum_u64(n_e);
-    if ((threadIdx.x & 63) == 0) {
-        if (n_k) atomicAdd(&scalars[1], (unsigned long long)n_k);
-        if (n_e) atomicAdd(&scalars[2], (unsigned long long)n_e);
+    // one update per workgroup and counter: these are same-address atomics (serialised chip-wide, ~12 ns each)
+    uint64_t tot_k, tot_e;
+    (void)block_exscan_256(n_k, &tot_k);
+    (void)block_exscan_256(n_e, &tot_e);
+    if (threadIdx.x == 0) {
+        if (tot_k) atomicAdd(&scalars[1], (unsigned long long)tot_k);
+        if (tot_e) atomicAdd(&scalars[2], (unsigned long long)tot_e);
     }
 }
 
