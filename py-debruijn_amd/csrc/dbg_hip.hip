@@ -107,7 +107,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -982,14 +982,21 @@ __global__ __launch_bounds__(256) void k_fa_copy(const char *__restrict__ text, 
 // first occurrence of every out-edge by streaming the k-mer instances once more, and rewrites the
 // rank bytes: order[] = (count desc, first-seen asc), fsorder[] = first-seen asc.
 // ------------------------------------------------------------------------------------------
+// `filter`: one bit per top-`fbits` hash value of a member.  The streaming pass below tests it first: the set itself
+// (16 bytes per slot, > 100 MB at scale) is a random HBM access per k-mer instance, the filter (16 MB) stays in cache
+// and rejects ~95 % of the instances.
 __global__ __launch_bounds__(256) void k_multi_insert(uint64_t n_nodes, const uint32_t *cnt, const uint64_t *keys,
-                                                      unsigned long long *set_keys, uint32_t *set_node, uint64_t cap_mask) {
+                                                      unsigned long long *set_keys, uint32_t *set_node, uint64_t cap_mask,
+                                                      uint32_t *filter, int fbits) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const uint4 c = reinterpret_cast<const uint4 *>(cnt)[i];
     if ((c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0) < 2) return;
     const unsigned long long key = keys[i];
-    uint64_t slot = kmer_hash(key) & cap_mask;
+    const uint64_t hv = kmer_hash(key);
+    const uint64_t fb = hv >> (64 - fbits);
+    atomicOr(&filter[fb >> 5], 1u << (fb & 31));
+    uint64_t slot = hv & cap_mask;
     for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
         const unsigned long long cur = atomicCAS(&set_keys[slot], EMPTY_KEY, key);
         if (cur == EMPTY_KEY) { set_node[slot] = (uint32_t)i; return; }
@@ -1000,6 +1007,7 @@ __global__ __launch_bounds__(256) void k_multi_insert(uint64_t n_nodes, const ui
 __global__ __launch_bounds__(256) void k_edge_first_seen(const char *__restrict__ bases, uint64_t n_bytes,
                                                          const uint32_t *__restrict__ startbits, int k,
                                                          const uint64_t *__restrict__ set_keys, uint64_t cap_mask,
+                                                         const uint32_t *__restrict__ filter, int fbits,
                                                          unsigned long long *estamp /* [slot * 4 + code] */) {
     __shared__ TileLds t;
     const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
@@ -1014,7 +1022,10 @@ __global__ __launch_bounds__(256) void k_edge_first_seen(const char *__restrict_
         const uint64_t win = window32(t, j);
         const uint64_t kmer = win >> (64 - 2 * k);
         const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
-        uint64_t slot = kmer_hash(kmer) & cap_mask;
+        const uint64_t hv = kmer_hash(kmer);
+        const uint64_t fb = hv >> (64 - fbits);
+        if (!((filter[fb >> 5] >> (fb & 31)) & 1u)) continue;  // not a multi-successor node
+        uint64_t slot = hv & cap_mask;
         for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
             const uint64_t cur = set_keys[slot];
             if (cur == kmer) { atomicMin(&estamp[slot * 4 + b], (unsigned long long)p); break; }
@@ -1262,6 +1273,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_shard) buf_free(b);
     for (auto &b : h->ar_walk) buf_free(b);
     for (auto &b : h->ar_wide) buf_free(b);
+    for (auto &b : h->ar_refine) buf_free(b);
     buf_free(h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
@@ -1826,24 +1838,32 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
         uint64_t cap = 1024;
         while (cap < n_multi * 2) cap <<= 1;
         unsigned long long *set_keys = nullptr, *estamp = nullptr;
-        uint32_t *set_node = nullptr;
-        int rc = dev_alloc(h, &set_keys, cap);
-        if (rc == DBG_OK) rc = dev_alloc(h, &set_node, cap);
-        if (rc == DBG_OK) rc = dev_alloc(h, &estamp, cap * 4);
+        uint32_t *set_node = nullptr, *filter = nullptr;
+        int fbits = 20;
+        while (fbits < 32 && (1ull << fbits) < n_multi * 16) ++fbits;
+        // grow-only arena (a multi-k driver calls this once per k: ~700 MB of hipMalloc + hipFree each time otherwise)
+        int rc = buf_ensure(h, h->ar_refine[0], cap * 8);
+        if (rc == DBG_OK) rc = buf_ensure(h, h->ar_refine[1], cap * 4);
+        if (rc == DBG_OK) rc = buf_ensure(h, h->ar_refine[2], cap * 32);
+        if (rc == DBG_OK) rc = buf_ensure(h, h->ar_refine[3], (1ull << fbits) / 8);
         if (rc == DBG_OK) {
+            set_keys = (unsigned long long *)h->ar_refine[0].p;
+            set_node = (uint32_t *)h->ar_refine[1].p;
+            estamp = (unsigned long long *)h->ar_refine[2].p;
+            filter = (uint32_t *)h->ar_refine[3].p;
             (void)hipMemsetAsync(set_keys, 0xFF, cap * 8, h->stream);
             (void)hipMemsetAsync(estamp, 0xFF, cap * 32, h->stream);
+            (void)hipMemsetAsync(filter, 0, (1ull << fbits) / 8, h->stream);
             hipLaunchKernelGGL(k_multi_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_cnt,
-                               h->d_keys, set_keys, set_node, cap - 1);
+                               h->d_keys, set_keys, set_node, cap - 1, filter, fbits);
             const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
             hipLaunchKernelGGL(k_edge_first_seen, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
-                               h->d_startbits, h->k, (const uint64_t *)set_keys, cap - 1, estamp);
+                               h->d_startbits, h->k, (const uint64_t *)set_keys, cap - 1, filter, fbits, estamp);
             hipLaunchKernelGGL(k_order_refine, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, cap, set_keys, set_node,
                                estamp, h->d_cnt, h->d_order, h->d_fsorder);
             hipError_t e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) { h->err = std::string("refine: ") + hipGetErrorString(e); rc = DBG_E_HIP; }
         }
-        dev_free(set_keys); dev_free(set_node); dev_free(estamp);
         if (rc != DBG_OK) return rc;
     }
     h->order_exact = true;

@@ -15,7 +15,7 @@ g = _dbg.Graph()
 g.synth_reads(1, int(reads * 150 / 30), reads, 150, err)
 g.build(31)
 out = {}
-for name, fn in (("build", lambda: g.build(31)), ("prune", lambda: g.prune(2)), ("tips", g.remove_tips),
+for name, fn in (("build", lambda: g.build(31)), ("refine_edge_order", g.refine_edge_order), ("prune", lambda: g.prune(2)), ("tips", g.remove_tips),
                  ("pull_reads", g.mark_pull_reads), ("walk_index", lambda: g.walk(False, 1 << 20))):
     print(name, "...", flush=True)
     t0 = time.perf_counter()
