@@ -53,10 +53,11 @@ __device__ inline char code_to_ascii(uint32_t code) {  // inverse of (ascii >> 1
 // rank of a base code in ASCII order (A < C < G < T) -- tie order of equal edge counts
 __device__ inline uint32_t code_ascii_rank(uint32_t code) { return (0x2310u >> (4 * code)) & 3u; }  // 0->0,1->1,2->3,3->2
 
-// Exclusive scan of one value per thread over a 256-thread block (4 waves of 64).
+// Exclusive scan of one value per thread over a block of NW waves of 64.
 // Returns the exclusive prefix; *block_total receives the block sum (all threads).
-__device__ inline uint64_t block_exscan_256(uint64_t v, uint64_t *block_total) {
-    __shared__ uint64_t wave_sum[4];
+template <int NW>
+__device__ inline uint64_t block_exscan(uint64_t v, uint64_t *block_total) {
+    __shared__ uint64_t wave_sum[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t inc = v;
 #pragma unroll
@@ -68,7 +69,7 @@ __device__ inline uint64_t block_exscan_256(uint64_t v, uint64_t *block_total) {
     __syncthreads();
     uint64_t base = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         uint64_t s = wave_sum[w];
         if (w < wave) base += s;
         tot += s;
@@ -77,6 +78,7 @@ __device__ inline uint64_t block_exscan_256(uint64_t v, uint64_t *block_total) {
     *block_total = tot;
     return base + inc - v;
 }
+__device__ inline uint64_t block_exscan_256(uint64_t v, uint64_t *block_total) { return block_exscan<4>(v, block_total); }
 
 __device__ inline uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll

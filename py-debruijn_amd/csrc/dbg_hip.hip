@@ -2365,7 +2365,7 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
         auto kern = k_ms_scatter<ST, HAS_ST>;
         const size_t lds = sizeof(MsLds<ST>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(256), lds, h->stream, P, in_w0, in_w1, in_st, shift, nb, offs,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(MS_NT), lds, h->stream, P, in_w0, in_w1, in_st, shift, nb, offs,
                            out_w0, out_w1, out_st);
     }
     HIPCHK(h, hipGetLastError());

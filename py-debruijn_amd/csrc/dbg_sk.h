@@ -380,6 +380,11 @@ __global__ __launch_bounds__(256, DBG_EXW_WAVES) void k_sk_extract_w(const char 
 constexpr int MS_CH = DBG_MS_CH;      // records sorted per LDS round
 constexpr int MS_SC = 32768;          // records per super-chunk
 constexpr int MS_MAX_NB = 1024;
+#ifndef DBG_MS_NT
+#define DBG_MS_NT 512
+#endif
+constexpr int MS_NT = DBG_MS_NT;      // threads of the scatter workgroup: its 90 KB of LDS allow one per CU, so the
+                                      // workgroup itself has to bring the waves that hide the record loads
 
 // Input of one multisplit level: `n_seg` contiguous segments of the record arrays.  Either all
 // segments form ONE group (level 1: the per-workgroup output segments of k_sk_extract) or every
@@ -473,7 +478,7 @@ struct MsLds {
 };
 
 template <class ST, bool HAS_ST>
-__global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t *__restrict__ in_w0,
+__global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_t *__restrict__ in_w0,
                                                     const uint64_t *__restrict__ in_w1, const ST *__restrict__ in_st,
                                                     int shift, int nb, const uint64_t *__restrict__ offs,
                                                     uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
@@ -486,19 +491,19 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
     const uint64_t g_lo = P.one_group ? 0 : P.sc_pre[seg], g_hi = P.one_group ? P.sc_pre[P.n_seg] : P.sc_pre[seg + 1];
     const uint64_t nsc = g_hi - g_lo, gidx = (uint64_t)blockIdx.x - g_lo;
     const uint64_t lbase = (uint64_t)nb * g_lo;
-    for (int b = threadIdx.x; b < nb; b += 256) s.run[b] = offs[lbase + (uint64_t)b * nsc + gidx];
+    for (int b = threadIdx.x; b < nb; b += MS_NT) s.run[b] = offs[lbase + (uint64_t)b * nsc + gidx];
     const uint64_t beg = P.start[seg] + sidx * MS_SC;
     const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
     for (uint64_t c0 = beg; c0 < end; c0 += MS_CH) {
         const int n = (int)min((uint64_t)MS_CH, end - c0);
-        for (int b = threadIdx.x; b < nb; b += 256) s.hist[b] = 0;
+        for (int b = threadIdx.x; b < nb; b += MS_NT) s.hist[b] = 0;
         __syncthreads();
-        uint64_t r0[MS_CH / 256], r1[MS_CH / 256];
-        ST rs[MS_CH / 256];
-        uint32_t rk[MS_CH / 256];
+        uint64_t r0[MS_CH / MS_NT], r1[MS_CH / MS_NT];
+        ST rs[MS_CH / MS_NT];
+        uint32_t rk[MS_CH / MS_NT];
 #pragma unroll
-        for (int i = 0; i < MS_CH / 256; ++i) {
-            const int q = i * 256 + threadIdx.x;
+        for (int i = 0; i < MS_CH / MS_NT; ++i) {
+            const int q = i * MS_NT + threadIdx.x;
             if (q < n) {
                 r0[i] = in_w0[c0 + q];
                 r1[i] = in_w1[c0 + q];
@@ -507,21 +512,22 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
             }
         }
         __syncthreads();
-        {  // exclusive scan of hist (nb <= 1024: four entries per thread)
-            const int b0 = threadIdx.x * 4;
-            uint32_t h4[4];
+        {  // exclusive scan of hist (nb <= 1024: MS_MAX_NB / MS_NT entries per thread)
+            constexpr int EPT = MS_MAX_NB / MS_NT;
+            const int b0 = threadIdx.x * EPT;
+            uint32_t h4[EPT];
             uint64_t sum = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { h4[j] = (b0 + j < nb) ? s.hist[b0 + j] : 0; sum += h4[j]; }
+            for (int j = 0; j < EPT; ++j) { h4[j] = (b0 + j < nb) ? s.hist[b0 + j] : 0; sum += h4[j]; }
             uint64_t tot;
-            uint32_t ex = (uint32_t)block_exscan_256(sum, &tot);
+            uint32_t ex = (uint32_t)block_exscan<MS_NT / 64>(sum, &tot);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { if (b0 + j < nb) s.start[b0 + j] = ex; ex += h4[j]; }
+            for (int j = 0; j < EPT; ++j) { if (b0 + j < nb) s.start[b0 + j] = ex; ex += h4[j]; }
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < MS_CH / 256; ++i) {
-            const int q = i * 256 + threadIdx.x;
+        for (int i = 0; i < MS_CH / MS_NT; ++i) {
+            const int q = i * MS_NT + threadIdx.x;
             if (q < n) {
                 const uint32_t b = (uint32_t)(r1[i] >> shift) & (uint32_t)(nb - 1);
                 const uint32_t d = s.start[b] + rk[i];
@@ -531,7 +537,7 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
             }
         }
         __syncthreads();
-        for (int q = threadIdx.x; q < n; q += 256) {
+        for (int q = threadIdx.x; q < n; q += MS_NT) {
             const uint64_t x1 = s.w1[q];
             const uint32_t b = (uint32_t)(x1 >> shift) & (uint32_t)(nb - 1);
             const uint64_t g = s.run[b] + (q - s.start[b]);
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) void k_ms_scatter(MsParents P, const uint64_t 
             if (HAS_ST) out_st[g] = s.st[q];
         }
         __syncthreads();
-        for (int b = threadIdx.x; b < nb; b += 256) s.run[b] += s.hist[b];
+        for (int b = threadIdx.x; b < nb; b += MS_NT) s.run[b] += s.hist[b];
         __syncthreads();
     }
 }
