@@ -107,7 +107,9 @@ int dbg_abi_version(void);
 /* Tunables (no reference counterpart): "engine" 0 = partitioned super-k-mer build (default),
  * 1 = single global hash table; "bucket_bits" 0 = auto, else log2 of the bucket count (<= 20);
  * "lds_slots" 2048 or 4096 slots of the per-bucket LDS table; "walk_jump_min_nodes" see dbg_walk;
- * "phase_limit" timing ablation of the count kernel (the build then fails on purpose). */
+ * "phase_limit" timing ablation of the count kernel (the build then fails on purpose);
+ * "estimate_scale_pct" test hook: scales the distinct-k-mer estimate that sizes the node arrays (a low value
+ * makes the first count launch run out of room and exercises the retry; dbg_stats_t.count_launches). */
 int dbg_set_option(dbg_t *h, const char *name, int64_t value);
 
 /* ---- reads (replaces the `reads` list argument, debruijn.py:206; FASTA

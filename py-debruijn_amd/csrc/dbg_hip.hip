@@ -100,6 +100,7 @@ struct dbg {
     int bucket_bits = 0;     // 0 = auto (super-k-mer engine)
     int lds_slots = 4096;    // LDS table slots per bucket workgroup (2048 or 4096)
     int phase_limit = 0;     // ablation of k_sk_count (timing only; the build then fails on purpose)
+    int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
 
     // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
     // so buffers survive across dbg_build calls on the same handle
@@ -1600,6 +1601,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "bucket_bits" && value >= 0 && value <= 20) { h->bucket_bits = (int)value; return DBG_OK; }
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
+    if (n == "estimate_scale_pct" && value >= 1 && value <= 1000) { h->est_scale_pct = (int)value; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -2560,7 +2562,8 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
     uint64_t node_cap = node_capacity_hint ? std::min<uint64_t>(node_capacity_hint, id_limit) : node_cap_max;
     if (!node_capacity_hint && est_distinct > 0.0)
-        node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2) + (1u << 20));
+        node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2 * h->est_scale_pct / 100.0) +
+                                                        (h->est_scale_pct == 100 ? (1u << 20) : 1024u));
     uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
     auto ensure_node_arrays = [&]() -> int {
         CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
@@ -2623,7 +2626,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
                                st[where], k, m, n_buckets, (const SkCountOut *)d_out, h->phase_limit);
             HIPCHK(h, hipGetLastError());
         }
-        h->stats.count_launches = n_rec ? 1 : 0;
+        h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_count = t.stop();
         if (h->phase_limit) { h->err = "ablation run (phase_limit set): timing only"; return DBG_E_ARG; }

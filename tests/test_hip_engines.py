@@ -135,3 +135,23 @@ def test_rebuild_on_same_handle_reuses_buffers():
     b = table(g, 21)
     for x, y in zip(a[:3], b[:3]):
         assert np.array_equal(x, y)
+
+
+def test_capacity_retry_when_the_estimate_is_low():
+    """The node arrays are sized from a sampled distinct-k-mer estimate; if it is too low the count kernel says so
+    and the build runs it once more with the worst-case size -- same graph."""
+    reads = synth.reads_ascii(21, 400000, 60000, 100, 0.01)
+    off = np.arange(0, reads.size + 1, 100, dtype=np.uint64)
+    want = orc_c.build(reads.reshape(-1), off, 31)
+    g = _dbg.Graph()
+    g.set_option("estimate_scale_pct", 5)
+    g.set_reads(reads.reshape(-1), off)
+    g.build(31)
+    assert g.stats()["count_launches"] == 2
+    keys, stamps, counts, flags, succ, keys_raw = table(g, 31)
+    assert np.array_equal(keys, want["keys"]) and np.array_equal(stamps, want["stamps"]) and np.array_equal(counts, want["counts"])
+    check_succ(keys_raw, g.export_nodes()[2], succ, 31)
+    g2 = _dbg.Graph()
+    g2.set_reads(reads.reshape(-1), off)
+    g2.build(31)
+    assert g2.stats()["count_launches"] == 1
