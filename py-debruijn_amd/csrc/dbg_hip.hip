@@ -2779,11 +2779,6 @@ __global__ __launch_bounds__(256) void k_q_prepare(const uint64_t *__restrict__ 
     if (i < n) meta[i] = ((uint64_t)kmer_bucket22(keys[i], k, m) << 40) | i;
 }
 
-__global__ __launch_bounds__(256) void k_tag_local(uint32_t *succ, uint64_t n, uint32_t tag) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && succ[i] != NO_NODE) succ[i] |= tag;
-}
-
 __global__ __launch_bounds__(256) void k_apply_remote(const uint64_t *__restrict__ meta, const uint32_t *__restrict__ qcol,
                                                       const uint32_t *__restrict__ ans, uint64_t n, uint32_t tag,
                                                       uint32_t *succ, uint32_t *col, unsigned long long *scalars) {
