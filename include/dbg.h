@@ -137,7 +137,9 @@ int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_bytes, const vo
  * otherwise a slot count (rounded up to a power of two); DBG_E_CAPACITY if too small.
  * k: 1..63 for reads over ACGT (k <= 31: one 64-bit word per k-mer, the partitioned engine;
  * 32..63: two words per k-mer, a reference-keyed global table -- BASELINE.json configs[4]);
- * 1..11 for any other alphabet of at most 32 distinct bytes (5 bits per character). */
+ * 1..63 for any other alphabet of at most 32 distinct bytes (k <= 11: 5 bits per character in one word;
+ * above: tables keyed by reference into the reads -- such nodes have no packed key, dbg_export_nodes returns
+ * zeros for keys and the k-mer of node i is the k bytes at offset stamps[i] >> 1 of the reads). */
 int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint);
 
 /* ---- exact successor order (Counter semantics of debruijn.py:159-165 and :215-216): finds the first

@@ -227,6 +227,56 @@ def main_wide():
           sum(1 for c in fuzz if c["result"]["vertices"] and not c["result"]["contigs"]), "with vertices but no contig")
 
 
+def main_pepwide():
+    """Peptides (and other non-ACGT alphabets) with k = 12..40: by-reference tables on the device: `make_golden.py pepwide`."""
+    import random
+    rng = random.Random(20260413)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    fuzz = []
+    for i in range(120):
+        alpha = rng.choice([aa, aa, aa[:6], "EVQLG", "KR", "ACGTN", "acgtACGT"])
+        k = rng.choice([12, 13, 16, 20, 24, 25, 31, 40, rng.randint(12, 40)])
+        rnd = lambda n: "".join(rng.choice(alpha) for _ in range(n))
+        kind = rng.random()
+        if kind < 0.45:    # a block longer than k occurs twice with different continuations
+            R = rnd(k + rng.randint(1, 20))
+            G = rnd(rng.randint(5, 30)) + R + rnd(rng.randint(5, 40)) + R + rnd(rng.randint(5, 30))
+        elif kind < 0.65:  # tandem repeat: the k-mers close a cycle
+            unit = rnd(rng.randint(2, 12))
+            G = rnd(rng.randint(0, 8)) + unit * ((k + 30) // len(unit) + 2) + rnd(rng.randint(0, 8))
+        else:
+            G = rnd(rng.randint(k + 5, k + 90))
+        reads = []
+        for _ in range(rng.randint(1, 16)):
+            L = rng.randint(max(1, k - 3), min(len(G), k + 35))
+            st = rng.randint(0, len(G) - L)
+            r = list(G[st:st + L])
+            if rng.random() < 0.45:
+                j = L - 1 - rng.randint(0, 5) if rng.random() < 0.6 else rng.randrange(L)
+                r[max(j, 0)] = rng.choice(alpha)
+            reads.append("".join(r))
+        if rng.random() < 0.3:
+            reads += reads[:rng.randint(1, 3)]
+        thr = rng.choice([1, 2, 2, 3, 3, 5])
+        final = rng.random() < 0.4
+        res = run_reference(reads, k, thr, final)
+        fuzz.append({"inputs": {"reads": reads, "k": k, "threshold": thr, "final": final}, "result": res})
+    with open(os.path.join(GOLDEN, "fuzz_peptide_wide.json"), "w") as fh:
+        json.dump(fuzz, fh, separators=(",", ":"))
+    print("fuzz_peptide_wide:", len(fuzz), "cases;",
+          sum(1 for c in fuzz if c["result"]["already_pull_out"]), "with pulled tips;",
+          sum(1 for c in fuzz if c["result"]["branch_kmer"]), "with branches;",
+          sum(1 for c in fuzz if c["result"]["contigs"]), "with contigs")
+    pep = ['EVQLVESGGGLVQPGGSLRLSCAAS', 'GGGLVQPGGSLRLSCAASGFTFS', 'LVQPGGSLRLSCAASGFNIKDTYIH', 'EVQLVESGGGLVQPGGSLRL',
+           'SLRLSCAASGFNIKDTYIHWVRQAPGK', 'GGSLRLSCAASGFNIKDTYIHWV']
+    res = run_reference_driver(pep, 10, 14, 2)  # crosses the packed / by-reference boundary (k = 11 -> 12)
+    with open(os.path.join(GOLDEN, "driver_peptide_k10_14.json"), "w") as fh:
+        json.dump({"name": "driver_peptide_k10_14",
+                   "inputs": {"reads": pep, "k_lowerlimit": 10, "k_upperlimit": 14, "threshold": 2},
+                   "result": res}, fh, separators=(",", ":"))
+    print("driver_peptide_k10_14", len(res["final_contigs"]))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     pep = ['EVQLVE', 'QLVAPG', 'LVESGGAL', 'LVESGGGL']  # II_assembleFromReads.py:55 (input only)
@@ -364,6 +414,9 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["wide"]:
         main_wide()
+    elif sys.argv[1:] == ["pepwide"]:
+        main_pepwide()
     else:
         main()
         main_wide()
+        main_pepwide()

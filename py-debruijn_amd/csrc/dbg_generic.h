@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void k_g_pull_reads(const char *__restrict__ b
 
 // accessor of the generic layout for the shared tip / walk / jump kernels
 struct GGen {
-    const uint64_t *keys;
+    const uint64_t *keys;     // packed k-mers (k <= 11), or nullptr: k-mers are read from the reads at the node's stamp
+    const char *bases;        // ... (dbg_genref.h)
+    const uint64_t *stamps;
+    const uint8_t *lut;       // byte -> code
     const uint8_t *flags;
     const uint32_t *keepmask;
     const uint8_t *rank_mc;
@@ -260,9 +263,16 @@ struct GGen {
     __device__ uint32_t succ_of(uint32_t x, uint32_t code) const { return succ[(uint64_t)x * GEN_D + code]; }
     __device__ uint32_t cnt_of(uint32_t x, uint32_t code) const { return cnt[(uint64_t)x * GEN_D + code]; }
     __device__ bool terminal(uint32_t x) const { return deg[x] == 0; }
-    __device__ uint32_t last_code(uint32_t x) const { return (uint32_t)(keys[x] & (GEN_D - 1)); }
+    __device__ uint32_t last_code(uint32_t x) const {
+        return keys ? (uint32_t)(keys[x] & (GEN_D - 1)) : (uint32_t)lut[(uint8_t)bases[(stamps[x] >> 1) + k - 1]];
+    }
     __device__ char sym_char(uint32_t code) const { return alpha[code]; }
     __device__ void spell(uint32_t x, char *out) const {
+        if (!keys) {
+            const uint64_t p = stamps[x] >> 1;
+            for (int q = 0; q < k; ++q) out[q] = bases[p + q];
+            return;
+        }
         const uint64_t key = keys[x];
         for (int q = 0; q < k; ++q) out[q] = alpha[(key >> (GEN_BITS * (k - 1 - q))) & (GEN_D - 1)];
     }

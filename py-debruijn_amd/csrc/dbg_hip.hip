@@ -21,6 +21,7 @@
 #include "dbg_device.h"
 #include "dbg_sk.h"
 #include "dbg_generic.h"
+#include "dbg_genref.h"
 #include "dbg_wide.h"
 
 using namespace dbgk;
@@ -1513,15 +1514,90 @@ static int compute_alphabet(dbg *h) {
 }
 
 static GGen gen_view(const dbg *h) {
-    return GGen{h->d_keys, h->d_flags, h->d_keepmask, h->d_rank_mc, h->d_deg, h->d_succ, h->d_cnt, h->d_alpha, h->k};
+    return GGen{h->d_keys, h->d_bases, h->d_stamps, h->d_lut, h->d_flags, h->d_keepmask, h->d_rank_mc, h->d_deg, h->d_succ,
+                h->d_cnt, h->d_alpha, h->k};
+}
+
+// k-mers longer than one packed word: tables keyed by reference into the reads (dbg_genref.h); d_keys stays null
+static int build_genref(dbg *h, int k) {
+    h->D = GEN_D;
+    h->sym_bits = GEN_BITS;
+    if (h->n_bytes >= (1ull << 46)) { h->err = "reads too large for 48-bit references"; return DBG_E_CAPACITY; }
+    Timer t_count(h->stream);
+    uint64_t cap = 1024;
+    int lg = 10;
+    while (cap < (h->n_bytes + 1) * 2) { cap <<= 1; ++lg; }
+    unsigned long long *ntab = nullptr, *etab = nullptr, *estamp = nullptr;
+    uint32_t *nocc = nullptr, *eocc = nullptr, *ecount = nullptr, *word_rank = nullptr;
+    auto cleanup = [&]() { dev_free(ntab); dev_free(etab); dev_free(nocc); dev_free(eocc); dev_free(ecount); dev_free(word_rank); dev_free(estamp); };
+    int rc = DBG_OK;
+    do {
+        if ((rc = dev_alloc(h, &ntab, cap)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &etab, cap)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &ecount, cap)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &nocc, cap / 32)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &eocc, cap / 32)) != DBG_OK) break;
+        (void)hipMemsetAsync(ntab, 0xFF, cap * 8, h->stream);
+        (void)hipMemsetAsync(etab, 0xFF, cap * 8, h->stream);
+        (void)hipMemsetAsync(ecount, 0, cap * 4, h->stream);
+        (void)hipMemsetAsync(nocc, 0, cap / 8, h->stream);
+        (void)hipMemsetAsync(eocc, 0, cap / 8, h->stream);
+        (void)hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream);
+        if (h->n_bytes) {
+            const unsigned grid = (unsigned)std::min<uint64_t>((h->n_bytes + 255) / 256, 1u << 16);
+            hipLaunchKernelGGL(k_gr_insert, dim3(grid), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, h->d_startbits, k, ntab,
+                               nocc, etab, eocc, ecount, cap - 1, 64 - lg, (unsigned long long *)h->d_scalars);
+        }
+        uint64_t sc[4] = {0, 0, 0, 0};
+        if (hipMemcpyAsync(sc, h->d_scalars, 32, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "generic count failed"; rc = DBG_E_HIP; break; }
+        if (sc[0] & 2) { h->err = "generic engine: hash table full"; rc = DBG_E_CAPACITY; break; }
+        h->n_kmer_inst = sc[1];
+        h->n_edge_inst = sc[2];
+        h->stats.ms_count = t_count.stop();
+        h->stats.count_launches = 1;
+        Timer t_c(h->stream);
+        const uint64_t n_words = cap / 32;
+        if ((rc = dev_alloc(h, &word_rank, n_words)) != DBG_OK) break;
+        uint64_t n = 0;
+        if ((rc = exclusive_scan(h, n_words, PopcWords{nocc}, word_rank, &n)) != DBG_OK) break;
+        if (n >= 0xFFFFFFF0ull) { h->err = "more than 2^32-16 nodes"; rc = DBG_E_CAPACITY; break; }
+        h->n_nodes = n;
+        if ((rc = dev_alloc(h, &h->d_stamps, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_flags, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_cnt, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_succ, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_deg, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_keepmask, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_rank_mc, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &h->d_rank_fs, n * GEN_D)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &estamp, n * GEN_D)) != DBG_OK) break;
+        if (n) {
+            (void)hipMemsetAsync(h->d_cnt, 0, n * GEN_D * 4, h->stream);
+            (void)hipMemsetAsync(h->d_succ, 0xFF, n * GEN_D * 4, h->stream);
+            (void)hipMemsetAsync(estamp, 0xFF, n * GEN_D * 8, h->stream);
+            (void)hipMemsetAsync(h->d_keepmask, 0, n * 4, h->stream);
+            hipLaunchKernelGGL(k_gr_gather, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, ntab, nocc, word_rank, n_words,
+                               h->d_stamps, h->d_flags);
+            hipLaunchKernelGGL(k_gr_edges, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, etab, ecount, cap, ntab, cap - 1,
+                               64 - lg, h->d_bases, h->d_stamps, h->d_lut, k, h->d_cnt, h->d_succ, estamp,
+                               (unsigned long long *)h->d_scalars);
+            hipLaunchKernelGGL(k_g_rank, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_cnt, estamp, h->d_rank_mc,
+                               h->d_rank_fs, h->d_deg);
+        }
+        if (hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "generic graph assembly failed"; rc = DBG_E_HIP; break; }
+        if (sc[0] & 128) { h->err = "internal: edge endpoint missing from the node table"; rc = DBG_E_HIP; break; }
+        h->stats.ms_succ = t_c.stop();
+        h->order_exact = true;  // ranks come from per-edge first-seen positions already
+    } while (0);
+    cleanup();
+    return rc;
 }
 
 static int build_generic(dbg *h, int k) {
     if (h->n_sym > GEN_D) { h->err = "reads hold more than 32 distinct characters"; return DBG_E_ALPHABET; }
-    if (GEN_BITS * (k + 1) > 64) {
-        h->err = "alphabets other than ACGT are packed at 5 bits per character: k must be <= 11";
-        return DBG_E_ALPHABET;
-    }
+    if (GEN_BITS * (k + 1) > 64) return build_genref(h, k);  // k >= 12: by-reference tables
     h->D = GEN_D;
     h->sym_bits = GEN_BITS;
     Timer t_count(h->stream);
@@ -2032,6 +2108,13 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
             hipLaunchKernelGGL(k_wpull_reads, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
                                h->d_startbits, h->k, set, bcap - 1, h->d_keys, h->d_keys_hi, h->d_offsets, h->n_reads,
                                h->d_read_flags);
+        } else if (h->D == GEN_D && !h->d_keys) {  // generic alphabet, k >= 12: set of branch node ids, keys by reference
+            uint32_t *set = (uint32_t *)h->d_btab;
+            hipLaunchKernelGGL(k_gr_set_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_flags,
+                               h->d_bases, h->d_stamps, h->k, set, bcap - 1);
+            hipLaunchKernelGGL(k_gr_pull_reads, dim3((unsigned)std::min<uint64_t>(tiles * 32, 1u << 16)), dim3(256), 0, h->stream,
+                               h->d_bases, h->n_bytes, h->d_startbits, h->k, set, bcap - 1, h->d_stamps, h->d_offsets,
+                               h->n_reads, h->d_read_flags);
         } else {
         hipLaunchKernelGGL(k_branch_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                            h->d_flags, h->d_keys, (unsigned long long *)h->d_btab, bcap - 1);
@@ -2223,7 +2306,8 @@ extern "C" int dbg_get_stats(dbg_t *h, dbg_stats_t *o) {
 extern "C" int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint32_t *counts, uint8_t *flags) {
     if (!h || !h->k) return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    D2H(h, keys, h->d_keys, h->n_nodes * 8);
+    if (keys && !h->d_keys) memset(keys, 0, h->n_nodes * 8);  // k-mers kept by reference (generic alphabet, k >= 12): see stamps
+    else D2H(h, keys, h->d_keys, h->n_nodes * 8);
     D2H(h, stamps, h->d_stamps, h->n_nodes * 8);
     D2H(h, counts, h->d_cnt, h->n_nodes * 4 * h->D);
     D2H(h, flags, h->d_flags, h->n_nodes);

@@ -7,9 +7,10 @@ through the C ABI of ``include/dbg.h`` (binding: ``_dbg.py``).  There is no CPU
 path: without the built library and a GPU every call raises.
 
 Differences a caller can observe, all documented in DESIGN.md:
-  * limits of the packed k-mer words: reads of upper-case A/C/G/T only: 1 <= k <= 63 (two 64-bit words
-    per k-mer above 31); any other alphabet (peptides, lower case, N, ...): at most 32 distinct
-    single-byte characters and 1 <= k <= 11 (ValueError otherwise -- never a silent drop or split);
+  * limits: 1 <= k <= 63 (reads of upper-case A/C/G/T only: two 64-bit words per k-mer above 31; any other
+    alphabet -- peptides, lower case, N, ... --: at most 32 distinct single-byte characters, packed at
+    5 bits up to k = 11 and keyed by reference into the reads above); ValueError otherwise, never a
+    silent drop or split;
   * ``output_contigs`` needs the objects returned by this module's ``construct_graph``;
   * graphs of ``LAZY_MIN_NODES`` (2e6, env ``DBG_LAZY_MIN_NODES``) or more nodes come back as read-only
     ``Mapping`` views over the exported arrays (label lookup, ``len``, ordered iteration; equal to the
@@ -300,7 +301,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     Returns ((vertices, edges), pull_out_read, branch_kmer, already_pull_out, edge_count_table).
     """
     if not isinstance(k, (int, np.integer)) or not (1 <= int(k) <= 63):
-        raise ValueError("the device path supports 1 <= k <= 63 (1 <= k <= 11 for alphabets other than ACGT)")
+        raise ValueError("the device path supports 1 <= k <= 63")
     k = int(k)
     if isinstance(reads, DeviceReads):
         g = reads._graph  # reads are resident (alphabet is checked by the kernels: AlphabetError is a ValueError)
@@ -331,7 +332,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     alphabet, bits = g.alphabet()                 # code -> character
     chars = alphabet.decode("latin-1")
     order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
-    keys_hi = g.export_keys_hi()[order] if bits * k > 64 else None
+    keys_hi = g.export_keys_hi()[order] if bits == 2 and bits * k > 64 else None
     counts_o = counts[order]
     rank_mc, rank_fs = rank_mc[order], rank_fs[order]
     flags_o = flags[order]
@@ -341,8 +342,14 @@ def construct_graph(reads, k, threshold=3, final=False):
     keep_o = g.export_keepmask()[order]
     n_ranks = rank_mc.shape[1]
 
-    lazy = len(order) >= LAZY_MIN_NODES
-    if lazy:
+    byref = bits == 5 and bits * (k + 1) > 64  # generic alphabet, k >= 12: a node's k-mer is the text at its first occurrence
+    lazy = len(order) >= LAZY_MIN_NODES and not byref
+    if byref:
+        text = reads._pull()[0] if isinstance(reads, DeviceReads) else bases.tobytes().decode("latin-1")
+        labels = [text[p:p + k] for p in (stamps[order] >> np.uint64(1)).tolist()]
+        vertices, edges, ect = _Vertices(), {}, {}
+        take = lambda idx: [labels[i] for i in idx]
+    elif lazy:
         store = _NodeStore(k, alphabet, bits, keys[order], keys_hi, counts_o, rank_mc, rank_fs, indeg, outdeg, pulled_o, keep_o)
         vertices, edges, ect = _LazyVertices(store), _LazyEdges(store), _LazyEdgeCounts(store)
         take = store.labels

@@ -14,7 +14,7 @@ from oracle import dbg_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["driver_dna_k5_8", "driver_dna_k12_15", "driver_peptide_k3_5", "driver_dna_k30_34"])
+@pytest.mark.parametrize("name", ["driver_dna_k5_8", "driver_dna_k12_15", "driver_peptide_k3_5", "driver_dna_k30_34", "driver_peptide_k10_14"])
 def test_driver_matches_reference_vectors(name):
     import II_assembleFromReads as drv
     case = load_golden(name)

@@ -82,10 +82,11 @@ def test_golden_case(name):
         assert_same(got, ref, inp["final"], name + " (reference)")
 
 
-@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240), ("fuzz_wide", 160)])
+@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240), ("fuzz_wide", 160), ("fuzz_peptide_wide", 120)])
 def test_fuzz_family_against_reference_vectors(family, n_min):
     """fuzz_small: sub-alphabets of ACGT (2-bit path); fuzz_peptide: amino acids (generic 5-bit path);
-    fuzz_wide: 32 <= k <= 63 (two-word k-mers) with repeats longer than k, tips and tandem-repeat cycles."""
+    fuzz_wide: 32 <= k <= 63 (two-word k-mers) with repeats longer than k, tips and tandem-repeat cycles;
+    fuzz_peptide_wide: peptides / N-containing / mixed-case reads at k = 12..40 (tables keyed by reference)."""
     with open(os.path.join(GOLDEN, family + ".json")) as fh:
         cases = json.load(fh)
     n = 0
@@ -148,15 +149,19 @@ def test_other_alphabets_take_the_generic_path():
 def test_alphabet_limits_fail_loudly():
     import _dbg
     import debruijn as prod
-    with pytest.raises(ValueError):      # non-ACGT needs 5 bits per character: k <= 11
-        prod.construct_graph(["EVQLVESGGGLVQPGGSLRL"], 12)
     with pytest.raises(ValueError):      # more than 32 distinct characters
         prod.construct_graph(["".join(chr(48 + i) for i in range(40))], 3)
+    with pytest.raises(ValueError):      # k-mers longer than 63 characters
+        prod.construct_graph(["ACGT" * 40], 64)
     g = _dbg.Graph()
-    b = np.frombuffer(b"ACGTNACGTACGTACGT", dtype=np.uint8)
+    b = np.frombuffer(("".join(chr(48 + i) for i in range(40)) * 2).encode(), dtype=np.uint8)
     g.set_reads(b, np.array([0, b.size], dtype=np.uint64))
     with pytest.raises(_dbg.AlphabetError):
         g.build(12)
+    # peptides beyond one packed word (k >= 12) take the by-reference tables: same results as the oracle
+    reads = ["EVQLVESGGGLVQPGGSLRLSCAAS", "GGGLVQPGGSLRLSCAASGFTFS", "EVQLVESGGGLVQPGGSLRL"]
+    for k in (11, 12, 16, 20):
+        assert_same(run_product(reads, k, 2, False), run_oracle(reads, k, 2, False), False, f"peptides k={k}")
 
 
 def test_empty_and_degenerate_inputs():

@@ -38,7 +38,7 @@ def test_oracle_matches_reference_vectors(name):
         assert got[key] == want, f"{name}: digest {key} differs from the reference"
 
 
-@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240), ("fuzz_wide", 160)])
+@pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240), ("fuzz_wide", 160), ("fuzz_peptide_wide", 120)])
 def test_oracle_fuzz_family(family, n_min):
     with open(os.path.join(GOLDEN, family + ".json")) as fh:
         cases = json.load(fh)
@@ -50,7 +50,7 @@ def test_oracle_fuzz_family(family, n_min):
             assert res[f] == case["result"][f], f"fuzz case {i}: field {f} differs ({inp})"
 
 
-@pytest.mark.parametrize("name", ["driver_dna_k5_8", "driver_dna_k12_15", "driver_peptide_k3_5", "driver_dna_k30_34"])
+@pytest.mark.parametrize("name", ["driver_dna_k5_8", "driver_dna_k12_15", "driver_peptide_k3_5", "driver_dna_k30_34", "driver_peptide_k10_14"])
 def test_oracle_multi_k_driver(name):
     case = load_golden(name)
     inp = case["inputs"]
