@@ -1692,7 +1692,7 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
     while (cap < want) { cap <<= 1; ++lg; }
     const uint64_t pk_words = (h->n_bytes + 31) / 32, n_occ = cap / 32;
     uint64_t *pk = nullptr;
-    unsigned long long *tab = nullptr;
+    WSlot *tab = nullptr;
     uint32_t *tcnt = nullptr, *occ = nullptr, *word_rank = nullptr;
     auto cleanup = [&]() {};  // everything lives in the grow-only arena (hipMalloc of tens of GB costs seconds)
     int rc = DBG_OK;
@@ -1700,17 +1700,17 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
     do {
         Timer t(h->stream);
         if ((rc = buf_ensure(h, h->ar_wide[0], (pk_words + 3) * 8)) != DBG_OK) break;
-        if ((rc = buf_ensure(h, h->ar_wide[1], cap * 8)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot))) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[2], cap * 16)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[3], n_occ * 4)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[4], n_occ * 4)) != DBG_OK) break;
         pk = (uint64_t *)h->ar_wide[0].p;
-        tab = (unsigned long long *)h->ar_wide[1].p;
+        tab = (WSlot *)h->ar_wide[1].p;
         tcnt = (uint32_t *)h->ar_wide[2].p;
         occ = (uint32_t *)h->ar_wide[3].p;
         word_rank = (uint32_t *)h->ar_wide[4].p;
         (void)hipMemsetAsync(pk + pk_words, 0, 3 * 8, h->stream);
-        (void)hipMemsetAsync(tab, 0xFF, cap * 8, h->stream);
+        (void)hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream);
         (void)hipMemsetAsync(tcnt, 0, cap * 16, h->stream);
         (void)hipMemsetAsync(occ, 0, n_occ * 4, h->stream);
         (void)hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream);
@@ -1755,7 +1755,7 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
         h->nodes_in_arena = true;
         hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
-                           pk, k, h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
+                           h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
         h->stats.ms_compact = tg.stop();
         Timer ts(h->stream);
         if (total)

@@ -5,8 +5,9 @@
 // with a 16-bit fingerprint, and the key of a slot is "the k-mer at that offset of the reads".
 // Claiming a slot is one 64-bit CAS, keeping the first occurrence is one 64-bit atomicMin (every
 // value a slot ever holds points at an instance of the same k-mer, so its key never changes), and
-// a probe compares against the 2-bit packed copy of the reads -- immutable, hence race-free.
-// After compaction the slot holds the node id instead and compares go to the node key arrays.
+// a probe compares against the 2-bit packed copy of the reads -- immutable, hence race-free.  Each slot also
+// carries a write-once cache of its key next to the protocol word (struct WSlot): a hit there costs one sector.
+// After compaction the protocol word holds the node id.
 //
 //   k_wpack        ASCII reads -> 2 bits per base, 32 bases per word        [debruijn.py:129-143 input]
 //   k_wcount       every k-mer instance: insert / first-occurrence stamp / successor counter
@@ -41,8 +42,15 @@ __device__ inline K128 k128_append(K128 key, uint32_t b, int k) {
     return r;
 }
 
-constexpr uint64_t W_STAMP_MASK = (1ull << 48) - 1;  // slot = fingerprint << 48 | stamp (later: node id)
+constexpr uint64_t W_STAMP_MASK = (1ull << 48) - 1;  // ref = fingerprint << 48 | stamp (later: node id)
 constexpr uint64_t W_EMPTY = ~0ull;
+// One 32-byte sector per slot.  `ref` is the protocol word (see the header of this file); lo/hi are a CACHE of the slot's
+// key, written once by the lane that claimed the slot, all-ones until then (no k-mer has hi == ~0).  A probe that
+// finds its own key there is done with one sector; anything else (not written yet, or another key with the same
+// fingerprint) falls back to the compare by reference, which is what makes the table exact.
+struct alignas(32) WSlot {
+    unsigned long long ref, lo, hi, pad;
+};
 
 // 64 bases starting at base p of the packed reads (the array is padded with three zero words)
 __device__ inline void packed_windows(const uint64_t *__restrict__ pk, uint64_t p, uint64_t &A, uint64_t &B) {
@@ -106,7 +114,7 @@ __device__ inline bool tile_inst(const TileLds &t, int j, int k, WInst &o) {
 
 __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, uint64_t n_bytes,
                                                 const uint32_t *__restrict__ startbits, int k,
-                                                const uint64_t *__restrict__ pk, unsigned long long *tab, uint32_t *tcnt,
+                                                const uint64_t *__restrict__ pk, WSlot *tab, uint32_t *tcnt,
                                                 uint64_t cap_mask, int hash_shift, uint32_t *occ,
                                                 unsigned long long *scalars) {
     __shared__ TileLds t;
@@ -129,21 +137,29 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
         uint64_t slot = hv >> hash_shift;
         bool found = false;
         for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
-            unsigned long long cur = __hip_atomic_load(&tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            WSlot *s = tab + slot;
+            unsigned long long cur = __hip_atomic_load(&s->ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == W_EMPTY) {
-                cur = atomicCAS(&tab[slot], W_EMPTY, mine);
+                cur = atomicCAS(&s->ref, W_EMPTY, mine);
                 if (cur == W_EMPTY) {
+                    __hip_atomic_store(&s->lo, (unsigned long long)in.key.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&s->hi, (unsigned long long)in.key.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     atomicOr(&occ[slot >> 5], 1u << (slot & 31));
                     found = true;
                     break;
                 }
             }
-            if ((cur >> 48) == (mine >> 48) && k128_eq(packed_kmer(pk, (cur & W_STAMP_MASK) >> 1, k), in.key)) {
-                // same fingerprint: the smaller value is the earlier instance.  Most instances are not the first
-                // of their k-mer (30x coverage) and skip the atomic: the slot only ever decreases
-                if (mine < cur) atomicMin(&tab[slot], mine);
-                found = true;
-                break;
+            if ((cur >> 48) == (mine >> 48)) {
+                const unsigned long long clo = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long chi = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((clo == in.key.lo && chi == in.key.hi) ||
+                    k128_eq(packed_kmer(pk, (cur & W_STAMP_MASK) >> 1, k), in.key)) {
+                    // the smaller value is the earlier instance.  Most instances are not the first of their k-mer
+                    // (30x coverage) and skip the atomic: the slot only ever decreases
+                    if (mine < cur) atomicMin(&s->ref, mine);
+                    found = true;
+                    break;
+                }
             }
             slot = (slot + 1) & cap_mask;
         }
@@ -161,9 +177,9 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
 }
 
 // occupied slots -> node arrays (table order); the slot keeps its fingerprint and takes the node id
-__global__ __launch_bounds__(256) void k_wgather(unsigned long long *tab, const uint32_t *__restrict__ tcnt,
+__global__ __launch_bounds__(256) void k_wgather(WSlot *tab, const uint32_t *__restrict__ tcnt,
                                                  const uint32_t *occ, const uint32_t *word_rank, uint64_t n_words,
-                                                 const uint64_t *__restrict__ pk, int k, uint64_t *keys_lo, uint64_t *keys_hi,
+                                                 uint64_t *keys_lo, uint64_t *keys_hi,
                                                  uint64_t *stamps, uint32_t *cnt, uint8_t *flags) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
@@ -173,36 +189,30 @@ __global__ __launch_bounds__(256) void k_wgather(unsigned long long *tab, const 
         const int b = __ffs(bits) - 1;
         bits &= bits - 1;
         const uint64_t slot = w * 32 + b;
-        const unsigned long long cur = tab[slot];
-        const uint64_t st = cur & W_STAMP_MASK;
-        const K128 key = packed_kmer(pk, st >> 1, k);
-        keys_lo[node] = key.lo;
-        keys_hi[node] = key.hi;
+        const WSlot sl = tab[slot];  // the key cache is complete: the count kernel has finished
+        const uint64_t st = sl.ref & W_STAMP_MASK;
+        keys_lo[node] = sl.lo;
+        keys_hi[node] = sl.hi;
         stamps[node] = st;
         reinterpret_cast<uint4 *>(cnt)[node] = reinterpret_cast<const uint4 *>(tcnt)[slot];
         flags[node] = (uint8_t)(st & 1);
-        tab[slot] = (cur & ~W_STAMP_MASK) | node;
+        tab[slot].ref = (sl.ref & ~W_STAMP_MASK) | node;
         ++node;
     }
 }
 
-__device__ inline uint32_t wtab_find(const unsigned long long *__restrict__ tab, uint64_t cap_mask, int hash_shift, K128 key,
-                                     const uint64_t *__restrict__ keys_lo, const uint64_t *__restrict__ keys_hi) {
-    const uint64_t hv = k128_hash(key);
-    uint64_t slot = hv >> hash_shift;
+__device__ inline uint32_t wtab_find(const WSlot *__restrict__ tab, uint64_t cap_mask, int hash_shift, K128 key) {
+    uint64_t slot = k128_hash(key) >> hash_shift;
     for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
-        const unsigned long long cur = tab[slot];
-        if (cur == W_EMPTY) return NO_NODE;
-        if ((cur >> 48) == (hv & 0xFFFFull)) {
-            const uint32_t node = (uint32_t)(cur & W_STAMP_MASK);
-            if (keys_lo[node] == key.lo && keys_hi[node] == key.hi) return node;
-        }
+        const WSlot sl = tab[slot];  // one sector: reference word and key
+        if (sl.ref == W_EMPTY) return NO_NODE;
+        if (sl.lo == key.lo && sl.hi == key.hi) return (uint32_t)(sl.ref & W_STAMP_MASK);
         slot = (slot + 1) & cap_mask;
     }
     return NO_NODE;
 }
 
-__global__ __launch_bounds__(256) void k_wsucc(const unsigned long long *__restrict__ tab, uint64_t cap_mask, int hash_shift, int k,
+__global__ __launch_bounds__(256) void k_wsucc(const WSlot *__restrict__ tab, uint64_t cap_mask, int hash_shift, int k,
                                                uint64_t n_nodes, const uint64_t *__restrict__ keys_lo,
                                                const uint64_t *__restrict__ keys_hi, const uint32_t *__restrict__ cnt,
                                                uint32_t *succ, uint8_t *order, uint8_t *deg) {
@@ -214,7 +224,7 @@ __global__ __launch_bounds__(256) void k_wsucc(const unsigned long long *__restr
     uint32_t s[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
-        s[b] = c[b] ? wtab_find(tab, cap_mask, hash_shift, k128_append(key, (uint32_t)b, k), keys_lo, keys_hi) : NO_NODE;
+        s[b] = c[b] ? wtab_find(tab, cap_mask, hash_shift, k128_append(key, (uint32_t)b, k)) : NO_NODE;
     reinterpret_cast<uint4 *>(succ)[i] = make_uint4(s[0], s[1], s[2], s[3]);
     deg[i] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
     uint32_t code[4] = {0, 1, 3, 2};  // ascii order A, C, G, T as codes; rank by (count desc, ascii asc)
