@@ -113,6 +113,7 @@ struct dbg {
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
+    bool partial_graph = false;   // the node table is one shard of several: successor ids point into other handles
     // branch k-mer lookup (pull-out reads)
     uint64_t *d_btab = nullptr;
     uint64_t btab_cap = 0;
@@ -1203,6 +1204,9 @@ __global__ __launch_bounds__(256) void k_walk_desc(const uint32_t *starts, uint6
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+// a shard's successor ids (owner << 29 | id) index other handles' node tables: traversal kernels must not follow them
+static const char *const kPartialGraph =
+    "this handle holds one shard of a multi-GPU build: gather the shards first (multi_gpu.gather_graph / dbg_import_graph)";
 static void free_build(dbg *h) {
     dev_free(h->d_tab); dev_free(h->d_occ);
     if (h->nodes_in_arena) {
@@ -1224,6 +1228,7 @@ static void free_build(dbg *h) {
     dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
     dev_free(h->d_ctg_seq);
+    h->partial_graph = false;
     h->k = 0; h->cap = 0; h->n_nodes = h->n_edges = 0;
     h->pruned = h->tipped = h->pull_reads_done = h->walked = h->walk_indexed = false;
     h->n_branch = h->n_pulled = h->tip_rounds = h->n_pull_reads = 0;
@@ -1880,7 +1885,7 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
 
 extern "C" int dbg_refine_edge_order(dbg_t *h) {
     if (!h || !h->k) return DBG_E_ARG;
-    if (h->shard_state && shard_of(h).shard_bits) { h->err = "edge-order refinement is single-GPU for now"; return DBG_E_ARG; }
+    if (h->partial_graph) { h->err = kPartialGraph; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     if (h->D == GEN_D) return DBG_OK;  // the generic engine ranks by per-edge first-seen positions at build time
     dev_free(h->d_fsorder);
@@ -2005,6 +2010,7 @@ extern "C" int dbg_get_alphabet(dbg_t *h, char *codes32, int *n_symbols, int *bi
 extern "C" int dbg_prune(dbg_t *h, double threshold) {
     if (!h || !h->k) return DBG_E_ARG;
     if (threshold == 0.0) { h->err = "threshold must be non-zero (the reference divides by it)"; return DBG_E_ARG; }
+    if (h->partial_graph) { h->err = kPartialGraph; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     Timer t(h->stream);
     HIPCHK(h, hipMemsetAsync(h->d_scalars + 16, 0, 8, h->stream));
@@ -2978,6 +2984,7 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
     h->n_edge_inst = n_edge;
     for (int d = 0; d < n_shards; ++d) { q_starts[d] = sh.q_start[d]; q_counts[d] = sh.q_cnt[d]; }
     *d_q_keys = h->ar_shard[0].p;
+    h->partial_graph = n_shards > 1;
     h->stats.ms_build_total = t_total.stop();
     return DBG_OK;
 }

@@ -160,6 +160,12 @@ def main():
         succ = g.export_succ()
         rp, col, cnt = g.export_csr()
         assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+        if world > 1:  # a shard's successor ids point into other ranks' tables: traversal must refuse, not follow them
+            try:
+                g.prune(2)
+                raise AssertionError("prune on a shard must fail")
+            except _dbg.DbgError as e:
+                assert "gather" in str(e)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, stamps=stamps, counts=counts, succ=succ)
     # ---- traversal after the sharded build: gather to rank 0, then the single-GPU path
     if mode == "fake":
