@@ -227,7 +227,14 @@ int dbg_shard_apply(dbg_t *h, const void *d_answers);
  * afterwards the handle is what dbg_build would have produced on the whole read set (node order aside):
  * dbg_refine_edge_order, dbg_prune, dbg_remove_tips, dbg_mark_pull_reads, dbg_walk and the exports apply. */
 int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *shard_nodes, const void *d_keys,
-                     const void *d_stamps, const void *d_counts, const void *d_succ);
+                     const void *d_keys_hi, const void *d_stamps, const void *d_counts, const void *d_succ);
+/* k > 31 (two-word k-mers): d_keys_hi is required and d_succ is ignored -- the shards of such a build carry keys,
+ * stamps and counts only (the k-mer INSTANCES travel between ranks, dbg_shard_extract / dbg_shard_build take and
+ * return (lo, hi | next base << 62, local stamp | has-successor << 32) u64 triples and there are no successor
+ * queries); dbg_import_graph resolves every successor with one table over the gathered nodes.
+ * k <= 31: d_keys_hi may be NULL. */
+/* device pointer of the upper key words (NULL for k <= 31) */
+int dbg_device_keys_hi(dbg_t *h, const void **d_keys_hi);
 
 #ifdef __cplusplus
 }

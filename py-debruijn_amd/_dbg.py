@@ -30,7 +30,7 @@ SYMBOLS = (
     "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
-    "dbg_import_graph",
+    "dbg_import_graph", "dbg_device_keys_hi",
 )
 
 
@@ -116,7 +116,8 @@ def load_library():
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_shard_apply": (C.c_int, [H, vp]),
-        "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp]),
+        "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp, vp]),
+        "dbg_device_keys_hi": (C.c_int, [H, C.POINTER(vp)]),
         "dbg_reads_device": (C.c_int, [H, C.POINTER(vp), u64p, C.POINTER(vp), u64p]),
     }
     for name, (res, args) in sig.items():
@@ -342,8 +343,9 @@ class Graph:
         counts = [int(c) for c in counts]
         n = sum(counts)
         dev = self.sizes_device()
+        # k <= 31: super-k-mer records (w0, w1, 32-bit stamp); k > 31: k-mer instances (lo, hi | next << 62, 64-bit meta)
         return counts, (device_tensor(p0.value, n, "int64", dev), device_tensor(p1.value, n, "int64", dev),
-                        device_tensor(p2.value, n, "int32", dev))
+                        device_tensor(p2.value, n, "int32" if int(k) <= 31 else "int64", dev))
 
     def sizes_device(self):
         return getattr(self, "_device_index", default_device())
@@ -379,8 +381,13 @@ class Graph:
         p = [C.c_void_p() for _ in range(5)]
         self._chk(self._lib.dbg_device_views(self._h, *[C.byref(x) for x in p]))
         n, dev = self.sizes()["n_nodes"], self.sizes_device()
-        return {"keys": device_tensor(p[0].value, n, "int64", dev), "stamps": device_tensor(p[2].value, n, "int64", dev),
-                "counts": device_tensor(p[1].value, 4 * n, "int32", dev), "succ": device_tensor(p[4].value, 4 * n, "int32", dev)}
+        out = {"keys": device_tensor(p[0].value, n, "int64", dev), "stamps": device_tensor(p[2].value, n, "int64", dev),
+               "counts": device_tensor(p[1].value, 4 * n, "int32", dev), "succ": device_tensor(p[4].value, 4 * n, "int32", dev)}
+        hi = C.c_void_p()
+        self._chk(self._lib.dbg_device_keys_hi(self._h, C.byref(hi)))
+        if hi.value:  # two-word k-mers
+            out["keys_hi"] = device_tensor(hi.value, n, "int64", dev)
+        return out
 
     def reads_tensors(self):
         """Zero-copy torch views of the resident reads: (bases uint8 [n_bytes], offsets int64 [n_reads + 1])."""
@@ -394,12 +401,12 @@ class Graph:
         self.set_reads_device(bases.data_ptr(), bases.numel(), offsets.data_ptr(), offsets.numel() - 1,
                               keepalive=(bases, offsets))
 
-    def import_graph(self, k, shard_nodes, keys, stamps, counts, succ):
+    def import_graph(self, k, shard_nodes, keys, stamps, counts, succ, keys_hi=None):
         """Install the concatenated shard arrays (torch tensors on this device) as this handle's graph."""
         sn = (C.c_uint64 * len(shard_nodes))(*[int(x) for x in shard_nodes])
-        ptr = lambda t: C.c_void_p(t.data_ptr()) if t.numel() else None
-        self._chk(self._lib.dbg_import_graph(self._h, int(k), len(shard_nodes), sn, ptr(keys), ptr(stamps), ptr(counts),
-                                             ptr(succ)))
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        self._chk(self._lib.dbg_import_graph(self._h, int(k), len(shard_nodes), sn, ptr(keys), ptr(keys_hi), ptr(stamps),
+                                             ptr(counts), ptr(succ)))
 
 
 class _DevView:

@@ -2396,6 +2396,12 @@ extern "C" int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint
     return DBG_OK;
 }
 
+extern "C" int dbg_device_keys_hi(dbg_t *h, const void **d_keys_hi) {
+    if (!h || !h->k || !d_keys_hi) return DBG_E_ARG;
+    *d_keys_hi = h->d_keys_hi;
+    return DBG_OK;
+}
+
 extern "C" int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_bytes, const void **d_offsets, uint64_t *n_reads) {
     if (!h || !h->d_offsets) { if (h) h->err = "no reads set"; return DBG_E_ARG; }
     if (d_bases) *d_bases = h->d_bases;
@@ -2882,12 +2888,147 @@ __global__ __launch_bounds__(256) void k_apply_remote(const uint64_t *__restrict
 
 static int shard_args_ok(dbg *h, int k, int n_shards) {
     if (!h) return DBG_E_ARG;
-    if (k < 1 || k > 31) { h->err = "k must be in 1..31"; return DBG_E_ARG; }
+    if (k < 1 || k > 63) { h->err = "k must be in 1..63"; return DBG_E_ARG; }
     if (n_shards < 1 || n_shards > 8 || (n_shards & (n_shards - 1))) {
         h->err = "n_shards must be 1, 2, 4 or 8 (owner = top bits of the bucket hash; node ids keep 29 bits)";
         return DBG_E_ARG;
     }
     if (h->engine != 0) { h->err = "sharded builds use the super-k-mer engine"; return DBG_E_ARG; }
+    return DBG_OK;
+}
+
+// ---- two-word k-mers (32 <= k <= 63): the instances travel, see dbg_wide.h
+struct HasSuccBit {
+    const uint64_t *t_st;
+    __device__ uint64_t operator()(uint64_t i) const { return (t_st[i] >> 32) & 1ull; }
+};
+
+static int shard_extract_wide(dbg *h, int k, int n_shards, uint64_t *send_counts, const void **d_lo, const void **d_hi,
+                              const void **d_st) {
+    free_build(h);
+    h->stats = dbg_stats_t{};
+    CHK(compute_alphabet(h));
+    if (!h->is_dna) { h->err = "sharded builds take ACGT reads"; return DBG_E_ALPHABET; }
+    int shard_bits = 0;
+    while ((1 << shard_bits) < n_shards) ++shard_bits;
+    Timer t(h->stream);
+    unsigned long long *cursor = (unsigned long long *)(h->d_scalars + 48);
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+    const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+    if (tiles)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ws_extract<false>), dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases,
+                           h->n_bytes, h->d_startbits, k, shard_bits, cursor, (uint64_t *)nullptr, (uint64_t *)nullptr,
+                           (uint64_t *)nullptr, (unsigned long long *)h->d_scalars);
+    uint64_t sc[64];
+    HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
+    h->n_kmer_inst = sc[1];
+    h->n_edge_inst = sc[2];
+    uint64_t offs[8] = {0}, total = 0;
+    for (int d = 0; d < 8; ++d) {
+        offs[d] = total;
+        if (d < n_shards) send_counts[d] = sc[48 + d];
+        total += sc[48 + d];
+    }
+    for (int a = 0; a < 3; ++a) CHK(buf_ensure(h, h->ar_rec[0][a], (total + 16) * 8));
+    uint64_t *lo = (uint64_t *)h->ar_rec[0][0].p, *hi = (uint64_t *)h->ar_rec[0][1].p, *st = (uint64_t *)h->ar_rec[0][2].p;
+    HIPCHK(h, hipMemcpyAsync(cursor, offs, sizeof(offs), hipMemcpyHostToDevice, h->stream));
+    if (tiles)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ws_extract<true>), dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases,
+                           h->n_bytes, h->d_startbits, k, shard_bits, cursor, lo, hi, st, (unsigned long long *)h->d_scalars);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    h->stats.ms_extract = t.stop();
+    h->stats.n_records = total;
+    *d_lo = lo; *d_hi = hi; *d_st = st;
+    ShardState &sh = shard_of(h);
+    sh.n_shards = n_shards;
+    sh.k = k;
+    sh.n_kmer_inst_local = h->n_kmer_inst;
+    return DBG_OK;
+}
+
+static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uint64_t *t_lo, const uint64_t *t_hi,
+                            const uint64_t *t_st, const uint64_t *recv_counts, const uint64_t *stamp_base,
+                            uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys) {
+    uint64_t n_rec = 0;
+    std::vector<uint64_t> seg(n_shards);
+    for (int r = 0; r < n_shards; ++r) { seg[r] = n_rec; n_rec += recv_counts[r]; }
+    h->k = k;
+    h->stats.n_records = n_rec;
+    Timer t_total(h->stream);
+    uint64_t cap = 1024;
+    int lg = 10;
+    while (cap < (uint64_t)((double)(n_rec + 1) / 0.7)) { cap <<= 1; ++lg; }
+    const uint64_t n_occ = cap / 32;
+    CHK(buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot)));
+    CHK(buf_ensure(h, h->ar_wide[2], cap * 16));
+    CHK(buf_ensure(h, h->ar_wide[3], n_occ * 4));
+    CHK(buf_ensure(h, h->ar_wide[4], n_occ * 4));
+    WSlot *tab = (WSlot *)h->ar_wide[1].p;
+    uint32_t *tcnt = (uint32_t *)h->ar_wide[2].p, *occ = (uint32_t *)h->ar_wide[3].p, *word_rank = (uint32_t *)h->ar_wide[4].p;
+    HIPCHK(h, hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream));
+    HIPCHK(h, hipMemsetAsync(tcnt, 0, cap * 16, h->stream));
+    HIPCHK(h, hipMemsetAsync(occ, 0, n_occ * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+    Timer tc(h->stream);
+    for (int r = 0; r < n_shards; ++r) {
+        if (!recv_counts[r]) continue;
+        hipLaunchKernelGGL(k_ws_insert, dim3(grid_for(recv_counts[r], 256)), dim3(256), 0, h->stream, t_lo, t_hi, t_st, seg[r],
+                           recv_counts[r], stamp_base[r] << 1, tab, tcnt, cap - 1, 64 - lg, occ,
+                           (unsigned long long *)h->d_scalars);
+    }
+    uint64_t sc0 = 0;
+    HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+    h->stats.ms_count = tc.stop();
+    HIPCHK(h, hipGetLastError());
+    if (sc0 & 2) { h->err = "hash table capacity exceeded"; return DBG_E_CAPACITY; }
+    h->stats.count_launches = (uint64_t)n_shards;
+    uint64_t n_edge = 0;
+    CHK(reduce_sum(h, n_rec, HasSuccBit{t_st}, &n_edge));
+    h->n_kmer_inst = n_rec;
+    h->n_edge_inst = n_edge;
+    uint64_t total = 0;
+    CHK(exclusive_scan(h, n_occ, PopcWords{occ}, word_rank, &total));
+    if (total >= (1ull << 29) - 16) { h->err = "a shard holds at most 2^29 nodes"; return DBG_E_CAPACITY; }
+    h->n_nodes = total;
+    CHK(buf_ensure(h, h->ar_node[0], total * 8));
+    CHK(buf_ensure(h, h->ar_node[1], total * 8));
+    CHK(buf_ensure(h, h->ar_node[2], total * 16));
+    CHK(buf_ensure(h, h->ar_node[3], total));
+    CHK(buf_ensure(h, h->ar_node[4], total));
+    CHK(buf_ensure(h, h->ar_node[5], total * 16));
+    CHK(buf_ensure(h, h->ar_node[6], total));
+    CHK(buf_ensure(h, h->ar_wide[5], total * 8));
+    h->d_keys = (uint64_t *)h->ar_node[0].p;
+    h->d_stamps = (uint64_t *)h->ar_node[1].p;
+    h->d_cnt = (uint32_t *)h->ar_node[2].p;
+    h->d_flags = (uint8_t *)h->ar_node[3].p;
+    h->d_order = (uint8_t *)h->ar_node[4].p;
+    h->d_succ = (uint32_t *)h->ar_node[5].p;
+    h->d_deg = (uint8_t *)h->ar_node[6].p;
+    h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
+    h->nodes_in_arena = true;
+    hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
+                       h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
+    // successors inside this shard only (ids local, untagged): the gathered graph resolves all of them (dbg_import_graph)
+    if (total)
+        hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, total,
+                           h->d_keys, h->d_keys_hi, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    ShardState &sh = shard_of(h);
+    int shard_bits = 0;
+    while ((1 << shard_bits) < n_shards) ++shard_bits;
+    sh.n_shards = n_shards; sh.my_shard = my_shard; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
+    sh.q_start.assign(n_shards, 0);
+    sh.q_cnt.assign(n_shards, 0);
+    for (int d = 0; d < n_shards; ++d) { q_starts[d] = 0; q_counts[d] = 0; }
+    *d_q_keys = nullptr;
+    h->partial_graph = n_shards > 1;
+    h->stats.ms_build_total = t_total.stop();
     return DBG_OK;
 }
 
@@ -2897,6 +3038,7 @@ extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_c
     if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
     if (h->n_bytes >= (1ull << 31)) { h->err = "a shard's reads must stay below 2 GiB (32-bit local stamps)"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    if (k > 31) return shard_extract_wide(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
     free_build(h);
     h->stats = dbg_stats_t{};
     uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
@@ -2935,6 +3077,9 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
     if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !q_starts || !q_counts || !d_q_keys)
         return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    if (k > 31)
+        return shard_build_wide(h, k, n_shards, my_shard, (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)d_st32,
+                                recv_counts, stamp_base, q_starts, q_counts, d_q_keys);
     int shard_bits = 0;
     while ((1 << shard_bits) < n_shards) ++shard_bits;
     uint64_t n_rec = 0;
@@ -3070,10 +3215,20 @@ __global__ __launch_bounds__(256) void k_import_fix(uint64_t n_nodes, const uint
     if ((threadIdx.x & 63) == 0 && edges) atomicAdd(&scalars[2], edges);
 }
 
+__global__ __launch_bounds__(256) void k_flags_from_stamps(uint64_t n, const uint64_t *__restrict__ stamps, uint8_t *flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (uint8_t)(stamps[i] & 1);
+}
+struct CountSum {
+    const uint32_t *cnt;
+    __device__ uint64_t operator()(uint64_t i) const { return cnt[i]; }
+};
+
 extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *shard_nodes, const void *d_keys,
-                                const void *d_stamps, const void *d_counts, const void *d_succ) {
+                                const void *d_keys_hi, const void *d_stamps, const void *d_counts, const void *d_succ) {
     if (!h || !shard_nodes || n_shards < 1 || n_shards > 8) return DBG_E_ARG;
-    if (k < 1 || k > 31) { h->err = "k must be in 1..31"; return DBG_E_ARG; }
+    if (k < 1 || k > 63) { h->err = "k must be in 1..63"; return DBG_E_ARG; }
+    const bool wide = k > 31;
     if (!h->d_offsets) { h->err = "set the gathered reads first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     free_build(h);
@@ -3086,7 +3241,7 @@ extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *s
         n += shard_nodes[s];
     }
     if (n >= 0xFFFFFFF0ull) { h->err = "more than 2^32-16 nodes"; return DBG_E_CAPACITY; }
-    if (n && (!d_keys || !d_stamps || !d_counts || !d_succ)) return DBG_E_ARG;
+    if (n && (!d_keys || !d_stamps || !d_counts || (!wide && !d_succ) || (wide && !d_keys_hi))) return DBG_E_ARG;
     h->k = k;
     h->stats = dbg_stats_t{};
     Timer t(h->stream);
@@ -3110,7 +3265,36 @@ extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *s
         HIPCHK(h, hipMemcpyAsync(h->d_keys, d_keys, n * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_stamps, d_stamps, n * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->d_cnt, d_counts, n * 16, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_succ, d_succ, n * 16, hipMemcpyDeviceToDevice, h->stream));
+        if (!wide) HIPCHK(h, hipMemcpyAsync(h->d_succ, d_succ, n * 16, hipMemcpyDeviceToDevice, h->stream));
+    }
+    if (wide) {
+        // two-word k-mers: the shards did not resolve successors (dbg_wide.h).  One table over all nodes, then the
+        // same successor kernel as the single-GPU build (it also writes the rank bytes and the degrees).
+        CHK(buf_ensure(h, h->ar_wide[5], n * 8));
+        h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
+        uint64_t cap = 1024;
+        int lg = 10;
+        while (cap < 2 * n + 2) { cap <<= 1; ++lg; }
+        CHK(buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot)));
+        WSlot *tab = (WSlot *)h->ar_wide[1].p;
+        HIPCHK(h, hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream));
+        if (n) {
+            HIPCHK(h, hipMemcpyAsync(h->d_keys_hi, d_keys_hi, n * 8, hipMemcpyDeviceToDevice, h->stream));
+            hipLaunchKernelGGL(k_wnode_insert, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_keys, h->d_keys_hi, tab,
+                               cap - 1, 64 - lg);
+            hipLaunchKernelGGL(k_wsucc, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, n, h->d_keys,
+                               h->d_keys_hi, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
+            hipLaunchKernelGGL(k_flags_from_stamps, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_stamps, h->d_flags);
+            HIPCHK(h, hipGetLastError());
+        }
+        uint64_t edges = 0;
+        CHK(reduce_sum(h, n * 4, CountSum{h->d_cnt}, &edges));
+        h->n_edge_inst = edges;
+        h->n_kmer_inst = 0;
+        int rcw = finish_graph(h);
+        if (rcw != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rcw; }
+        h->stats.ms_build_total = t.stop();
+        return DBG_OK;
     }
     HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->d_scalars + 48, base, sizeof(base), hipMemcpyHostToDevice, h->stream));

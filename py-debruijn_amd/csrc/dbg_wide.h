@@ -320,4 +320,134 @@ __global__ __launch_bounds__(256) void k_wedge_first_seen(const char *__restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Multi-GPU build of two-word k-mers.  The unit on the wire is the k-mer INSTANCE (the super-k-mer records of
+// the 64-bit path hold 50 bases at most): (lo, hi | next base << 62, rank-local stamp | has-successor << 32),
+// owner = top bits of the k-mer hash.  The owner counts in a table keyed by reference into the received tuples
+// (claim = tuple index, one 32-bit-wide CAS; key cache and first-occurrence stamp beside it, as in WSlot).
+// Successors are NOT resolved on the shards: traversal needs the gathered graph anyway, and
+// dbg_import_graph resolves them there with one table over all nodes -- no query exchange for this path.
+// ------------------------------------------------------------------------------------------------
+__device__ inline uint32_t ws_owner(K128 key, int shard_bits) {
+    return shard_bits ? (uint32_t)(k128_hash(key) >> (64 - shard_bits)) : 0u;
+}
+
+// pass 1: instances per owner (8 counters); pass 2: the tuples, each owner's into its own contiguous range
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_ws_extract(const char *__restrict__ bases, uint64_t n_bytes,
+                                                    const uint32_t *__restrict__ startbits, int k, int shard_bits,
+                                                    unsigned long long *owner_cursor /* [8]: counts (pass 1) / write cursors */,
+                                                    uint64_t *t_lo, uint64_t *t_hi, uint64_t *t_st,
+                                                    unsigned long long *scalars /* [0] err [1] N_k [2] N_e */) {
+    __shared__ TileLds t;
+    __shared__ uint32_t cnt[8];
+    __shared__ unsigned long long base[8];
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    const uint32_t bad = load_tile(t, bases, n_bytes, startbits, tile0);
+    if (bad && !EMIT) atomicOr(&scalars[0], 1ull);
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t slot_of_round[TILE / 256];  // owner | rank << 3, 0xFFFFFFFF: no instance
+    uint64_t n_k = 0, n_e = 0;
+#pragma unroll
+    for (int r = 0; r < TILE / 256; ++r) {
+        const int j = r * 256 + threadIdx.x;
+        slot_of_round[r] = 0xFFFFFFFFu;
+        WInst in;
+        if (tile0 + j >= n_bytes || !tile_inst(t, j, k, in) || (in.at_end && in.s0)) continue;
+        const uint32_t o = ws_owner(in.key, shard_bits);
+        slot_of_round[r] = o | (atomicAdd(&cnt[o], 1u) << 3);
+        n_k += 1;
+        n_e += in.at_end ^ 1u;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && cnt[threadIdx.x])
+        base[threadIdx.x] = atomicAdd(&owner_cursor[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    if (!EMIT) {
+        uint64_t tot_k, tot_e;
+        (void)block_exscan_256(n_k, &tot_k);
+        (void)block_exscan_256(n_e, &tot_e);
+        if (threadIdx.x == 0) {
+            if (tot_k) atomicAdd(&scalars[1], (unsigned long long)tot_k);
+            if (tot_e) atomicAdd(&scalars[2], (unsigned long long)tot_e);
+        }
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TILE / 256; ++r) {
+        if (slot_of_round[r] == 0xFFFFFFFFu) continue;
+        const int j = r * 256 + threadIdx.x;
+        WInst in;
+        (void)tile_inst(t, j, k, in);
+        const uint64_t dst = base[slot_of_round[r] & 7u] + (slot_of_round[r] >> 3);
+        const uint64_t stamp = ((tile0 + j) << 1) | (in.s0 ^ 1u);  // rank-local, < 2^32
+        t_lo[dst] = in.key.lo;
+        t_hi[dst] = in.key.hi | ((uint64_t)in.next << 62);
+        t_st[dst] = stamp | ((uint64_t)(in.at_end ^ 1u) << 32);
+    }
+}
+
+constexpr uint64_t WS_HI_MASK = (1ull << 62) - 1;
+
+// received tuples of one source rank -> the shard's table.  WSlot: ref = first-occurrence stamp (global, atomicMin),
+// lo/hi = key cache, pad = the claim: index of the tuple that created the slot (~0 free)
+__global__ __launch_bounds__(256) void k_ws_insert(const uint64_t *__restrict__ t_lo, const uint64_t *__restrict__ t_hi,
+                                                   const uint64_t *__restrict__ t_st, uint64_t first, uint64_t n,
+                                                   uint64_t stamp_base2, WSlot *tab, uint32_t *tcnt, uint64_t cap_mask,
+                                                   int hash_shift, uint32_t *occ, unsigned long long *scalars) {
+    const uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= first + n) return;
+    const K128 key{t_hi[i] & WS_HI_MASK, t_lo[i]};
+    const uint32_t next = (uint32_t)(t_hi[i] >> 62);
+    const unsigned long long gstamp = stamp_base2 + (t_st[i] & 0xFFFFFFFFull);
+    const bool has_succ = (t_st[i] >> 32) & 1ull;
+    uint64_t slot = k128_hash(key) >> hash_shift;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        WSlot *s = tab + slot;
+        unsigned long long c = __hip_atomic_load(&s->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool mine_now = false;
+        if (c == W_EMPTY) {
+            c = atomicCAS(&s->pad, W_EMPTY, (unsigned long long)i);
+            if (c == W_EMPTY) {
+                __hip_atomic_store(&s->lo, (unsigned long long)key.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&s->hi, (unsigned long long)key.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicOr(&occ[slot >> 5], 1u << (slot & 31));
+                mine_now = true;
+            }
+        }
+        if (!mine_now) {
+            const unsigned long long clo = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long chi = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the cache may not be written yet: the claiming tuple itself is the authority
+            mine_now = (clo == key.lo && chi == key.hi) || (t_lo[c] == key.lo && (t_hi[c] & WS_HI_MASK) == key.hi);
+        }
+        if (mine_now) {
+            if (gstamp < __hip_atomic_load(&s->ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&s->ref, gstamp);
+            if (has_succ) atomicAdd(&tcnt[slot * 4 + next], 1u);
+            return;
+        }
+        slot = (slot + 1) & cap_mask;
+    }
+    atomicOr(&scalars[0], 2ull);  // table full
+}
+
+// gathered graph: every node into a fresh table (keys are distinct: claim the first free slot); k_wsucc then resolves
+__global__ __launch_bounds__(256) void k_wnode_insert(uint64_t n_nodes, const uint64_t *__restrict__ keys_lo,
+                                                      const uint64_t *__restrict__ keys_hi, WSlot *tab, uint64_t cap_mask,
+                                                      int hash_shift) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const K128 key{keys_hi[i], keys_lo[i]};
+    uint64_t slot = k128_hash(key) >> hash_shift;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        if (atomicCAS(&tab[slot].ref, W_EMPTY, (unsigned long long)i) == W_EMPTY) {
+            tab[slot].lo = key.lo;
+            tab[slot].hi = key.hi;
+            return;
+        }
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
 }  // namespace dbgk

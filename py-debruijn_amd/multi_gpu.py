@@ -14,6 +14,9 @@ link of a rank at once (a ring collective would be bound by one link):
   5. all-to-all of the answers (uint32 node ids) back                 -- dbg_shard_apply
 
 After step 5 every rank holds its shard: node ids are (owner << 29) | local id, stamps are global.
+Two-word k-mers (k > 31) go through the same five calls: their records are the k-mer instances themselves
+(owner = top bits of the k-mer hash), steps 4-5 carry nothing, and the successors are resolved by
+``gather_graph`` / dbg_import_graph on the gathered node set.
 Traversal (prune / tips / pull-out reads / contig walk) crosses ranks; ``gather_graph`` moves the shards
 and the reads to one rank, whose handle then behaves like a single-GPU build (gather first).
 The graph object may be an ``_dbg.Graph`` or anything with the same four shard_* methods
@@ -38,9 +41,10 @@ def exchange_counts(dist, counts, device):
     return [int(x) for x in recv.tolist()]
 
 
-def alltoallv(dist, tensor, send_counts, recv_counts):
-    """Variable all-to-all of a 1-D tensor laid out contiguously in destination order
-    (all_to_all_single with split sizes; staged through the host for gloo)."""
+MAX_MESSAGE_BYTES = 1 << 30  # per (source, destination) pair and call; larger transfers go in rounds
+
+
+def _alltoallv_once(dist, tensor, send_counts, recv_counts):
     n_out = sum(recv_counts)
     if _is_gloo(dist):
         out = torch.empty(n_out, dtype=tensor.dtype)
@@ -48,6 +52,37 @@ def alltoallv(dist, tensor, send_counts, recv_counts):
         return out.to(tensor.device)
     out = torch.empty(n_out, dtype=tensor.dtype, device=tensor.device)
     dist.all_to_all_single(out, tensor.contiguous(), list(recv_counts), list(send_counts))
+    return out
+
+
+def alltoallv(dist, tensor, send_counts, recv_counts):
+    """Variable all-to-all of a 1-D tensor laid out contiguously in destination order
+    (all_to_all_single with split sizes; staged through the host for gloo).
+
+    A (source, destination) message of 4 GiB or more is not safe with every backend (observed: a 7 GB
+    self-copy over nccl arrived truncated), so pairs above MAX_MESSAGE_BYTES are moved in rounds of that
+    size; the number of rounds is agreed on with one all-reduce.
+    """
+    limit = max(1, MAX_MESSAGE_BYTES // tensor.element_size())
+    biggest = max(list(send_counts) + list(recv_counts) + [0])
+    t = torch.tensor([biggest], dtype=torch.int64, device="cpu" if _is_gloo(dist) else tensor.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rounds = max(1, -(-int(t.item()) // limit))
+    if rounds == 1:
+        return _alltoallv_once(dist, tensor, send_counts, recv_counts)
+    w = len(send_counts)
+    s_off = [sum(send_counts[:d]) for d in range(w)]
+    r_off = [sum(recv_counts[:d]) for d in range(w)]
+    out = torch.empty(sum(recv_counts), dtype=tensor.dtype, device=tensor.device)
+    for r in range(rounds):
+        sc = [max(0, min(limit, c - r * limit)) for c in send_counts]
+        rc = [max(0, min(limit, c - r * limit)) for c in recv_counts]
+        part = torch.cat([tensor[s_off[d] + r * limit: s_off[d] + r * limit + sc[d]] for d in range(w)])
+        got = _alltoallv_once(dist, part, sc, rc)
+        pos = 0
+        for d in range(w):
+            out[r_off[d] + r * limit: r_off[d] + r * limit + rc[d]] = got[pos:pos + rc[d]]
+            pos += rc[d]
     return out
 
 
@@ -129,6 +164,7 @@ def gather_graph(g, k, dist, dst=0, make_graph=None):
         return alltoallv(dist, x, send, recv)
 
     keys = to_dst(nodes["keys"], 0)
+    keys_hi = to_dst(nodes["keys_hi"], 0) if "keys_hi" in nodes else None  # two-word k-mers (k > 31)
     stamps = to_dst(nodes["stamps"], 0)
     counts = to_dst(nodes["counts"], 0, 4)
     succ = to_dst(nodes["succ"], 0, 4)
@@ -145,5 +181,8 @@ def gather_graph(g, k, dist, dst=0, make_graph=None):
     else:
         merged = make_graph()
     merged.set_reads_tensors(all_bases, all_offsets)
-    merged.import_graph(k, [s[0] for s in sizes], keys, stamps, counts, succ)
+    if keys_hi is None:
+        merged.import_graph(k, [s[0] for s in sizes], keys, stamps, counts, succ)
+    else:
+        merged.import_graph(k, [s[0] for s in sizes], keys, stamps, counts, succ, keys_hi)
     return merged

@@ -131,7 +131,7 @@ class NumpyMergedGraph:
     def set_reads_tensors(self, bases, offsets):
         self.bases, self.offsets = bases.numpy(), offsets.numpy()
 
-    def import_graph(self, k, shard_nodes, keys, stamps, counts, succ):
+    def import_graph(self, k, shard_nodes, keys, stamps, counts, succ, keys_hi=None):
         base = np.concatenate([[0], np.cumsum(shard_nodes)]).astype(np.uint64)
         s = succ.numpy().view(np.uint32).astype(np.uint64)
         none = s == 0xFFFFFFFF
@@ -144,6 +144,8 @@ class NumpyMergedGraph:
 def main():
     mode, out_dir, k, n_reads, read_len = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if os.environ.get("SHARD_MAX_MSG"):  # force the multi-round path of alltoallv at test sizes
+        multi_gpu.MAX_MESSAGE_BYTES = int(os.environ["SHARD_MAX_MSG"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     per = n_reads // world
     reads = synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01, first_read=rank * per)
@@ -157,6 +159,7 @@ def main():
         g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
         multi_gpu.sharded_build(g, k, dist)
         keys, stamps, counts, _ = g.export_nodes()
+        keys_hi = g.export_keys_hi()
         succ = g.export_succ()
         rp, col, cnt = g.export_csr()
         assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
@@ -166,7 +169,9 @@ def main():
                 raise AssertionError("prune on a shard must fail")
             except _dbg.DbgError as e:
                 assert "gather" in str(e)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, stamps=stamps, counts=counts, succ=succ)
+    if mode == "fake":
+        keys_hi = np.zeros_like(keys)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys, keys_hi=keys_hi, stamps=stamps, counts=counts, succ=succ)
     # ---- traversal after the sharded build: gather to rank 0, then the single-GPU path
     if mode == "fake":
         merged = multi_gpu.gather_graph(g, k, dist, dst=0, make_graph=NumpyMergedGraph)
@@ -189,7 +194,8 @@ def main():
                 off, chars, score, stamp, seq = h.export_contigs()
                 co = np.lexsort((seq, stamp))
                 text = chars.tobytes()
-                return {"keys": kk[o], "stamps": st[o], "counts": cn[o], "flags": fl[o], "order": mc[o], "fsorder": fs[o],
+                return {"keys": kk[o], "keys_hi": h.export_keys_hi()[o], "stamps": st[o], "counts": cn[o], "flags": fl[o],
+                        "order": mc[o], "fsorder": fs[o],
                         "pull_ranks": ranks[o], "pull_reads": h.export_pull_reads(),
                         "contigs": [text[int(off[i]):int(off[i + 1])] for i in co], "scores": score[co],
                         "sizes": {key: h.sizes()[key] for key in ("n_nodes", "n_edges", "n_branch", "n_pulled", "n_pull_reads",
@@ -201,7 +207,7 @@ def main():
             single.build(k)
             want = rest_of_path(single)
             assert got["sizes"] == want["sizes"], (got["sizes"], want["sizes"])
-            for key in ("keys", "stamps", "counts", "flags", "order", "fsorder", "pull_ranks", "pull_reads", "scores"):
+            for key in ("keys", "keys_hi", "stamps", "counts", "flags", "order", "fsorder", "pull_ranks", "pull_reads", "scores"):
                 assert np.array_equal(got[key], want[key]), key
             assert got["contigs"] == want["contigs"] and len(want["contigs"]) > 0
             assert allb.size == n_reads * read_len

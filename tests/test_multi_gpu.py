@@ -25,12 +25,14 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(mode, world, tmp_path, k, n_reads, read_len):
+def run_ranks(mode, world, tmp_path, k, n_reads, read_len, max_msg=None):
     port = free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if max_msg:
+            env["SHARD_MAX_MSG"] = str(max_msg)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), mode, str(tmp_path), str(k),
                                        str(n_reads), str(read_len)], env=env))
     for p in procs:
@@ -44,13 +46,16 @@ def check(shards, world, k, n_reads, read_len):
                                               first_read=r * per) for r in range(world)])
     want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
     keys = np.concatenate([s["keys"] for s in shards])
+    keys_hi = np.concatenate([s["keys_hi"] for s in shards])
     stamps = np.concatenate([s["stamps"] for s in shards])
     counts = np.concatenate([s["counts"] for s in shards])
     assert keys.size == want["n_nodes"], "every k-mer is owned by exactly one shard"
     o = np.argsort(stamps, kind="stable")
-    assert np.array_equal(keys[o], want["keys"])
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(keys_hi[o], want["keys_hi"])
     assert np.array_equal(stamps[o], want["stamps"])       # global first-occurrence stamps
     assert np.array_equal(counts[o], want["counts"])
+    if k > 31:
+        return  # two-word k-mers: the shards carry keys, stamps and counts; successors are resolved after the gather
     mask = np.uint64((1 << (2 * k)) - 1)
     for r, s in enumerate(shards):                           # successors: (owner << 29) | id on the owner
         for code in range(4):
@@ -66,9 +71,9 @@ def check(shards, world, k, n_reads, read_len):
             assert np.all(s["succ"][~has, code] == 0xFFFFFFFF)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_exchange_logic_on_cpu_gloo(world, tmp_path):
-    shards = run_ranks("fake", world, tmp_path, 9, 64, 40)
+@pytest.mark.parametrize("world,max_msg", [(2, None), (4, None), (4, 200)])  # 200 B per message: transfers go in several rounds
+def test_exchange_logic_on_cpu_gloo(world, max_msg, tmp_path):
+    shards = run_ranks("fake", world, tmp_path, 9, 64, 40, max_msg)
     check(shards, world, 9, 64, 40)
     # gather for traversal: rank 0 holds the whole graph over the rank-major concatenation of the reads
     m = np.load(os.path.join(tmp_path, "merged.npz"))
@@ -87,7 +92,7 @@ def test_exchange_logic_on_cpu_gloo(world, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,n_reads,read_len", [(21, 4000, 100), (31, 20000, 150), (5, 400, 30)])
+@pytest.mark.parametrize("k,n_reads,read_len", [(21, 4000, 100), (31, 20000, 150), (5, 400, 30), (40, 6000, 120), (63, 8000, 150)])
 def test_two_ranks_on_one_gpu(k, n_reads, read_len, tmp_path):
     shards = run_ranks("gpu", 2, tmp_path, k, n_reads, read_len)
     check(shards, 2, k, n_reads, read_len)
@@ -98,3 +103,10 @@ def test_four_ranks_on_one_gpu(tmp_path):
     """Two owner bits (the box allows at most six processes on its GPU, so eight ranks run only on the real node)."""
     shards = run_ranks("gpu", 4, tmp_path, 21, 8000, 100)
     check(shards, 4, 21, 8000, 100)
+
+
+@pytest.mark.gpu
+def test_four_ranks_on_one_gpu_two_word_kmers(tmp_path):
+    """BASELINE.json configs[4] in miniature: k = 63 over four ranks (the k-mer instances travel)."""
+    shards = run_ranks("gpu", 4, tmp_path, 63, 8000, 150)
+    check(shards, 4, 63, 8000, 150)
