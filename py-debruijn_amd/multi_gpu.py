@@ -41,7 +41,7 @@ def exchange_counts(dist, counts, device):
     return [int(x) for x in recv.tolist()]
 
 
-MAX_MESSAGE_BYTES = 1 << 30  # per (source, destination) pair and call; larger transfers go in rounds
+MAX_MESSAGE_BYTES = (1 << 31) - 4096  # per (source, destination) pair and call; larger transfers go in rounds
 
 
 def _alltoallv_once(dist, tensor, send_counts, recv_counts):
