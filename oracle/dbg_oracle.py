@@ -304,3 +304,55 @@ def assemble(sequences, k_lower, k_upper, threshold, verbose=False):
         trace[k] = {"contigs": list(sequences), "pull_out_read": list(pull)}
         sequences.extend(pull)
     return sequences, trace
+
+
+# ---- the two helpers the reference's pipeline never calls (debruijn.py:35-75, :78-95) ----------------------------
+def get_kmers(sequences, k):
+    """debruijn.py:35-75, literally: short sequences are removed, glued onto sequences that overlap them by three
+    characters, then the distinct k-mers of what is left, in first-occurrence order.  Mutates ``sequences``."""
+    short = []
+    for s in sequences:
+        if len(s) < k:
+            short.append(s)
+    for s in short:
+        sequences.remove(s)
+    it = 0
+    while it < len(short):          # a for-loop over a list that shrinks underneath it
+        piece = short[it]
+        it += 1
+        glued = False
+        for j in range(len(sequences)):
+            seq = sequences[j]
+            if seq[len(seq) - 3:] == piece[:3]:
+                sequences[j] = seq + piece[3:]
+                glued = True
+            if piece[len(piece) - 3:] == seq[:3]:
+                sequences[j] = piece + seq[3:]
+                glued = True
+        if glued:
+            short.remove(piece)
+    seen = {}
+    for s in sequences:
+        for i in range(len(s)):
+            km = s[i:i + k]
+            if len(km) == k:
+                seen[km] = seen.get(km, 0) + 1
+    return list(seen)
+
+
+def get_graph_from_kmers(kmers, k):
+    """debruijn.py:78-95, literally: all-pairs (k-1)-overlap scan."""
+    edges, vertices = {}, {}
+    for km in kmers:
+        vertices[km] = Node(km)
+        edges[km] = []
+        for other in edges:
+            if km[1:] == other[:k - 1]:
+                edges[km] = edges[km] + [other]
+                vertices[km].outdegree += 1
+                vertices[other].indegree += 1
+            if km[:k - 1] == other[1:]:
+                edges[other] = edges[other] + [km]
+                vertices[other].outdegree += 1
+                vertices[km].indegree += 1
+    return vertices, edges

@@ -277,6 +277,38 @@ def main_pepwide():
     print("driver_peptide_k10_14", len(res["final_contigs"]))
 
 
+def main_aux():
+    """The two helpers of debruijn.py the pipeline does not call (get_kmers :35-75, get_graph_from_kmers :78-95):
+    `make_golden.py aux`."""
+    import random
+    rng = random.Random(20260414)
+    cases = []
+    for i in range(300):
+        alpha = rng.choice(["ACGT", "AC", "EVQLG", "ACDEFGHIKLMNPQRSTVWY"])
+        k = rng.randint(2, 7)
+        n = rng.randint(0, 12)
+        G = "".join(rng.choice(alpha) for _ in range(rng.randint(6, 40)))
+        seqs = []
+        for _ in range(n):
+            if rng.random() < 0.7:
+                L = rng.randint(1, min(len(G), k + 8))
+                st = rng.randint(0, len(G) - L)
+                seqs.append(G[st:st + L])
+            else:
+                seqs.append("".join(rng.choice(alpha) for _ in range(rng.randint(0, k + 6))))
+        if rng.random() < 0.3 and seqs:
+            seqs += [rng.choice(seqs) for _ in range(rng.randint(1, 3))]
+        work = list(seqs)
+        kmers = ref.get_kmers(work, k)
+        V, E = ref.get_graph_from_kmers(list(kmers), k)
+        cases.append({"sequences": seqs, "k": k, "kmers": kmers, "sequences_after": work,
+                      "vertices": [[v, V[v].indegree, V[v].outdegree] for v in V], "edges": [[v, list(E[v])] for v in E]})
+    with open(os.path.join(GOLDEN, "aux_kmers.json"), "w") as fh:
+        json.dump(cases, fh, separators=(",", ":"))
+    print("aux_kmers:", len(cases), "cases;", sum(1 for c in cases if c["sequences_after"] != c["sequences"]), "with glued or dropped sequences;",
+          sum(1 for c in cases if any(i > 1 or o > 1 for _, i, o in c["vertices"])), "with degrees above 1")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     pep = ['EVQLVE', 'QLVAPG', 'LVESGGAL', 'LVESGGGL']  # II_assembleFromReads.py:55 (input only)
@@ -416,7 +448,10 @@ if __name__ == "__main__":
         main_wide()
     elif sys.argv[1:] == ["pepwide"]:
         main_pepwide()
+    elif sys.argv[1:] == ["aux"]:
+        main_aux()
     else:
         main()
         main_wide()
         main_pepwide()
+        main_aux()

@@ -28,7 +28,7 @@ import numpy as np
 import _dbg
 
 __all__ = ["Node", "read_reads", "read_reads_device", "DeviceReads", "construct_graph", "output_contigs",
-           "get_score_device"]
+           "get_score_device", "get_kmers", "get_graph_from_kmers"]
 
 
 
@@ -424,3 +424,97 @@ def output_contigs(g, branch_kmer, already_pull_out):
 def get_score_device(contigs):
     """getScore (II_assembleFromReads.py:14-18) of each contig as computed by the walk kernel."""
     return list(contigs.scores)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The two helpers of the reference module that its pipeline never calls (debruijn.py:210 mentions get_kmers in a
+# comment only).  Kept so that the module surface is complete; k-mer enumeration runs on the device, the glue
+# step and the overlap adjacency are host bookkeeping over short lists.
+# ------------------------------------------------------------------------------------------------------------------
+def _glue_short_sequences(sequences, k):
+    """debruijn.py:39-56: sequences shorter than k leave the list; each is then glued onto every remaining sequence
+    that overlaps it by exactly three characters (at either end).  Mutates ``sequences`` like the reference, and walks
+    the short list the way a Python ``for`` does while elements are removed from it (the element after a removed
+    one is skipped)."""
+    short = [s for s in sequences if len(s) < k]
+    for s in short:
+        sequences.remove(s)
+    i = 0
+    while i < len(short):
+        piece = short[i]
+        glued = False
+        for j, seq in enumerate(sequences):
+            if seq[len(seq) - 3:] == piece[:3]:
+                sequences[j] = seq + piece[3:]
+                glued = True
+            if piece[len(piece) - 3:] == seq[:3]:      # tested against the sequence as it was before this step
+                sequences[j] = piece + seq[3:]
+                glued = True
+        if glued:
+            short.remove(piece)
+        i += 1
+
+
+def get_kmers(sequences, k):
+    """debruijn.py:35-75: distinct k-mers of the sequences (after the glue step above, which mutates the argument), in
+    first-occurrence order.  Sequences longer than k go through the device build (its node table IS that list);
+    sequences of exactly k characters hold one k-mer each and are merged in by position on the host."""
+    _glue_short_sequences(sequences, k)
+    first = {}  # k-mer -> position of its first occurrence in the concatenation of the sequences
+    if any(len(s) > k for s in sequences):
+        bases, offsets = _pack_reads(sequences)
+        g = _dbg.Graph()
+        try:
+            g.set_reads(bases, offsets)
+            g.build(k)
+            keys, stamps, _, _ = g.export_nodes(counts=False, flags=False)
+            alphabet, bits = g.alphabet()
+            pos = (stamps >> np.uint64(1)).tolist()
+            if bits == 5 and bits * (k + 1) > 64:      # keyed by reference: the text at the stamp is the k-mer
+                text = bases.tobytes().decode("latin-1")
+                labels = [text[p:p + k] for p in pos]
+            else:
+                hi = g.export_keys_hi() if bits == 2 and bits * k > 64 else None
+                labels = _dbg.decode_keys(keys, k, alphabet, bits, hi)
+            first = dict(zip(labels, pos))
+        finally:
+            g.close()
+    off = 0
+    for s in sequences:
+        if len(s) == k and first.get(s, off + 1) > off:
+            first[s] = off
+        off += len(s)
+    return sorted(first, key=first.get)
+
+
+def get_graph_from_kmers(kmers, k):
+    """debruijn.py:78-95: (k-1)-overlap adjacency over a list of k-mers with true in/out degrees -- same dict and list
+    orders as the reference's all-pairs scan (quadratic there; prefix / suffix indexes here)."""
+    vertices, edges = {}, {}
+    seq_no = {}                     # key -> its position in `edges` (insertion order)
+    by_prefix, by_suffix = {}, {}   # (k-1)-character prefix / suffix -> keys in insertion order
+    for kmer in kmers:
+        if kmer not in seq_no:
+            seq_no[kmer] = len(seq_no)
+            by_prefix.setdefault(kmer[:k - 1], []).append(kmer)
+            by_suffix.setdefault(kmer[1:], []).append(kmer)
+        node = vertices[kmer] = Node(kmer)   # a repeated k-mer starts over, as in the reference
+        edges[kmer] = []
+        follows = by_prefix.get(kmer[1:], ())        # kmer -> other
+        precedes = by_suffix.get(kmer[:k - 1], ())   # other -> kmer
+        # the reference visits every key once, in insertion order, and tests "kmer -> key" before "key -> kmer"
+        a = b = 0
+        while a < len(follows) or b < len(precedes):
+            if b >= len(precedes) or (a < len(follows) and seq_no[follows[a]] <= seq_no[precedes[b]]):
+                other = follows[a]
+                a += 1
+                edges[kmer].append(other)
+                node.outdegree += 1
+                vertices[other].indegree += 1
+            else:
+                other = precedes[b]
+                b += 1
+                edges[other].append(kmer)
+                vertices[other].outdegree += 1
+                node.indegree += 1
+    return vertices, edges

@@ -28,7 +28,7 @@ def golden_case_names():
     names = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.json"))):
         n = os.path.basename(p)[:-5]
-        if n.startswith(("driver_", "fuzz_", "synth_")):
+        if n.startswith(("driver_", "fuzz_", "synth_", "aux_")):
             continue
         names.append(n)
     return names

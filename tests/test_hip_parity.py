@@ -236,3 +236,20 @@ def test_walk_index_without_text():
     assert np.array_equal(np.diff(off.astype(np.int64))[a], np.diff(off2.astype(np.int64))[b])
     with pytest.raises(_dbg.DbgError):
         g.export_contigs()
+
+
+def test_unused_helpers_against_reference_vectors():
+    """get_kmers (k-mer enumeration on the device) / get_graph_from_kmers of the drop-in module."""
+    import debruijn as prod
+    with open(os.path.join(GOLDEN, "aux_kmers.json")) as fh:
+        cases = json.load(fh)
+    for c in cases:
+        work = list(c["sequences"])
+        kmers = prod.get_kmers(work, c["k"])
+        assert kmers == c["kmers"] and work == c["sequences_after"], c["sequences"]
+        V, E = prod.get_graph_from_kmers(list(kmers), c["k"])
+        assert [[v, V[v].indegree, V[v].outdegree] for v in V] == c["vertices"]
+        assert [[v, list(E[v])] for v in E] == c["edges"]
+    V, E = prod.get_graph_from_kmers(["AAA", "AAC", "AAA"], 3)   # a repeated k-mer starts over, like the reference
+    Vo, Eo = orc.get_graph_from_kmers(["AAA", "AAC", "AAA"], 3)
+    assert [(v, V[v].indegree, V[v].outdegree, E[v]) for v in V] == [(v, Vo[v].indegree, Vo[v].outdegree, Eo[v]) for v in Vo]

@@ -57,3 +57,20 @@ def test_oracle_multi_k_driver(name):
     final, trace = orc.assemble(inp["reads"], inp["k_lowerlimit"], inp["k_upperlimit"], inp["threshold"])
     assert final == case["result"]["final_contigs"]
     assert {str(k): v for k, v in trace.items()} == case["result"]["trace"]
+
+
+def test_oracle_unused_helpers_against_reference_vectors():
+    """get_kmers / get_graph_from_kmers (debruijn.py:35-95; the pipeline never calls them)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, "aux_kmers.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) >= 300
+    for c in cases:
+        work = list(c["sequences"])
+        kmers = orc.get_kmers(work, c["k"])
+        assert kmers == c["kmers"] and work == c["sequences_after"], c["sequences"]
+        V, E = orc.get_graph_from_kmers(list(kmers), c["k"])
+        assert [[v, V[v].indegree, V[v].outdegree] for v in V] == c["vertices"]
+        assert [[v, list(E[v])] for v in E] == c["edges"]
