@@ -224,7 +224,9 @@ int dbg_shard_apply(dbg_t *h, const void *d_answers);
  * order on one GPU (device pointers: keys u64[n], stamps u64[n], counts u32[n][4], succ u32[n][4] with ids
  * (owner << 29) | id), become the graph of handle `h`, whose reads must be the rank-major concatenation of all
  * ranks' reads (the global stamps index into it).  Successor ids are rewritten to positions in the concatenation;
- * afterwards the handle is what dbg_build would have produced on the whole read set (node order aside):
+ * the arrays are BORROWED, not copied (they are most of the memory of the gathered graph): keep them alive and do
+ * not touch them while this handle uses the graph; d_succ is rewritten in place.
+ * Afterwards the handle is what dbg_build would have produced on the whole read set (node order aside):
  * dbg_refine_edge_order, dbg_prune, dbg_remove_tips, dbg_mark_pull_reads, dbg_walk and the exports apply. */
 int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *shard_nodes, const void *d_keys,
                      const void *d_keys_hi, const void *d_stamps, const void *d_counts, const void *d_succ);

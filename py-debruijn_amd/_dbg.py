@@ -405,6 +405,7 @@ class Graph:
         """Install the concatenated shard arrays (torch tensors on this device) as this handle's graph."""
         sn = (C.c_uint64 * len(shard_nodes))(*[int(x) for x in shard_nodes])
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        self._graph_keep = (keys, keys_hi, stamps, counts, succ)  # borrowed by the library, not copied
         self._chk(self._lib.dbg_import_graph(self._h, int(k), len(shard_nodes), sn, ptr(keys), ptr(keys_hi), ptr(stamps),
                                              ptr(counts), ptr(succ)))
 

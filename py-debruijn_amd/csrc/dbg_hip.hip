@@ -3245,33 +3245,30 @@ extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *s
     h->k = k;
     h->stats = dbg_stats_t{};
     Timer t(h->stream);
-    CHK(buf_ensure(h, h->ar_node[0], n * 8));
-    CHK(buf_ensure(h, h->ar_node[1], n * 8));
-    CHK(buf_ensure(h, h->ar_node[2], n * 16));
+    // The big arrays are BORROWED, not copied (eight BASELINE-size shards are 140 GB of them: a second copy would
+    // not fit): the caller keeps them alive and leaves them alone while this graph is in use.  Flags, rank bytes and
+    // degrees are new (arena); successor ids are rewritten in place.
     CHK(buf_ensure(h, h->ar_node[3], n));
     CHK(buf_ensure(h, h->ar_node[4], n));
-    CHK(buf_ensure(h, h->ar_node[5], n * 16));
     CHK(buf_ensure(h, h->ar_node[6], n));
-    h->d_keys = (uint64_t *)h->ar_node[0].p;
-    h->d_stamps = (uint64_t *)h->ar_node[1].p;
-    h->d_cnt = (uint32_t *)h->ar_node[2].p;
+    h->d_keys = (uint64_t *)d_keys;
+    h->d_stamps = (uint64_t *)d_stamps;
+    h->d_cnt = (uint32_t *)d_counts;
     h->d_flags = (uint8_t *)h->ar_node[3].p;
     h->d_order = (uint8_t *)h->ar_node[4].p;
-    h->d_succ = (uint32_t *)h->ar_node[5].p;
     h->d_deg = (uint8_t *)h->ar_node[6].p;
-    h->nodes_in_arena = true;
-    h->n_nodes = n;
-    if (n) {
-        HIPCHK(h, hipMemcpyAsync(h->d_keys, d_keys, n * 8, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_stamps, d_stamps, n * 8, hipMemcpyDeviceToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(h->d_cnt, d_counts, n * 16, hipMemcpyDeviceToDevice, h->stream));
-        if (!wide) HIPCHK(h, hipMemcpyAsync(h->d_succ, d_succ, n * 16, hipMemcpyDeviceToDevice, h->stream));
+    if (wide) {
+        CHK(buf_ensure(h, h->ar_node[5], n * 16));
+        h->d_succ = (uint32_t *)h->ar_node[5].p;
+    } else {
+        h->d_succ = (uint32_t *)d_succ;
     }
+    h->nodes_in_arena = true;  // free_build must not free any of these
+    h->n_nodes = n;
     if (wide) {
         // two-word k-mers: the shards did not resolve successors (dbg_wide.h).  One table over all nodes, then the
         // same successor kernel as the single-GPU build (it also writes the rank bytes and the degrees).
-        CHK(buf_ensure(h, h->ar_wide[5], n * 8));
-        h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
+        h->d_keys_hi = (uint64_t *)d_keys_hi;
         uint64_t cap = 1024;
         int lg = 10;
         while (cap < 2 * n + 2) { cap <<= 1; ++lg; }
@@ -3279,7 +3276,6 @@ extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *s
         WSlot *tab = (WSlot *)h->ar_wide[1].p;
         HIPCHK(h, hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream));
         if (n) {
-            HIPCHK(h, hipMemcpyAsync(h->d_keys_hi, d_keys_hi, n * 8, hipMemcpyDeviceToDevice, h->stream));
             hipLaunchKernelGGL(k_wnode_insert, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_keys, h->d_keys_hi, tab,
                                cap - 1, 64 - lg);
             hipLaunchKernelGGL(k_wsucc, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, n, h->d_keys,
