@@ -2753,6 +2753,10 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     //      shard: grouped by owner and parked for the exchange)
     {
         Timer t(h->stream);
+        if (n_q) {
+            hipLaunchKernelGGL(k_q_bucket, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, qk[0], qm[0], n_q, k, m);
+            HIPCHK(h, hipGetLastError());
+        }
         CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 64 * 16 + 16));
         uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets;
         uint64_t *q_seg = q_cnt + n_buckets;  // [0..1]: one input segment; [2..]: per-owner children

@@ -992,11 +992,8 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     ++qi;
                 }
             }
-            __syncthreads();
-            if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
-            const uint32_t nq = s.n_q;
-            unsigned long long qgot = 0;
-            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&fresh_args(outp)->scalars[5], (unsigned long long)nq);  // query cursor
+            // ---- thread 0 turns the reservation into the bucket's bases before the barrier that ends the lookups: one
+            //      barrier publishes both, and its serial work overlaps the other waves' lookups
             if (threadIdx.x == 0) {
                 const auto &orr = *fresh_args(outp);
                 const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
@@ -1015,11 +1012,14 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     orr.ranges[ri] = rg;
                 }
             }
-            // minimizer bucket of every staged query (dense, no divergence) while the query cursor is in flight
-            for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT)
-                s.q_meta[i] |= (unsigned long long)kmer_bucket22(s.q_key[i], k, m) << 40;
             __syncthreads();
-            if (phase_limit == 5) { skip_rest = true; break; }  // + reservation + query buckets
+            if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
+            const uint32_t nq = s.n_q;
+            unsigned long long qgot = 0;
+            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&fresh_args(outp)->scalars[5], (unsigned long long)nq);  // query cursor
+            // (the minimizer bucket of every query is filled in by k_q_bucket afterwards: here it would occupy three
+            //  waves for ~150 instructions per bucket while the other thirteen wait at the barrier)
+            if (phase_limit == 5) { skip_rest = true; break; }  // + reservation
             if (s.fail) break;
             const uint64_t gbase = s.gbase, ebase = s.ebase;
             const auto &ow = *fresh_args(outp);  // loaded here, not kept in SGPRs across the whole bucket loop
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                                 const uint64_t node = gbase + li;
                                 const uint64_t skey = ((oq.keys[node] << 2) | (uint64_t)b) & kmask;
                                 oq.q_key[qbase + qi] = skey;
-                                oq.q_meta[qbase + qi] = ((unsigned long long)kmer_bucket22(skey, k, m) << 40) | (node * 4 + b);
+                                oq.q_meta[qbase + qi] = node * 4 + b;
                                 oq.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
                             }
                             if (v != 0xFFFFu) ++rank;  // every base that occurs owns one CSR column
@@ -1112,6 +1112,12 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
         if (failed || s.fail) return;  // s.fail was written before the last barrier every thread passed
         if (skip_rest) { clean = false; if (have_prefetch) prefetch(bucket + gridDim.x); }
     }
+}
+
+// target bucket of every cross-bucket query: bits 40.. of q_meta (what the query multisplit sorts by)
+__global__ __launch_bounds__(256) void k_q_bucket(const uint64_t *__restrict__ q_key, uint64_t *q_meta, uint64_t n, int k, int m) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q_meta[i] = (q_meta[i] & ((1ull << 40) - 1)) | ((uint64_t)kmer_bucket22(q_key[i], k, m) << 40);
 }
 
 // ------------------------------------------------------------------------------------------------
