@@ -110,7 +110,8 @@ struct dbg {
         uint64_t bytes = 0;
     };
     Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4];
-    int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_cap = 0;
+    int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
+    int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
     bool partial_graph = false;   // the node table is one shard of several: successor ids point into other handles
@@ -1683,6 +1684,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     if (n == "estimate_scale_pct" && value >= 1 && value <= 1000) { h->est_scale_pct = (int)value; return DBG_OK; }
+    if (n == "target_distinct" && value >= 0 && value <= 4096) { h->target_distinct = (int)value; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -2437,7 +2439,7 @@ template <class ST, bool HAS_ST>
 static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_cnt, uint32_t n_seg, bool one_group,
                             uint64_t total, const uint64_t *in_w0, const uint64_t *in_w1, const ST *in_st,
                             uint64_t *out_w0, uint64_t *out_w1, ST *out_st, int shift, int nb, uint64_t *c_start,
-                            uint64_t *c_cnt, dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs) {
+                            uint64_t *c_cnt, dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs, int fbits = 0) {
     CHK(buf_ensure(h, b_scpre, (uint64_t)(n_seg + 1) * 8));
     uint64_t *sc_pre = (uint64_t *)b_scpre.p;
     uint64_t nsc = 0;
@@ -2450,7 +2452,7 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
     uint32_t *cmat = (uint32_t *)b_cmat.p;
     uint64_t *offs = (uint64_t *)b_offs.p;
     if (nsc) {
-        hipLaunchKernelGGL(k_ms_hist, dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb, cmat);
+        hipLaunchKernelGGL(k_ms_hist, dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb, fbits, cmat);
         HIPCHK(h, hipGetLastError());
         uint64_t tot = 0;
         CHK(exclusive_scan(h, n_log, MsLogical{P, cmat, nb}, offs, &tot));
@@ -2463,7 +2465,7 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
         auto kern = k_ms_scatter<ST, HAS_ST>;
         const size_t lds = sizeof(MsLds<ST>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(MS_NT), lds, h->stream, P, in_w0, in_w1, in_st, shift, nb, offs,
+        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(MS_NT), lds, h->stream, P, in_w0, in_w1, in_st, shift, nb, fbits, offs,
                            out_w0, out_w1, out_st);
     }
     HIPCHK(h, hipGetLastError());
@@ -2477,11 +2479,13 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
 template <class ST, bool HAS_ST>
 static int multisplit_two_level(dbg *h, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
                                 uint64_t total, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], int field_lo, int l1,
-                                int l2, uint64_t *final_start, uint64_t *final_cnt, int *where) {
+                                int l2, uint64_t *final_start, uint64_t *final_cnt, int *where, int nb2 = 0) {
+    // nb2 > 0: the second level has nb2 children (any number up to 1024) taken from ALL the hash bits below level 1
     int cur = 0;
     const int top = field_lo + SK_BUCKET_BITS;
     const int nb1 = 1 << l1;
     uint64_t *cs, *cc;
+    if (nb2 > 0) l2 = 1;
     if (l2 > 0) {
         CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
         cs = (uint64_t *)h->ar_misc[1].p;
@@ -2495,10 +2499,11 @@ static int multisplit_two_level(dbg *h, const uint64_t *seg_start, const uint64_
                                        h->ar_misc[4])));
     cur ^= 1;
     if (l2 > 0) {
-        const int nb = 1 << l2;
+        const int fb = nb2 > 0 ? SK_BUCKET_BITS - l1 : 0;
+        const int nb = nb2 > 0 ? nb2 : 1 << l2;
         CHK((multisplit_level<ST, HAS_ST>(h, cs, cc, (uint32_t)nb1, false, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
-                                           w1[cur ^ 1], st[cur ^ 1], top - l1 - l2, nb, final_start, final_cnt,
-                                           h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+                                           w1[cur ^ 1], st[cur ^ 1], nb2 > 0 ? top - SK_BUCKET_BITS : top - l1 - l2, nb,
+                                           final_start, final_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb)));
         cur ^= 1;
     }
     *where = cur;
@@ -2603,6 +2608,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     }
     if (T < shard_bits) T = shard_bits;
     int l1 = T < 9 ? T : (T >= 20 ? 10 : 9), l2 = T - l1;  // level 1 is fixed before the estimate refines T
+    int nb2 = 0;                                            // children of the second level (0: not decided yet)
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
@@ -2630,18 +2636,25 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (est[0]) {
             const double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
             est_distinct = distinct / own;
-            T = l1;  // a fuller table (up to 1.2x the target) beats twice the buckets: the per-bucket cost is fixed
-            while (T < l1 + 10 && (double)(1ull << T) * 1.2 < distinct / TARGET_DISTINCT) ++T;
-            l2 = T - l1;
+            // the second level takes any number of children up to 1024 (all hash bits below level 1, scaled): the
+            // bucket count follows the estimate instead of jumping by powers of two
+            const double want = distinct / ((double)h->target_distinct > 0 ? (double)h->target_distinct : TARGET_DISTINCT);
+            nb2 = (int)std::min<double>(1024.0, std::max<double>(1.0, std::ceil(want / nb1)));
+            l2 = nb2 > 1 ? 1 : 0;  // "there is a second level"
         }
     }
-    const uint64_t n_buckets = 1ull << T;
+    if (nb2 == 0 && l2 > 0) nb2 = 1 << l2;  // forced or small geometries: a power of two, plain bit fields
+    const int fb2 = (nb2 > 0 && (nb2 & (nb2 - 1)) != 0) || (auto_T && l1 >= 9 && nb2 > 1) ? SK_BUCKET_BITS - l1 : 0;
+    const uint64_t n_buckets = l2 > 0 ? (uint64_t)nb1 * (uint64_t)nb2 : (uint64_t)nb1;
+    T = 0;
+    while ((1ull << T) < n_buckets) ++T;  // only for reporting
+    const int l2_pow = (fb2 || l2 == 0) ? 0 : (int)std::lround(std::log2((double)nb2));  // second level as plain bits
     CHK(buf_ensure(h, h->ar_misc[5], n_buckets * 16));
     uint64_t *b_start = (uint64_t *)h->ar_misc[5].p, *b_cnt = b_start + n_buckets;
     if (l2 > 0) {
+        const int sh2 = fb2 ? top - SK_BUCKET_BITS : top - l1 - l2_pow;
         CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, false, n_rec, w0[1], w1[1], st[1], w0[0], w1[0],
-                                        st[0], top - l1 - l2, 1 << l2, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3],
-                                        h->ar_misc[4])));
+                                        st[0], sh2, nb2, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
         where = 0;
     } else {
         HIPCHK(h, hipMemcpyAsync(b_start, c1_start, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -2795,8 +2808,8 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             uint32_t *qc2[2] = {qc[qset], qc[qset ^ 1]};
             int qwhere = 0;
             if (T > 0) {
-                CHK((multisplit_two_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, n_q, qk2, qm2, qc2, 40, l1, l2, q_start,
-                                                          q_cnt, &qwhere)));
+                CHK((multisplit_two_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, n_q, qk2, qm2, qc2, 40, l1, l2_pow, q_start,
+                                                          q_cnt, &qwhere, fb2 ? nb2 : 0)));
             } else {
                 HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
                 HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
@@ -2813,7 +2826,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         h->stats.ms_succ = t.stop();
     }
     // geometry the answer stage of a sharded build needs again
-    h->sk_T = T; h->sk_l1 = l1; h->sk_l2 = l2; h->sk_n_ranges = n_ranges; h->sk_cap = CAP;
+    h->sk_T = T; h->sk_l1 = l1; h->sk_l2 = l2_pow; h->sk_nb2 = fb2 ? nb2 : 0; h->sk_n_ranges = n_ranges; h->sk_cap = CAP;
     return DBG_OK;
 }
 
@@ -3164,7 +3177,7 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     int qwhere = 0;
     if (h->sk_T > 0) {
         CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n, qk, qm, dummy, 40, h->sk_l1, h->sk_l2, q_start,
-                                                   q_cnt, &qwhere)));
+                                                   q_cnt, &qwhere, h->sk_nb2)));
     } else {
         HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));

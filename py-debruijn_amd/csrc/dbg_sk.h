@@ -409,7 +409,14 @@ __device__ inline void ms_locate(const MsParents &P, uint64_t g, uint32_t *seg, 
     *sidx = g - P.sc_pre[lo];
 }
 
-__global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__restrict__ w1, int shift, int nb,
+// child bucket of a record: the nb-way digit at `shift` of w1 (nb a power of two, fbits == 0), or -- so that the
+// bucket count need not be a power of two -- the fbits-wide field at `shift` scaled into [0, nb)
+__device__ inline uint32_t ms_child(uint64_t w1, int shift, int nb, int fbits) {
+    const uint32_t v = (uint32_t)(w1 >> shift);
+    return fbits ? (uint32_t)(((uint64_t)(v & ((1u << fbits) - 1u)) * (uint32_t)nb) >> fbits) : (v & (uint32_t)(nb - 1));
+}
+
+__global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__restrict__ w1, int shift, int nb, int fbits,
                                                  uint32_t *cmat) {
     __shared__ uint32_t hist[MS_MAX_NB];
     uint32_t seg;
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__
     const uint64_t beg = P.start[seg] + sidx * MS_SC;
     const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
     for (uint64_t i = beg + threadIdx.x; i < end; i += 256)
-        atomicAdd(&hist[(uint32_t)(w1[i] >> shift) & (uint32_t)(nb - 1)], 1u);
+        atomicAdd(&hist[ms_child(w1[i], shift, nb, fbits)], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256) cmat[(uint64_t)blockIdx.x * nb + b] = hist[b];
 }
@@ -480,7 +487,7 @@ struct MsLds {
 template <class ST, bool HAS_ST>
 __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_t *__restrict__ in_w0,
                                                     const uint64_t *__restrict__ in_w1, const ST *__restrict__ in_st,
-                                                    int shift, int nb, const uint64_t *__restrict__ offs,
+                                                    int shift, int nb, int fbits, const uint64_t *__restrict__ offs,
                                                     uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_raw[];
     MsLds<ST> &s = *reinterpret_cast<MsLds<ST> *>(ms_raw);
@@ -508,7 +515,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
                 r0[i] = in_w0[c0 + q];
                 r1[i] = in_w1[c0 + q];
                 if (HAS_ST) rs[i] = in_st[c0 + q];
-                rk[i] = atomicAdd(&s.hist[(uint32_t)(r1[i] >> shift) & (uint32_t)(nb - 1)], 1u);
+                rk[i] = atomicAdd(&s.hist[ms_child(r1[i], shift, nb, fbits)], 1u);
             }
         }
         __syncthreads();
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
         for (int i = 0; i < MS_CH / MS_NT; ++i) {
             const int q = i * MS_NT + threadIdx.x;
             if (q < n) {
-                const uint32_t b = (uint32_t)(r1[i] >> shift) & (uint32_t)(nb - 1);
+                const uint32_t b = ms_child(r1[i], shift, nb, fbits);
                 const uint32_t d = s.start[b] + rk[i];
                 s.w0[d] = r0[i];
                 s.w1[d] = r1[i];
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
         __syncthreads();
         for (int q = threadIdx.x; q < n; q += MS_NT) {
             const uint64_t x1 = s.w1[q];
-            const uint32_t b = (uint32_t)(x1 >> shift) & (uint32_t)(nb - 1);
+            const uint32_t b = ms_child(x1, shift, nb, fbits);
             const uint64_t g = s.run[b] + (q - s.start[b]);
             out_w0[g] = s.w0[q];
             out_w1[g] = x1;
