@@ -188,7 +188,9 @@ class Graph:
 
     def set_reads_fasta(self, path_or_bytes):
         """Parses a FASTA file on the GPU (read_reads semantics); no Python strings are created."""
-        if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+        if isinstance(path_or_bytes, np.ndarray):
+            raw = np.ascontiguousarray(path_or_bytes, dtype=np.uint8).reshape(-1)
+        elif isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
             raw = np.frombuffer(path_or_bytes, dtype=np.uint8)
         else:
             raw = np.fromfile(path_or_bytes, dtype=np.uint8)

@@ -971,11 +971,15 @@ __global__ __launch_bounds__(256) void k_fa_copy(const char *__restrict__ text, 
                                                  uint64_t n_lines, const uint8_t *is_read, const uint32_t *len,
                                                  const uint64_t *read_idx, const uint64_t *byte_off, char *bases,
                                                  uint64_t *offsets) {
-    const uint64_t l = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // 16 lanes per line: consecutive lanes copy consecutive bytes (a thread per line wrote 150 bytes one by one,
+    // each a separate uncoalesced access: 29 ms for 1.5 GB)
+    const uint64_t l = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const uint32_t sub = threadIdx.x & 15u;
     if (l >= n_lines || !is_read[l]) return;
     const uint64_t src = line_start[l], dst = byte_off[l];
-    offsets[read_idx[l]] = dst;
-    for (uint32_t i = 0; i < len[l]; ++i) bases[dst + i] = text[src + i];
+    if (sub == 0) offsets[read_idx[l]] = dst;
+    const uint32_t n = len[l];
+    for (uint32_t i = sub; i < n; i += 16) bases[dst + i] = text[src + i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1371,7 +1375,7 @@ extern "C" int dbg_set_reads_fasta(dbg_t *h, const char *text, uint64_t n_text) 
         if ((rc = dev_alloc(h, &h->d_offsets, n_reads + 1)) != DBG_OK) break;
         h->own_offsets = true;
         if (n_lines)
-            hipLaunchKernelGGL(k_fa_copy, dim3(grid_for(n_lines, 256)), dim3(256), 0, h->stream, d_text, line_start, n_lines,
+            hipLaunchKernelGGL(k_fa_copy, dim3(grid_for(n_lines * 16, 256)), dim3(256), 0, h->stream, d_text, line_start, n_lines,
                                is_read, len, read_idx, byte_off, h->d_bases, h->d_offsets);
         if (hipMemcpyAsync(h->d_offsets + n_reads, &n_bases, 8, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "FASTA ingest failed on the device"; rc = DBG_E_HIP; break; }
