@@ -167,7 +167,7 @@ int dbg_mark_pull_reads(dbg_t *h);
  *      (II_assembleFromReads.py:14-18).  final_mode != 0 walks with branch_kmer == []
  *      (debruijn.py:281-283).  max_chars bounds the materialised contig text (0 = 1 GiB). */
 int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars);
-/* Non-final walks of graphs with >= "walk_jump_min_nodes" nodes (dbg_set_option, default 2^20) resolve every
+/* Non-final walks of graphs with >= "walk_jump_min_nodes" nodes (dbg_set_option, default 2^14) resolve every
  * chain by pointer jumping (contigs overlap massively at scale); if the text would exceed max_chars
  * dbg_walk still returns DBG_OK with the contig index only (dbg_get_sizes: contigs_materialised == 0). */
 

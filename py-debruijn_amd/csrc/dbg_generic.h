@@ -267,6 +267,10 @@ struct GGen {
         return keys ? (uint32_t)(keys[x] & (GEN_D - 1)) : (uint32_t)lut[(uint8_t)bases[(stamps[x] >> 1) + k - 1]];
     }
     __device__ char sym_char(uint32_t code) const { return alpha[code]; }
+    __device__ char char_at(uint32_t x, int q) const {  // character q of node x's k-mer
+        if (!keys) return bases[(stamps[x] >> 1) + q];
+        return alpha[(keys[x] >> (GEN_BITS * (k - 1 - q))) & (GEN_D - 1)];
+    }
     __device__ void spell(uint32_t x, char *out) const {
         if (!keys) {
             const uint64_t p = stamps[x] >> 1;

@@ -85,7 +85,7 @@ struct dbg {
     uint32_t *d_ctg_seq = nullptr;
     bool walked = false;          // contig text materialised
     bool walk_indexed = false;    // contig index (offsets, scores, start stamps) valid
-    uint64_t walk_jump_min = 1ull << 20;  // non-final walk: pointer jumping from this many nodes on
+    uint64_t walk_jump_min = 1ull << 14;  // non-final walk: list ranking from this many nodes on (below: one thread per start)
 
     // alphabet / node layout: 2 bits and 4 successors for DNA, 5 bits and 32 for the generic engine
     int D = 4, sym_bits = 2, n_sym = 0;
@@ -567,6 +567,10 @@ struct GDna {
     }
     __device__ uint32_t last_code(uint32_t x) const { return (uint32_t)(keys[x] & 3u); }
     __device__ char sym_char(uint32_t code) const { return code_to_ascii(code); }
+    __device__ char char_at(uint32_t x, int q) const {  // character q of node x's k-mer
+        const int sh = 2 * (k - 1 - q);
+        return code_to_ascii((uint32_t)(sh >= 64 ? keys_hi[x] >> (sh - 64) : keys[x] >> sh) & 3u);
+    }
     __device__ void spell(uint32_t x, char *out) const {
         const uint64_t key = keys[x], hi = keys_hi ? keys_hi[x] : 0ull;
         for (int q = 0; q < k; ++q) {
@@ -1196,14 +1200,57 @@ __global__ __launch_bounds__(256) void k_jump_starts(const uint32_t *starts, uin
 __global__ __launch_bounds__(256) void k_walk_desc(const uint32_t *starts, uint64_t n_starts, const uint64_t *per_ctg,
                                                    const uint64_t *ctg_base, const uint64_t *char_base,
                                                    const uint64_t *per_score, const uint64_t *stamps, uint64_t *ctg_off,
-                                                   uint64_t *score_out, uint64_t *stamp_out, uint32_t *seq_out) {
+                                                   uint64_t *score_out, uint64_t *stamp_out, uint32_t *seq_out,
+                                                   uint32_t *ctg_start /* may be null */) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_starts || !per_ctg[i]) return;
     const uint64_t c = ctg_base[i];
+    if (ctg_start) ctg_start[c] = starts[i];
     ctg_off[c] = char_base[i];
     score_out[c] = per_score[i];
     stamp_out[c] = stamps[starts[i]];
     seq_out[c] = 0;
+}
+
+// ---- contig text in parallel.  One thread per start writing its chain character by character is a chain of
+// dependent global loads per character (2 s for the 1 261 contigs / 6.3e7 characters of BASELINE configs[0] without
+// errors: every start re-walks the shared genome path).  With the 2^j-th chain successor of every node tabulated
+// (binary lifting, ceil(log2(longest contig)) levels of n x 4 bytes) any character of any contig is an independent
+// O(log) lookup: character j >= k of the contig that starts at s is the last character of s's (j - k + 1)-th successor.
+template <class G>
+__global__ __launch_bounds__(256) void k_lift_init(uint64_t n_nodes, G g, uint32_t *up0) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_nodes) return;
+    uint32_t nxt = (uint32_t)v;  // chain ends: the node is its own successor (never followed inside a contig)
+    const uint8_t f = g.flags[v];
+    if (!(f & (DBG_F_PULLED | DBG_F_BRANCH)) && g.keep_count((uint32_t)v)) {
+        const uint32_t s = g.succ_of((uint32_t)v, g.first_kept((uint32_t)v));
+        if (!(g.flags[s] & DBG_F_PULLED)) nxt = s;
+    }
+    up0[v] = nxt;
+}
+__global__ __launch_bounds__(256) void k_lift_step(uint64_t n_nodes, const uint32_t *__restrict__ prev, uint32_t *next) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < n_nodes) next[v] = prev[prev[v]];
+}
+template <class G>
+__global__ __launch_bounds__(256) void k_text_fill(uint64_t n_chars, G g, const uint64_t *__restrict__ ctg_off, uint64_t n_ctg,
+                                                   const uint32_t *__restrict__ ctg_start, const uint32_t *__restrict__ up,
+                                                   uint64_t n_nodes, int levels, char *chars) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chars) return;
+    uint64_t lo = 0, hi = n_ctg;  // ctg_off[lo] <= c < ctg_off[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (ctg_off[mid] <= c) lo = mid; else hi = mid;
+    }
+    const uint64_t j = c - ctg_off[lo];
+    uint32_t x = ctg_start[lo];
+    if (j < (uint64_t)g.k) { chars[c] = g.char_at(x, (int)j); return; }
+    uint64_t d = j - (uint64_t)g.k + 1;
+    for (int l = 0; l < levels && d; ++l, d >>= 1)
+        if (d & 1) x = up[(uint64_t)l * n_nodes + x];
+    chars[c] = g.sym_char(g.last_code(x));
 }
 
 // ==========================================================================================
@@ -2151,6 +2198,9 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
 template <class G>
 static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     if (!max_chars) max_chars = 1ull << 30;
+    // without a branch node every node has at most one surviving successor: "all simple paths" of the final mode ARE the
+    // chain walks, and those have the parallel path (the per-start DFS took 2 s on BASELINE configs[0] without errors)
+    if (final_mode && h->n_branch == 0) final_mode = 0;
     Timer t(h->stream);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
     dev_free(h->d_ctg_seq);
@@ -2161,12 +2211,12 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     const bool use_jump = !final_mode && h->n_nodes >= h->walk_jump_min && ns;
     uint32_t *starts = nullptr;
     uint64_t *per_ctg = nullptr, *per_chr = nullptr, *base_ctg = nullptr, *base_chr = nullptr, *per_score = nullptr;
-    uint32_t *st_node = nullptr, *onpath = nullptr;
+    uint32_t *st_node = nullptr, *onpath = nullptr, *ctg_start = nullptr, *lift = nullptr;
     uint8_t *st_next = nullptr;
     Jump *jump[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
         dev_free(starts); dev_free(per_ctg); dev_free(per_chr); dev_free(base_ctg); dev_free(base_chr);
-        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score);
+        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score); dev_free(ctg_start); dev_free(lift);
         jump[0] = jump[1] = nullptr;  // arena-owned
     };
     int rc = DBG_OK;
@@ -2255,16 +2305,37 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
         if ((rc = dev_alloc(h, &h->d_ctg_stamp, n_ctg)) != DBG_OK) break;
         if ((rc = dev_alloc(h, &h->d_ctg_seq, n_ctg)) != DBG_OK) break;
         (void)hipMemcpyAsync(h->d_ctg_off + n_ctg, &h->contig_chars, 8, hipMemcpyHostToDevice, h->stream);
+        bool text_done = false;
         if (use_jump) {  // the index (offsets, scores, start stamps) comes straight from the jump table
+            if ((rc = dev_alloc(h, &ctg_start, n_ctg)) != DBG_OK) break;
             hipLaunchKernelGGL(k_walk_desc, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, per_ctg, base_ctg,
-                               base_chr, per_score, h->d_stamps, h->d_ctg_off, h->d_ctg_score, h->d_ctg_stamp, h->d_ctg_seq);
+                               base_chr, per_score, h->d_stamps, h->d_ctg_off, h->d_ctg_score, h->d_ctg_stamp, h->d_ctg_seq,
+                               ctg_start);
             hipError_t e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) { h->err = std::string("walk index: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
             h->walk_indexed = true;
             if (n_chr > max_chars) break;  // index only: the text would not fit (rc stays DBG_OK)
+            // text by binary lifting if its tables fit next to everything else (else: one thread per start below)
+            const uint64_t longest = h->n_nodes + (uint64_t)h->k;  // no contig is longer: it visits a node at most once
+            int levels = 1;
+            while ((1ull << levels) <= longest) ++levels;
+            if (n_ctg && (uint64_t)levels * h->n_nodes * 4 <= (8ull << 30)) {
+                if ((rc = dev_alloc(h, &h->d_ctg_chars, n_chr)) != DBG_OK) break;
+                if ((rc = dev_alloc(h, &lift, (uint64_t)levels * h->n_nodes)) != DBG_OK) break;
+                const dim3 ngrid(grid_for(h->n_nodes, 256));
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lift_init<G>), ngrid, dim3(256), 0, h->stream, h->n_nodes, g, lift);
+                for (int l = 1; l < levels; ++l)
+                    hipLaunchKernelGGL(k_lift_step, ngrid, dim3(256), 0, h->stream, h->n_nodes, lift + (uint64_t)(l - 1) * h->n_nodes,
+                                       lift + (uint64_t)l * h->n_nodes);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_text_fill<G>), dim3(grid_for(n_chr, 256)), dim3(256), 0, h->stream, n_chr, g,
+                                   h->d_ctg_off, n_ctg, ctg_start, lift, h->n_nodes, levels, h->d_ctg_chars);
+                text_done = true;
+            }
         }
-        if ((rc = dev_alloc(h, &h->d_ctg_chars, n_chr)) != DBG_OK) break;
-        launch(1);
+        if (!text_done) {
+            if ((rc = dev_alloc(h, &h->d_ctg_chars, n_chr)) != DBG_OK) break;
+            launch(1);
+        }
         if (hipGetLastError() != hipSuccess) { h->err = "walk pass 1 launch failed"; rc = DBG_E_HIP; break; }
         hipError_t e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) { h->err = std::string("walk: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
