@@ -357,19 +357,34 @@ def construct_graph(reads, k, threshold=3, final=False):
         labels = _dbg.decode_keys(keys[order], k, alphabet, bits, keys_hi)
         vertices, edges, ect = _Vertices(), {}, {}
         take = lambda idx: [labels[i] for i in idx]
-    for i, lab in enumerate(labels if not lazy else ()):
-        vertices[lab] = Node(lab, int(indeg[i]), int(outdeg[i]))
-        c = counts_o[i]
-        tail = lab[1:]
-        nd = int(outdeg[i])
-        # a rank holds a code only where the node has that many successors (DNA ranks all four codes)
-        ranked = [int(code) for code in rank_mc[i, :n_ranks] if code != 0xFF and c[code]][:nd]  # Counter.most_common order
-        for code in rank_fs[i, :n_ranks]:                                                        # Counter key order
-            if code != 0xFF and c[code]:
-                ect[lab + chars[code]] = int(c[code])
-        if not pulled_o[i]:
-            kp = int(keep_o[i])
-            edges[lab] = [tail + chars[code] for code in ranked if (kp >> code) & 1]
+    if not lazy:
+        # plain Python lists: indexing numpy scalars per node costs more than everything else in this loop
+        outdeg_l, indeg_l, pulled_l, keep_l = outdeg.tolist(), indeg.tolist(), pulled_o.tolist(), keep_o.tolist()
+        code1_l, cnt1_l = counts_o.argmax(axis=1).tolist(), counts_o.max(axis=1).tolist()
+        for i, lab in enumerate(labels):
+            nd = outdeg_l[i]
+            vertices[lab] = Node(lab, indeg_l[i], nd)
+            if nd == 1:    # the common case: one successor, no ranking to consult
+                code = code1_l[i]
+                ch = chars[code]
+                ect[lab + ch] = cnt1_l[i]
+                if not pulled_l[i]:
+                    edges[lab] = [lab[1:] + ch] if (keep_l[i] >> code) & 1 else []
+                continue
+            if nd == 0:
+                if not pulled_l[i]:
+                    edges[lab] = []
+                continue
+            c = counts_o[i]
+            tail = lab[1:]
+            # a rank holds a code only where the node has that many successors (DNA ranks all four codes)
+            ranked = [int(code) for code in rank_mc[i, :n_ranks] if code != 0xFF and c[code]][:nd]  # Counter.most_common order
+            for code in rank_fs[i, :n_ranks]:                                                        # Counter key order
+                if code != 0xFF and c[code]:
+                    ect[lab + chars[code]] = int(c[code])
+            if not pulled_l[i]:
+                kp = keep_l[i]
+                edges[lab] = [tail + chars[code] for code in ranked if (kp >> code) & 1]
 
     ranks = g.export_pull_ranks()[order]
     pulled_idx = np.nonzero(pulled_o)[0]
