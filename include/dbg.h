@@ -156,6 +156,9 @@ int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder);
 int dbg_get_alphabet(dbg_t *h, char *codes32, int *n_symbols, int *bits_per_symbol);
 /* surviving successors after dbg_prune, bit `code` per node (both layouts) */
 int dbg_export_keepmask(dbg_t *h, uint32_t *keepmask);
+/* order[n_nodes]: node ids in the reference's dict order (ascending first-occurrence stamp, debruijn.py:120-133) --
+ * the argsort of dbg_export_nodes' stamps, done by a device radix sort. */
+int dbg_export_dict_order(dbg_t *h, uint32_t *order);
 
 /* ---- a5 + a6: pruningEdges (debruijn.py:150-166) + branch detection (:230-236) */
 int dbg_prune(dbg_t *h, double threshold);
@@ -195,6 +198,11 @@ int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint64_t *score
                        uint32_t *seq_in_start);
 /* the same without the text: offsets[n_contigs+1] (contig i has offsets[i+1]-offsets[i] characters) */
 int dbg_export_contig_index(dbg_t *h, uint64_t *offsets, uint64_t *scores, uint64_t *start_stamp, uint32_t *seq_in_start);
+/* Text of ONE contig (buf_len >= its length from the index): what a caller uses when dbg_walk kept the index only
+ * because the whole text exceeds max_chars (contigs overlap massively at scale).  The first call after a walk builds
+ * the binary-lifting tables of the chain successors (n_nodes x ceil(log2 n_nodes) x 4 bytes), later calls are one
+ * small kernel each. */
+int dbg_export_contig_text(dbg_t *h, uint64_t index, char *buf, uint64_t buf_len);
 /* device-side views for callers that stay on the GPU (valid until the next build/destroy) */
 int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const void **d_stamps,
                      const void **d_flags, const void **d_succ);

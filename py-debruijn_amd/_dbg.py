@@ -24,12 +24,12 @@ SYMBOLS = (
     "dbg_create", "dbg_destroy", "dbg_last_error", "dbg_abi_version", "dbg_set_option", "dbg_set_reads", "dbg_set_reads_fasta",
     "dbg_set_reads_device",
     "dbg_synth_reads", "dbg_reads_checksum", "dbg_copy_reads", "dbg_reads_device", "dbg_build", "dbg_refine_edge_order", "dbg_export_orders",
-    "dbg_get_alphabet", "dbg_export_keepmask",
+    "dbg_get_alphabet", "dbg_export_keepmask", "dbg_export_dict_order",
     "dbg_prune", "dbg_remove_tips",
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_keys_hi",
     "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
-    "dbg_export_contig_index", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
+    "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
 )
 
@@ -105,12 +105,14 @@ def load_library():
         "dbg_get_stats": (C.c_int, [H, C.POINTER(Stats)]),
         "dbg_export_nodes": (C.c_int, [H, vp, vp, vp, vp]),
         "dbg_export_keys_hi": (C.c_int, [H, vp]),
+        "dbg_export_dict_order": (C.c_int, [H, vp]),
         "dbg_export_succ": (C.c_int, [H, vp]),
         "dbg_export_csr": (C.c_int, [H, vp, vp, vp]),
         "dbg_export_pull_ranks": (C.c_int, [H, vp]),
         "dbg_export_pull_reads": (C.c_int, [H, vp]),
         "dbg_export_contigs": (C.c_int, [H, vp, vp, vp, vp, vp]),
         "dbg_export_contig_index": (C.c_int, [H, vp, vp, vp, vp]),
+        "dbg_export_contig_text": (C.c_int, [H, C.c_uint64, vp, C.c_uint64]),
         "dbg_device_views": (C.c_int, [H] + [C.POINTER(vp)] * 5),
         "dbg_shard_extract": (C.c_int, [H, C.c_int, C.c_int, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
@@ -304,6 +306,12 @@ class Graph:
         self._chk(self._lib.dbg_export_csr(self._h, _ptr(rp), _ptr(col), _ptr(cnt)))
         return rp, col, cnt
 
+    def export_dict_order(self):
+        """Node ids in first-occurrence (dict) order: the argsort of the stamps, sorted on the device."""
+        o = np.empty(self.sizes()["n_nodes"], dtype=np.uint32)
+        self._chk(self._lib.dbg_export_dict_order(self._h, _ptr(o)))
+        return o
+
     def export_pull_ranks(self):
         r = np.empty(self.sizes()["n_nodes"], dtype=np.uint64)
         self._chk(self._lib.dbg_export_pull_ranks(self._h, _ptr(r)))
@@ -322,6 +330,12 @@ class Graph:
         seq = np.empty(n, dtype=np.uint32)
         self._chk(self._lib.dbg_export_contig_index(self._h, _ptr(off), _ptr(score), _ptr(stamp), _ptr(seq)))
         return off, score, stamp, seq
+
+    def export_contig_text(self, index, length):
+        """Text of one contig (bytes) -- also when the whole text was larger than the walk's max_chars."""
+        buf = np.empty(int(length), dtype=np.uint8)
+        self._chk(self._lib.dbg_export_contig_text(self._h, int(index), _ptr(buf), int(length)))
+        return buf.tobytes()
 
     def export_contigs(self):
         sz = self.sizes()

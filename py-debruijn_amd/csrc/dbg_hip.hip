@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>  // dbg_export_dict_order only
+
 #include "../../include/dbg.h"
 #include "dbg_device.h"
 #include "dbg_sk.h"
@@ -83,6 +85,9 @@ struct dbg {
     char *d_ctg_chars = nullptr;
     uint64_t *d_ctg_score = nullptr, *d_ctg_stamp = nullptr;
     uint32_t *d_ctg_seq = nullptr;
+    uint32_t *d_ctg_start = nullptr;  // list-ranking walk: start node of every contig (text on demand, dbg_export_contig_text)
+    uint32_t *d_lift = nullptr;       // binary-lifting tables of the last walk, built on the first text request
+    int lift_levels = 0;
     bool walked = false;          // contig text materialised
     bool walk_indexed = false;    // contig index (offsets, scores, start stamps) valid
     uint64_t walk_jump_min = 1ull << 14;  // non-final walk: list ranking from this many nodes on (below: one thread per start)
@@ -1279,7 +1284,8 @@ static void free_build(dbg *h) {
     h->csr_built = false;
     dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
-    dev_free(h->d_ctg_seq);
+    dev_free(h->d_ctg_seq); dev_free(h->d_ctg_start); dev_free(h->d_lift);
+    h->lift_levels = 0;
     h->partial_graph = false;
     h->k = 0; h->cap = 0; h->n_nodes = h->n_edges = 0;
     h->pruned = h->tipped = h->pull_reads_done = h->walked = h->walk_indexed = false;
@@ -2022,6 +2028,46 @@ extern "C" int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder) {
     return DBG_OK;
 }
 
+__global__ __launch_bounds__(256) void k_iota32(uint64_t n, uint32_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+// Node ids in the reference's dict order (first occurrence of the k-mer in the reads, debruijn.py:120-133): one device
+// radix sort of the stamps instead of a host argsort of 10^7..10^8 elements.
+extern "C" int dbg_export_dict_order(dbg_t *h, uint32_t *order) {
+    if (!h || !h->k || !order) { if (h) h->err = "dbg_build must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint64_t n = h->n_nodes;
+    if (!n) return DBG_OK;
+    if (n > 0x7FFFFFFFull) { h->err = "too many nodes for one sort"; return DBG_E_CAPACITY; }
+    uint64_t *keys_out = nullptr;
+    uint32_t *ids = nullptr, *ids_out = nullptr;
+    void *tmp = nullptr;
+    int rc = DBG_OK;
+    do {
+        if ((rc = dev_alloc(h, &keys_out, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &ids, n)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &ids_out, n)) != DBG_OK) break;
+        hipLaunchKernelGGL(k_iota32, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, ids);
+        int end_bit = 2;  // stamp = position << 1 | flag, position < n_bytes
+        while (end_bit < 64 && (h->n_bytes >> (end_bit - 1))) ++end_bit;
+        size_t tmp_bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, h->d_stamps, keys_out, ids, ids_out, (size_t)n, 0u,
+                                                 (unsigned)end_bit, h->stream);
+        if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+        if (e == hipSuccess)
+            e = rocprim::radix_sort_pairs(tmp, tmp_bytes, h->d_stamps, keys_out, ids, ids_out, (size_t)n, 0u, (unsigned)end_bit,
+                                          h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(order, ids_out, n * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) { h->err = std::string("dict order: ") + hipGetErrorString(e); rc = DBG_E_HIP; }
+    } while (0);
+    if (tmp) (void)hipFree(tmp);
+    dev_free(keys_out); dev_free(ids); dev_free(ids_out);
+    return rc;
+}
+
 __global__ __launch_bounds__(256) void k_keepmask_from_flags(uint64_t n, const uint8_t *flags, uint32_t *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t)(flags[i] & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;
@@ -2083,7 +2129,7 @@ extern "C" int dbg_prune(dbg_t *h, double threshold) {
     h->tipped = false;
     h->n_pulled = 0;
     h->pull_reads_done = false;
-    h->walked = false;
+    h->walked = h->walk_indexed = false;
     return DBG_OK;
 }
 
@@ -2131,7 +2177,7 @@ static int remove_tips_impl(dbg *h, const G &g) {
     }
     h->stats.ms_tips = t.stop();
     h->tipped = true;
-    h->walked = false;
+    h->walked = h->walk_indexed = false;
     return DBG_OK;
 }
 
@@ -2203,7 +2249,8 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     if (final_mode && h->n_branch == 0) final_mode = 0;
     Timer t(h->stream);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
-    dev_free(h->d_ctg_seq);
+    dev_free(h->d_ctg_seq); dev_free(h->d_ctg_start); dev_free(h->d_lift);
+    h->lift_levels = 0;
     h->n_contigs = h->contig_chars = 0;
     h->walked = false;
     h->walk_indexed = false;
@@ -2216,7 +2263,7 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     Jump *jump[2] = {nullptr, nullptr};
     auto cleanup = [&]() {
         dev_free(starts); dev_free(per_ctg); dev_free(per_chr); dev_free(base_ctg); dev_free(base_chr);
-        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score); dev_free(ctg_start); dev_free(lift);
+        dev_free(st_node); dev_free(onpath); dev_free(st_next); dev_free(per_score); dev_free(lift);
         jump[0] = jump[1] = nullptr;  // arena-owned
     };
     int rc = DBG_OK;
@@ -2307,7 +2354,8 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
         (void)hipMemcpyAsync(h->d_ctg_off + n_ctg, &h->contig_chars, 8, hipMemcpyHostToDevice, h->stream);
         bool text_done = false;
         if (use_jump) {  // the index (offsets, scores, start stamps) comes straight from the jump table
-            if ((rc = dev_alloc(h, &ctg_start, n_ctg)) != DBG_OK) break;
+            if ((rc = dev_alloc(h, &h->d_ctg_start, n_ctg)) != DBG_OK) break;
+            ctg_start = h->d_ctg_start;
             hipLaunchKernelGGL(k_walk_desc, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, per_ctg, base_ctg,
                                base_chr, per_score, h->d_stamps, h->d_ctg_off, h->d_ctg_score, h->d_ctg_stamp, h->d_ctg_seq,
                                ctg_start);
@@ -2471,6 +2519,69 @@ extern "C" int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint
     D2H(h, seq_in_start, h->d_ctg_seq, h->n_contigs * 4);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DBG_OK;
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void k_text_one(G g, uint32_t start, uint64_t len, const uint32_t *__restrict__ up,
+                                                  uint64_t n_nodes, int levels, char *chars) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    uint32_t x = start;
+    if (j < (uint64_t)g.k) { chars[j] = g.char_at(x, (int)j); return; }
+    uint64_t d = j - (uint64_t)g.k + 1;
+    for (int l = 0; l < levels && d; ++l, d >>= 1)
+        if (d & 1) x = up[(uint64_t)l * n_nodes + x];
+    chars[j] = g.sym_char(g.last_code(x));
+}
+
+template <class G>
+static int contig_text_impl(dbg *h, const G &g, uint64_t index, char *buf, uint64_t buf_len) {
+    uint64_t off[2] = {0, 0};
+    uint32_t start = 0;
+    HIPCHK(h, hipMemcpyAsync(off, h->d_ctg_off + index, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(&start, h->d_ctg_start + index, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const uint64_t len = off[1] - off[0];
+    if (buf_len < len) { h->err = "buffer smaller than the contig"; return DBG_E_ARG; }
+    if (!h->d_lift) {  // tables of the 2^j-th chain successors, built once per walk
+        int levels = 1;
+        while ((1ull << levels) <= h->n_nodes + (uint64_t)h->k) ++levels;
+        if ((uint64_t)levels * h->n_nodes * 4 > (64ull << 30)) { h->err = "graph too large for on-demand contig text"; return DBG_E_CAPACITY; }
+        CHK(dev_alloc(h, &h->d_lift, (uint64_t)levels * h->n_nodes));
+        const dim3 ngrid(grid_for(h->n_nodes, 256));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lift_init<G>), ngrid, dim3(256), 0, h->stream, h->n_nodes, g, h->d_lift);
+        for (int l = 1; l < levels; ++l)
+            hipLaunchKernelGGL(k_lift_step, ngrid, dim3(256), 0, h->stream, h->n_nodes, h->d_lift + (uint64_t)(l - 1) * h->n_nodes,
+                               h->d_lift + (uint64_t)l * h->n_nodes);
+        h->lift_levels = levels;
+    }
+    char *tmp = nullptr;
+    CHK(dev_alloc(h, &tmp, len));
+    if (len) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_text_one<G>), dim3(grid_for(len, 256)), dim3(256), 0, h->stream, g, start, len,
+                                h->d_lift, h->n_nodes, h->lift_levels, tmp);
+    hipError_t e = len ? hipMemcpyAsync(buf, tmp, len, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dev_free(tmp);
+    if (e != hipSuccess) { h->err = std::string("contig text: ") + hipGetErrorString(e); return DBG_E_HIP; }
+    return DBG_OK;
+}
+
+extern "C" int dbg_export_contig_text(dbg_t *h, uint64_t index, char *buf, uint64_t buf_len) {
+    if (!h || !h->walk_indexed || !buf) { if (h) h->err = "dbg_walk must run first"; return DBG_E_ARG; }
+    if (index >= h->n_contigs) { h->err = "contig index out of range"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->walked) {  // the whole text is on the device already
+        uint64_t off[2];
+        HIPCHK(h, hipMemcpyAsync(off, h->d_ctg_off + index, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (buf_len < off[1] - off[0]) { h->err = "buffer smaller than the contig"; return DBG_E_ARG; }
+        if (off[1] > off[0]) HIPCHK(h, hipMemcpyAsync(buf, h->d_ctg_chars + off[0], off[1] - off[0], hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return DBG_OK;
+    }
+    if (!h->d_ctg_start) { h->err = "no per-contig start nodes (walk did not take the list-ranking path)"; return DBG_E_ARG; }
+    if (h->D == GEN_D) return contig_text_impl(h, gen_view(h), index, buf, buf_len);
+    return contig_text_impl(h, dna_view(h), index, buf, buf_len);
 }
 
 extern "C" int dbg_device_keys_hi(dbg_t *h, const void **d_keys_hi) {

@@ -21,7 +21,7 @@ the append order of ``already_pull_out``, contig order) -- equals the reference.
 from __future__ import annotations
 
 import os
-from collections.abc import ItemsView, Mapping
+from collections.abc import ItemsView, Mapping, Sequence
 
 import numpy as np
 
@@ -111,25 +111,44 @@ LAZY_MIN_NODES = int(os.environ.get("DBG_LAZY_MIN_NODES", "2000000"))
 
 
 class _NodeStore:
-    """Host arrays of one graph in dict (first-occurrence) order + label <-> index conversion."""
+    """Host arrays of one graph (in the library's table order) + the dict-order permutation + label <-> index
+    conversion.  Indices of this class's methods are positions in dict (first-occurrence) order; ``order[i]`` is the
+    row of node i in the arrays, so nothing of size n_nodes is gathered or sorted on the host up front."""
 
-    def __init__(self, k, alphabet, bits, keys, keys_hi, counts, rank_mc, rank_fs, indeg, outdeg, pulled, keep):
+    def __init__(self, k, alphabet, bits, order, keys, keys_hi, counts, rank_mc, rank_fs, flags, keep):
         self.k, self.alphabet, self.bits = k, alphabet, bits
         self.chars = alphabet.decode("latin-1")
         self.code_of = {ch: i for i, ch in enumerate(self.chars)}  # alphabet[code] = character
+        self.order = order
         self.keys, self.keys_hi, self.counts = keys, keys_hi, counts
         self.rank_mc, self.rank_fs = rank_mc, rank_fs
-        self.indeg, self.outdeg, self.pulled, self.keep = indeg, outdeg, pulled, keep
+        self.flags, self.keep = flags, keep
         self.n = int(keys.size)
         self._sorted = None
+        self._inverse = None
+
+    def rows(self, idx):
+        return self.order[np.asarray(idx, dtype=np.int64)]
+
+    def row_labels(self, rows):
+        hi = None if self.keys_hi is None else self.keys_hi[rows]
+        return _dbg.decode_keys(self.keys[rows], self.k, self.alphabet, self.bits, hi)
 
     def labels(self, idx):
-        idx = np.asarray(idx, dtype=np.int64)
-        hi = None if self.keys_hi is None else self.keys_hi[idx]
-        return _dbg.decode_keys(self.keys[idx], self.k, self.alphabet, self.bits, hi)
+        return self.row_labels(self.rows(idx))
 
-    def label(self, i):
-        return self.labels([i])[0]
+    def indeg(self, i):
+        return int(self.flags[self.order[i]] & _dbg.F_INDEG)
+
+    def outdeg(self, i):
+        return int(np.count_nonzero(self.counts[self.order[i]]))
+
+    def pulled(self, i):
+        return bool(self.flags[self.order[i]] & _dbg.F_PULLED)
+
+    def alive(self):
+        """Dict-order indices of the nodes that were not pulled out."""
+        return np.nonzero((self.flags & _dbg.F_PULLED)[self.order] == 0)[0]
 
     def encode(self, lab):
         """(hi, lo) words of a k-character label, or None if it is not a k-mer over the alphabet."""
@@ -154,31 +173,38 @@ class _NodeStore:
             else:
                 perm = np.lexsort((self.keys, self.keys_hi))
             self._sorted = (perm, self.keys[perm], None if self.keys_hi is None else self.keys_hi[perm])
+            self._inverse = np.empty(self.n, dtype=np.int64)
+            self._inverse[self.order] = np.arange(self.n, dtype=np.int64)
         perm, lo_s, hi_s = self._sorted
         hi, lo = e
         if hi_s is None:
             if hi:
                 return -1
             a = int(np.searchsorted(lo_s, np.uint64(lo), side="left"))
-            return int(perm[a]) if a < self.n and int(lo_s[a]) == lo else -1
+            return int(self._inverse[perm[a]]) if a < self.n and int(lo_s[a]) == lo else -1
         a = int(np.searchsorted(hi_s, np.uint64(hi), side="left"))
         b = int(np.searchsorted(hi_s, np.uint64(hi), side="right"))
         c = a + int(np.searchsorted(lo_s[a:b], np.uint64(lo), side="left"))
-        return int(perm[c]) if c < b and int(lo_s[c]) == lo else -1
+        return int(self._inverse[perm[c]]) if c < b and int(lo_s[c]) == lo else -1
 
     def successors(self, i, pruned):
         """Successor labels of node i: Counter.most_common order; only the kept ones when `pruned`."""
-        lab = self.label(i)
-        c = self.counts[i]
-        nd = int(self.outdeg[i])
-        ranked = [int(code) for code in self.rank_mc[i] if code != 0xFF and c[code]][:nd]
-        kp = int(self.keep[i])
+        r = self.order[i]
+        lab = self.row_labels([r])[0]
+        c = self.counts[r]
+        nd = int(np.count_nonzero(c))
+        ranked = [int(code) for code in np.atleast_1d(self.rank_mc[r]) if code != 0xFF and c[code]][:nd]
+        kp = int(self.keep[r])
         return [lab[1:] + self.chars[code] for code in ranked if not pruned or (kp >> code) & 1]
 
     def edge_names(self, i):
-        lab = self.label(i)
-        c = self.counts[i]
-        return [(lab + self.chars[code], int(c[code])) for code in self.rank_fs[i] if code != 0xFF and c[code]]
+        r = self.order[i]
+        lab = self.row_labels([r])[0]
+        c = self.counts[r]
+        return [(lab + self.chars[code], int(c[code])) for code in np.atleast_1d(self.rank_fs[r]) if code != 0xFF and c[code]]
+
+    def edge_count(self, i, code):
+        return int(self.counts[self.order[i], code]) if code < self.counts.shape[1] else 0
 
 
 class _LazyVertices(Mapping):
@@ -203,7 +229,7 @@ class _LazyVertices(Mapping):
         i = self._s.find(lab)
         if i < 0:
             raise KeyError(lab)
-        return Node(lab, int(self._s.indeg[i]), int(self._s.outdeg[i]))
+        return Node(lab, self._s.indeg(i), self._s.outdeg(i))
 
 
 class _LazyEdges(Mapping):
@@ -211,7 +237,13 @@ class _LazyEdges(Mapping):
 
     def __init__(self, store):
         self._s = store
-        self._alive = np.nonzero(~store.pulled)[0]
+        self._alive_idx = None
+
+    @property
+    def _alive(self):
+        if self._alive_idx is None:
+            self._alive_idx = self._s.alive()
+        return self._alive_idx
 
     def __len__(self):
         return int(self._alive.size)
@@ -222,11 +254,11 @@ class _LazyEdges(Mapping):
 
     def __contains__(self, lab):
         i = self._s.find(lab)
-        return i >= 0 and not self._s.pulled[i]
+        return i >= 0 and not self._s.pulled(i)
 
     def __getitem__(self, lab):
         i = self._s.find(lab)
-        if i < 0 or self._s.pulled[i]:
+        if i < 0 or self._s.pulled(i):
             raise KeyError(lab)
         return self._s.successors(i, True)
 
@@ -236,9 +268,11 @@ class _LazyEdgeCounts(Mapping):
 
     def __init__(self, store):
         self._s = store
-        self._n = int((store.counts != 0).sum())
+        self._n = None
 
     def __len__(self):
+        if self._n is None:
+            self._n = int(np.count_nonzero(self._s.counts))
         return self._n
 
     def __iter__(self):
@@ -261,9 +295,10 @@ class _LazyEdgeCounts(Mapping):
             raise KeyError(name)
         i = self._s.find(name[:-1])
         code = self._s.code_of.get(name[-1])
-        if i < 0 or code is None or code >= self._s.counts.shape[1] or not self._s.counts[i, code]:
+        n = self._s.edge_count(i, code) if i >= 0 and code is not None else 0
+        if not n:
             raise KeyError(name)
-        return int(self._s.counts[i, code])
+        return n
 
 
 class _EdgeItems(ItemsView):
@@ -281,6 +316,34 @@ class _Tracked(list):
 class ContigList(list):
     """list[str] of contigs plus the device-computed getScore of each (``.scores``)."""
     scores = None
+
+
+MAX_CONTIG_CHARS = 0  # dbg_walk's max_chars; 0 = the library default (1 GiB of contig text kept on the device)
+
+
+class LazyContigs(Sequence):
+    """Contigs of a walk whose text was larger than MAX_CONTIG_CHARS: same order, ``.scores`` and ``.lengths`` as
+    ContigList, every text fetched from the device when it is indexed (dbg_export_contig_text)."""
+
+    def __init__(self, graph, order, off, score):
+        self._graph = graph
+        self._order = order
+        self._off = off
+        self.scores = score[order].tolist()
+        self.lengths = (off[1:] - off[:-1])[order].tolist()
+
+    def __len__(self):
+        return len(self._order)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        c = int(self._order[i])
+        return self._graph.export_contig_text(c, int(self._off[c + 1] - self._off[c])).decode("latin-1")
 
 
 def _pack_reads(reads):
@@ -331,32 +394,34 @@ def construct_graph(reads, k, threshold=3, final=False):
     rank_mc, rank_fs = g.export_orders()          # (n, D): successor codes by rank
     alphabet, bits = g.alphabet()                 # code -> character
     chars = alphabet.decode("latin-1")
-    order = np.argsort(stamps, kind="stable")  # dict order == first-occurrence order
-    keys_hi = g.export_keys_hi()[order] if bits == 2 and bits * k > 64 else None
-    counts_o = counts[order]
-    rank_mc, rank_fs = rank_mc[order], rank_fs[order]
-    flags_o = flags[order]
-    outdeg = (counts_o != 0).sum(axis=1)
-    indeg = flags_o & _dbg.F_INDEG
-    pulled_o = (flags_o & _dbg.F_PULLED) != 0
-    keep_o = g.export_keepmask()[order]
+    order = g.export_dict_order().astype(np.int64)  # dict order == first-occurrence order (sorted on the device)
+    keys_hi = g.export_keys_hi() if bits == 2 and bits * k > 64 else None
+    keep = g.export_keepmask()
     n_ranks = rank_mc.shape[1]
 
     byref = bits == 5 and bits * (k + 1) > 64  # generic alphabet, k >= 12: a node's k-mer is the text at its first occurrence
     lazy = len(order) >= LAZY_MIN_NODES and not byref
-    if byref:
-        text = reads._pull()[0] if isinstance(reads, DeviceReads) else bases.tobytes().decode("latin-1")
-        labels = [text[p:p + k] for p in (stamps[order] >> np.uint64(1)).tolist()]
-        vertices, edges, ect = _Vertices(), {}, {}
-        take = lambda idx: [labels[i] for i in idx]
-    elif lazy:
-        store = _NodeStore(k, alphabet, bits, keys[order], keys_hi, counts_o, rank_mc, rank_fs, indeg, outdeg, pulled_o, keep_o)
+    if lazy:  # the arrays stay in table order; the views go through `order` when they are asked for something
+        store = _NodeStore(k, alphabet, bits, order, keys, keys_hi, counts, rank_mc, rank_fs, flags, keep)
         vertices, edges, ect = _LazyVertices(store), _LazyEdges(store), _LazyEdgeCounts(store)
-        take = store.labels
+        row_labels = store.row_labels
     else:
-        labels = _dbg.decode_keys(keys[order], k, alphabet, bits, keys_hi)
+        if byref:
+            text = reads._pull()[0] if isinstance(reads, DeviceReads) else bases.tobytes().decode("latin-1")
+            labels = [text[p:p + k] for p in (stamps[order] >> np.uint64(1)).tolist()]
+        else:
+            labels = _dbg.decode_keys(keys[order], k, alphabet, bits, None if keys_hi is None else keys_hi[order])
         vertices, edges, ect = _Vertices(), {}, {}
-        take = lambda idx: [labels[i] for i in idx]
+        inverse = np.empty(len(order), dtype=np.int64)
+        inverse[order] = np.arange(len(order))
+        row_labels = lambda rows: [labels[i] for i in inverse[rows]]
+        counts_o = counts[order]
+        rank_mc, rank_fs = rank_mc[order], rank_fs[order]
+        flags_o = flags[order]
+        outdeg = (counts_o != 0).sum(axis=1)
+        indeg = flags_o & _dbg.F_INDEG
+        pulled_o = (flags_o & _dbg.F_PULLED) != 0
+        keep_o = keep[order]
     if not lazy:
         # plain Python lists: indexing numpy scalars per node costs more than everything else in this loop
         outdeg_l, indeg_l, pulled_l, keep_l = outdeg.tolist(), indeg.tolist(), pulled_o.tolist(), keep_o.tolist()
@@ -386,10 +451,11 @@ def construct_graph(reads, k, threshold=3, final=False):
                 kp = keep_l[i]
                 edges[lab] = [tail + chars[code] for code in ranked if (kp >> code) & 1]
 
-    ranks = g.export_pull_ranks()[order]
-    pulled_idx = np.nonzero(pulled_o)[0]
-    pulled_idx = pulled_idx[np.argsort(ranks[pulled_idx], kind="stable")]
-    already_pull_out = _Tracked(take(pulled_idx))
+    # the two label lists: rows of the table, put into the reference's order by a sort of the (few) selected rows
+    pulled_rows = np.nonzero(flags & _dbg.F_PULLED)[0]
+    ranks = g.export_pull_ranks()
+    pulled_rows = pulled_rows[np.argsort(ranks[pulled_rows], kind="stable")]
+    already_pull_out = _Tracked(row_labels(pulled_rows))
 
     if final:  # debruijn.py:281-283
         pull_out_read = []
@@ -397,7 +463,8 @@ def construct_graph(reads, k, threshold=3, final=False):
     else:
         rf = g.export_pull_reads()
         pull_out_read = [reads[i] for i in np.nonzero(rf)[0]]
-        branch_kmer = _Tracked(take(np.nonzero(flags_o & _dbg.F_BRANCH)[0]))
+        branch_rows = np.nonzero(flags & _dbg.F_BRANCH)[0]
+        branch_kmer = _Tracked(row_labels(branch_rows[np.argsort(stamps[branch_rows], kind="stable")]))
 
     token = object()
     vertices._graph = g
@@ -427,10 +494,13 @@ def output_contigs(g, branch_kmer, already_pull_out):
     final_mode = len(branch_kmer) == 0  # identical to the chain walk when the graph has no branch node
     sz = graph.sizes()
     print('Number of kmers have no income edges: ', sz["n_starts"])  # debruijn.py:336
-    graph.walk(final_mode)
+    graph.walk(final_mode, MAX_CONTIG_CHARS)
+    if not graph.sizes()["contigs_materialised"]:  # index only: the texts stay on the device until asked for
+        off, score, stamp, seq = graph.export_contig_index()
+        return LazyContigs(graph, np.lexsort((seq, stamp)), off, score)
     off, chars, score, stamp, seq = graph.export_contigs()
     order = np.lexsort((seq, stamp))  # starts in dict order, emission order inside a start
-    text = chars.tobytes().decode("ascii")
+    text = chars.tobytes().decode("latin-1")
     out = ContigList(text[int(off[i]):int(off[i + 1])] for i in order)
     out.scores = [int(score[i]) for i in order]
     return out

@@ -236,6 +236,41 @@ def test_walk_index_without_text():
     assert np.array_equal(np.diff(off.astype(np.int64))[a], np.diff(off2.astype(np.int64))[b])
     with pytest.raises(_dbg.DbgError):
         g.export_contigs()
+    # ... and every text on demand (dbg_export_contig_text), equal to the materialised walk's
+    text = chars.tobytes()
+    want = {(int(stamp[i]), int(seq[i])): text[int(off[i]):int(off[i + 1])] for i in range(stamp.size)}
+    for i in range(stamp2.size):
+        assert g.export_contig_text(i, int(off2[i + 1] - off2[i])) == want[(int(stamp2[i]), int(seq2[i]))]
+    with pytest.raises(_dbg.DbgError):
+        g.export_contig_text(stamp2.size, 10)       # out of range
+    if stamp2.size:
+        with pytest.raises(_dbg.DbgError):
+            g.export_contig_text(0, 0)              # buffer smaller than the contig
+    g.prune(2)                                      # the graph changed: the old index is gone
+    with pytest.raises(_dbg.DbgError):
+        g.export_contig_text(0, 1 << 20)
+
+
+@pytest.mark.parametrize("name", ["dna_med_k21_e1_t2", "dna_med_k63_e1_t2", "dna_small_k9_e1_t1", "peptide_k4_nonfinal",
+                                  "hand_cycle_rho_t1_nonfinal", "hand_short_reads_t1_nonfinal"])
+def test_contigs_fetched_on_demand_in_the_drop_in(name, monkeypatch):
+    """Contig text larger than the device budget: output_contigs returns a lazy sequence with the same contents."""
+    import debruijn as prod
+    case = load_golden(name)
+    reads = case_reads(case)
+    inp = case["inputs"]
+    if inp["final"]:
+        pytest.skip("non-final only")
+    monkeypatch.setenv("DBG_WALK_JUMP_MIN", "0")
+    want = run_product(reads, inp["k"], inp["threshold"], False)
+    monkeypatch.setattr(prod, "MAX_CONTIG_CHARS", 1)
+    g, pull, branch, already, _ = prod.construct_graph(list(reads), inp["k"], threshold=inp["threshold"], final=False)
+    lazy = prod.output_contigs(g, branch, already)
+    assert isinstance(lazy, prod.LazyContigs) or len(want["contigs"]) == 0
+    assert list(lazy) == want["contigs"] and list(lazy.scores) == want["scores"]
+    if len(lazy):
+        assert lazy[-1] == want["contigs"][-1] and lazy[0:2] == want["contigs"][0:2]
+        assert lazy.lengths == [len(c) for c in want["contigs"]]
 
 
 def test_unused_helpers_against_reference_vectors():
