@@ -309,6 +309,11 @@ struct U64At {
     const uint64_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return p[i]; }
 };
+struct KmerInstances {  // k-mer instances of read i
+    const uint64_t *off;
+    uint64_t k;
+    __device__ uint64_t operator()(uint64_t i) const { const uint64_t len = off[i + 1] - off[i]; return len >= k ? len - k + 1 : 0; }
+};
 struct FlagSet {
     const uint8_t *f;
     uint8_t mask, want;
@@ -1750,10 +1755,15 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
 // ---- 32 <= k <= 63 over ACGT: two-word k-mers (see dbg_wide.h for the table protocol)
 static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
     if (h->n_bytes >= (1ull << 46)) { h->err = "reads too large for 48-bit stamps"; return DBG_E_CAPACITY; }
-    uint64_t want = table_capacity_hint ? table_capacity_hint : (uint64_t)((double)(h->n_bytes + 1) / 0.7);
-    uint64_t cap = 1024;
-    int lg = 10;
-    while (cap < want) { cap <<= 1; ++lg; }
+    // table slots: the k-mer instances (an upper bound of the distinct k-mers) / 0.7, any multiple of 1024 -- memset and
+    // compaction scan are proportional to the table
+    uint64_t want = table_capacity_hint;
+    if (!want) {
+        uint64_t inst = 0;
+        CHK(reduce_sum(h, h->n_reads, KmerInstances{h->d_offsets, (uint64_t)k}, &inst));
+        want = (uint64_t)((double)(inst + 1) / 0.7);
+    }
+    const uint64_t cap = std::max<uint64_t>(1024, (want + 1023) / 1024 * 1024);
     const uint64_t pk_words = (h->n_bytes + 31) / 32, n_occ = cap / 32;
     uint64_t *pk = nullptr;
     WSlot *tab = nullptr;
@@ -1786,7 +1796,7 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
         if (tiles)
             hipLaunchKernelGGL(k_wcount, dim3((unsigned)tiles), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
-                               h->d_startbits, k, pk, tab, tcnt, cap - 1, 64 - lg, occ, (unsigned long long *)h->d_scalars);
+                               h->d_startbits, k, pk, tab, tcnt, cap, occ, (unsigned long long *)h->d_scalars);
         h->stats.count_launches = tiles ? 1 : 0;
         hipError_t e = hipMemcpyAsync(sc, h->d_scalars, 32, hipMemcpyDeviceToHost, h->stream);
         h->stats.ms_count = tc.stop();
@@ -1818,12 +1828,12 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         h->d_deg = (uint8_t *)h->ar_node[6].p;
         h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
         h->nodes_in_arena = true;
-        hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
+        hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ * 32, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
                            h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
         h->stats.ms_compact = tg.stop();
         Timer ts(h->stream);
         if (total)
-            hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, total,
+            hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap, k, total,
                                h->d_keys, h->d_keys_hi, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
         e = hipStreamSynchronize(h->stream);
         h->stats.ms_succ = ts.stop();
@@ -2584,6 +2594,14 @@ extern "C" int dbg_export_contig_text(dbg_t *h, uint64_t index, char *buf, uint6
     return contig_text_impl(h, dna_view(h), index, buf, buf_len);
 }
 
+#ifdef DBG_MS_PROF
+extern "C" int dbg_debug_ms_prof(unsigned long long *out8, int reset) {  // experiment builds only (tools/ms_prof.py)
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dbgk::g_ms_prof), 64) != hipSuccess) return DBG_E_HIP;
+    if (reset) { unsigned long long z[8] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dbgk::g_ms_prof), z, 64) != hipSuccess) return DBG_E_HIP; }
+    return DBG_OK;
+}
+#endif
+
 extern "C" int dbg_device_keys_hi(dbg_t *h, const void **d_keys_hi) {
     if (!h || !h->k || !d_keys_hi) return DBG_E_ARG;
     *d_keys_hi = h->d_keys_hi;
@@ -3162,9 +3180,7 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     h->k = k;
     h->stats.n_records = n_rec;
     Timer t_total(h->stream);
-    uint64_t cap = 1024;
-    int lg = 10;
-    while (cap < (uint64_t)((double)(n_rec + 1) / 0.7)) { cap <<= 1; ++lg; }
+    const uint64_t cap = std::max<uint64_t>(1024, ((uint64_t)((double)(n_rec + 1) / 0.7) + 1023) / 1024 * 1024);
     const uint64_t n_occ = cap / 32;
     CHK(buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot)));
     CHK(buf_ensure(h, h->ar_wide[2], cap * 16));
@@ -3180,7 +3196,7 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     for (int r = 0; r < n_shards; ++r) {
         if (!recv_counts[r]) continue;
         hipLaunchKernelGGL(k_ws_insert, dim3(grid_for(recv_counts[r], 256)), dim3(256), 0, h->stream, t_lo, t_hi, t_st, seg[r],
-                           recv_counts[r], stamp_base[r] << 1, tab, tcnt, cap - 1, 64 - lg, occ,
+                           recv_counts[r], stamp_base[r] << 1, tab, tcnt, cap, occ,
                            (unsigned long long *)h->d_scalars);
     }
     uint64_t sc0 = 0;
@@ -3214,11 +3230,11 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     h->d_deg = (uint8_t *)h->ar_node[6].p;
     h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
     h->nodes_in_arena = true;
-    hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
+    hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ * 32, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
                        h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
     // successors inside this shard only (ids local, untagged): the gathered graph resolves all of them (dbg_import_graph)
     if (total)
-        hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, total,
+        hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap, k, total,
                            h->d_keys, h->d_keys_hi, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
@@ -3472,16 +3488,14 @@ extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *s
         // two-word k-mers: the shards did not resolve successors (dbg_wide.h).  One table over all nodes, then the
         // same successor kernel as the single-GPU build (it also writes the rank bytes and the degrees).
         h->d_keys_hi = (uint64_t *)d_keys_hi;
-        uint64_t cap = 1024;
-        int lg = 10;
-        while (cap < 2 * n + 2) { cap <<= 1; ++lg; }
+        const uint64_t cap = (2 * n + 1024) / 1024 * 1024;  // half full
         CHK(buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot)));
         WSlot *tab = (WSlot *)h->ar_wide[1].p;
         HIPCHK(h, hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream));
         if (n) {
             hipLaunchKernelGGL(k_wnode_insert, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_keys, h->d_keys_hi, tab,
-                               cap - 1, 64 - lg);
-            hipLaunchKernelGGL(k_wsucc, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, tab, cap - 1, 64 - lg, k, n, h->d_keys,
+                               cap);
+            hipLaunchKernelGGL(k_wsucc, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, tab, cap, k, n, h->d_keys,
                                h->d_keys_hi, h->d_cnt, h->d_succ, h->d_order, h->d_deg);
             hipLaunchKernelGGL(k_flags_from_stamps, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n, h->d_stamps, h->d_flags);
             HIPCHK(h, hipGetLastError());

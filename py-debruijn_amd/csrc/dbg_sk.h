@@ -426,8 +426,14 @@ __global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__
     __syncthreads();
     const uint64_t beg = P.start[seg] + sidx * MS_SC;
     const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
-    for (uint64_t i = beg + threadIdx.x; i < end; i += 256)
-        atomicAdd(&hist[ms_child(w1[i], shift, nb, fbits)], 1u);
+    for (uint64_t i0 = beg; i0 < end; i0 += 256 * 8) {  // eight loads in flight per thread, then their LDS atomics
+        uint64_t v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = w1[min(i0 + (uint64_t)(j * 256 + threadIdx.x), end - 1)];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (i0 + (uint64_t)(j * 256 + threadIdx.x) < end) atomicAdd(&hist[ms_child(v[j], shift, nb, fbits)], 1u);
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256) cmat[(uint64_t)blockIdx.x * nb + b] = hist[b];
 }
@@ -484,6 +490,13 @@ struct MsLds {
     uint64_t run[MS_MAX_NB];     // global cursor of the super-chunk per child bucket
 };
 
+#ifdef DBG_MS_PROF
+__device__ unsigned long long g_ms_prof[8];
+#define MS_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); prof_[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define MS_TICK(i) do {} while (0)
+#endif
+
 template <class ST, bool HAS_ST>
 __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_t *__restrict__ in_w0,
                                                     const uint64_t *__restrict__ in_w1, const ST *__restrict__ in_st,
@@ -491,9 +504,13 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
                                                     uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_raw[];
     MsLds<ST> &s = *reinterpret_cast<MsLds<ST> *>(ms_raw);
+#ifdef DBG_MS_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
     uint32_t seg;
     uint64_t sidx;
     ms_locate(P, blockIdx.x, &seg, &sidx);
+    MS_TICK(0);
     // position of this super-chunk inside its group, and the group's extent in the logical order
     const uint64_t g_lo = P.one_group ? 0 : P.sc_pre[seg], g_hi = P.one_group ? P.sc_pre[P.n_seg] : P.sc_pre[seg + 1];
     const uint64_t nsc = g_hi - g_lo, gidx = (uint64_t)blockIdx.x - g_lo;
@@ -505,20 +522,26 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
         const int n = (int)min((uint64_t)MS_CH, end - c0);
         for (int b = threadIdx.x; b < nb; b += MS_NT) s.hist[b] = 0;
         __syncthreads();
+        MS_TICK(1);
         uint64_t r0[MS_CH / MS_NT], r1[MS_CH / MS_NT];
         ST rs[MS_CH / MS_NT];
         uint32_t rk[MS_CH / MS_NT];
+        // all loads of the chunk first, unconditionally (a clamped index instead of a branch): behind `if (q < n)` the
+        // compiler issued load - wait - rank per record, eight memory round trips in a row (66 % of the kernel)
+#pragma unroll
+        for (int i = 0; i < MS_CH / MS_NT; ++i) {
+            const int q = min(i * MS_NT + (int)threadIdx.x, n - 1);
+            r0[i] = in_w0[c0 + q];
+            r1[i] = in_w1[c0 + q];
+            if (HAS_ST) rs[i] = in_st[c0 + q];
+        }
 #pragma unroll
         for (int i = 0; i < MS_CH / MS_NT; ++i) {
             const int q = i * MS_NT + threadIdx.x;
-            if (q < n) {
-                r0[i] = in_w0[c0 + q];
-                r1[i] = in_w1[c0 + q];
-                if (HAS_ST) rs[i] = in_st[c0 + q];
-                rk[i] = atomicAdd(&s.hist[ms_child(r1[i], shift, nb, fbits)], 1u);
-            }
+            if (q < n) rk[i] = atomicAdd(&s.hist[ms_child(r1[i], shift, nb, fbits)], 1u);
         }
         __syncthreads();
+        MS_TICK(2);
         {  // exclusive scan of hist (nb <= 1024: MS_MAX_NB / MS_NT entries per thread)
             constexpr int EPT = MS_MAX_NB / MS_NT;
             const int b0 = threadIdx.x * EPT;
@@ -532,6 +555,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
             for (int j = 0; j < EPT; ++j) { if (b0 + j < nb) s.start[b0 + j] = ex; ex += h4[j]; }
         }
         __syncthreads();
+        MS_TICK(3);
 #pragma unroll
         for (int i = 0; i < MS_CH / MS_NT; ++i) {
             const int q = i * MS_NT + threadIdx.x;
@@ -544,6 +568,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
             }
         }
         __syncthreads();
+        MS_TICK(4);
         for (int q = threadIdx.x; q < n; q += MS_NT) {
             const uint64_t x1 = s.w1[q];
             const uint32_t b = ms_child(x1, shift, nb, fbits);
@@ -553,9 +578,17 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
             if (HAS_ST) out_st[g] = s.st[q];
         }
         __syncthreads();
+        MS_TICK(5);
         for (int b = threadIdx.x; b < nb; b += MS_NT) s.run[b] += s.hist[b];
         __syncthreads();
+        MS_TICK(6);
     }
+#ifdef DBG_MS_PROF
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_ms_prof[i], prof_[i]);
+        atomicAdd(&g_ms_prof[7], 1ull);
+    }
+#endif
 }
 
 

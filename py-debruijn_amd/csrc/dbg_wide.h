@@ -112,10 +112,15 @@ __device__ inline bool tile_inst(const TileLds &t, int j, int k, WInst &o) {
     return true;
 }
 
+// The table takes any number of slots (a multiple of 1024), not only powers of two: its memset and the compaction scan are
+// proportional to it (2^31 slots x 48 B for 1.26e9 wanted = 16.8 ms of memset per build).  Home slot = high product.
+__device__ inline uint64_t whome(uint64_t hv, uint64_t cap) { return __umul64hi(hv, cap); }
+__device__ inline uint64_t wnext(uint64_t slot, uint64_t cap) { return slot + 1 == cap ? 0 : slot + 1; }
+
 __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, uint64_t n_bytes,
                                                 const uint32_t *__restrict__ startbits, int k,
                                                 const uint64_t *__restrict__ pk, WSlot *tab, uint32_t *tcnt,
-                                                uint64_t cap_mask, int hash_shift, uint32_t *occ,
+                                                uint64_t cap, uint32_t *occ,
                                                 unsigned long long *scalars) {
     __shared__ TileLds t;
     const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
@@ -134,9 +139,9 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
         n_e += in.at_end ^ 1u;
         const uint64_t hv = k128_hash(in.key);
         const unsigned long long mine = ((hv & 0xFFFFull) << 48) | stamp;
-        uint64_t slot = hv >> hash_shift;
+        uint64_t slot = whome(hv, cap);
         bool found = false;
-        for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        for (uint64_t probe = 0; probe < cap; ++probe) {
             WSlot *s = tab + slot;
             unsigned long long cur = __hip_atomic_load(&s->ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (cur == W_EMPTY) {
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
                     break;
                 }
             }
-            slot = (slot + 1) & cap_mask;
+            slot = wnext(slot, cap);
         }
         if (!found) { atomicOr(&scalars[0], 2ull); continue; }  // table full
         if (!in.at_end) atomicAdd(&tcnt[slot * 4 + in.next], 1u);
@@ -181,38 +186,36 @@ __global__ __launch_bounds__(256) void k_wgather(WSlot *tab, const uint32_t *__r
                                                  const uint32_t *occ, const uint32_t *word_rank, uint64_t n_words,
                                                  uint64_t *keys_lo, uint64_t *keys_hi,
                                                  uint64_t *stamps, uint32_t *cnt, uint8_t *flags) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // one thread per SLOT: neighbouring lanes read neighbouring sectors and write neighbouring nodes (one thread per
+    // occupancy word walked its 32 slots alone, every access a sector of its own: 41 ms for 4.6e8 nodes)
+    const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t w = slot >> 5;
     if (w >= n_words) return;
-    uint32_t bits = occ[w];
-    uint32_t node = word_rank[w];
-    while (bits) {
-        const int b = __ffs(bits) - 1;
-        bits &= bits - 1;
-        const uint64_t slot = w * 32 + b;
-        const WSlot sl = tab[slot];  // the key cache is complete: the count kernel has finished
-        const uint64_t st = sl.ref & W_STAMP_MASK;
-        keys_lo[node] = sl.lo;
-        keys_hi[node] = sl.hi;
-        stamps[node] = st;
-        reinterpret_cast<uint4 *>(cnt)[node] = reinterpret_cast<const uint4 *>(tcnt)[slot];
-        flags[node] = (uint8_t)(st & 1);
-        tab[slot].ref = (sl.ref & ~W_STAMP_MASK) | node;
-        ++node;
-    }
+    const uint32_t word = occ[w], bit = (uint32_t)(slot & 31);
+    if (!((word >> bit) & 1u)) return;
+    const uint32_t node = word_rank[w] + __popc(word & ((1u << bit) - 1u));
+    const WSlot sl = tab[slot];  // the key cache is complete: the count kernel has finished
+    const uint64_t st = sl.ref & W_STAMP_MASK;
+    keys_lo[node] = sl.lo;
+    keys_hi[node] = sl.hi;
+    stamps[node] = st;
+    reinterpret_cast<uint4 *>(cnt)[node] = reinterpret_cast<const uint4 *>(tcnt)[slot];
+    flags[node] = (uint8_t)(st & 1);
+    tab[slot].ref = (sl.ref & ~W_STAMP_MASK) | node;
 }
 
-__device__ inline uint32_t wtab_find(const WSlot *__restrict__ tab, uint64_t cap_mask, int hash_shift, K128 key) {
-    uint64_t slot = k128_hash(key) >> hash_shift;
-    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+__device__ inline uint32_t wtab_find(const WSlot *__restrict__ tab, uint64_t cap, K128 key) {
+    uint64_t slot = whome(k128_hash(key), cap);
+    for (uint64_t probe = 0; probe < cap; ++probe) {
         const WSlot sl = tab[slot];  // one sector: reference word and key
         if (sl.ref == W_EMPTY) return NO_NODE;
         if (sl.lo == key.lo && sl.hi == key.hi) return (uint32_t)(sl.ref & W_STAMP_MASK);
-        slot = (slot + 1) & cap_mask;
+        slot = wnext(slot, cap);
     }
     return NO_NODE;
 }
 
-__global__ __launch_bounds__(256) void k_wsucc(const WSlot *__restrict__ tab, uint64_t cap_mask, int hash_shift, int k,
+__global__ __launch_bounds__(256) void k_wsucc(const WSlot *__restrict__ tab, uint64_t cap, int k,
                                                uint64_t n_nodes, const uint64_t *__restrict__ keys_lo,
                                                const uint64_t *__restrict__ keys_hi, const uint32_t *__restrict__ cnt,
                                                uint32_t *succ, uint8_t *order, uint8_t *deg) {
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(256) void k_wsucc(const WSlot *__restrict__ tab, ui
     uint32_t s[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b)
-        s[b] = c[b] ? wtab_find(tab, cap_mask, hash_shift, k128_append(key, (uint32_t)b, k)) : NO_NODE;
+        s[b] = c[b] ? wtab_find(tab, cap, k128_append(key, (uint32_t)b, k)) : NO_NODE;
     reinterpret_cast<uint4 *>(succ)[i] = make_uint4(s[0], s[1], s[2], s[3]);
     deg[i] = (uint8_t)((c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0));
     uint32_t code[4] = {0, 1, 3, 2};  // ascii order A, C, G, T as codes; rank by (count desc, ascii asc)
@@ -394,16 +397,16 @@ constexpr uint64_t WS_HI_MASK = (1ull << 62) - 1;
 // lo/hi = key cache, pad = the claim: index of the tuple that created the slot (~0 free)
 __global__ __launch_bounds__(256) void k_ws_insert(const uint64_t *__restrict__ t_lo, const uint64_t *__restrict__ t_hi,
                                                    const uint64_t *__restrict__ t_st, uint64_t first, uint64_t n,
-                                                   uint64_t stamp_base2, WSlot *tab, uint32_t *tcnt, uint64_t cap_mask,
-                                                   int hash_shift, uint32_t *occ, unsigned long long *scalars) {
+                                                   uint64_t stamp_base2, WSlot *tab, uint32_t *tcnt, uint64_t cap,
+                                                   uint32_t *occ, unsigned long long *scalars) {
     const uint64_t i = first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= first + n) return;
     const K128 key{t_hi[i] & WS_HI_MASK, t_lo[i]};
     const uint32_t next = (uint32_t)(t_hi[i] >> 62);
     const unsigned long long gstamp = stamp_base2 + (t_st[i] & 0xFFFFFFFFull);
     const bool has_succ = (t_st[i] >> 32) & 1ull;
-    uint64_t slot = k128_hash(key) >> hash_shift;
-    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+    uint64_t slot = whome(k128_hash(key), cap);
+    for (uint64_t probe = 0; probe < cap; ++probe) {
         WSlot *s = tab + slot;
         unsigned long long c = __hip_atomic_load(&s->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool mine_now = false;
@@ -427,26 +430,25 @@ __global__ __launch_bounds__(256) void k_ws_insert(const uint64_t *__restrict__ 
             if (has_succ) atomicAdd(&tcnt[slot * 4 + next], 1u);
             return;
         }
-        slot = (slot + 1) & cap_mask;
+        slot = wnext(slot, cap);
     }
     atomicOr(&scalars[0], 2ull);  // table full
 }
 
 // gathered graph: every node into a fresh table (keys are distinct: claim the first free slot); k_wsucc then resolves
 __global__ __launch_bounds__(256) void k_wnode_insert(uint64_t n_nodes, const uint64_t *__restrict__ keys_lo,
-                                                      const uint64_t *__restrict__ keys_hi, WSlot *tab, uint64_t cap_mask,
-                                                      int hash_shift) {
+                                                      const uint64_t *__restrict__ keys_hi, WSlot *tab, uint64_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
     const K128 key{keys_hi[i], keys_lo[i]};
-    uint64_t slot = k128_hash(key) >> hash_shift;
-    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+    uint64_t slot = whome(k128_hash(key), cap);
+    for (uint64_t probe = 0; probe < cap; ++probe) {
         if (atomicCAS(&tab[slot].ref, W_EMPTY, (unsigned long long)i) == W_EMPTY) {
             tab[slot].lo = key.lo;
             tab[slot].hi = key.hi;
             return;
         }
-        slot = (slot + 1) & cap_mask;
+        slot = wnext(slot, cap);
     }
 }
 
