@@ -81,6 +81,7 @@ struct dbg {
 
     // walk
     uint64_t n_starts = 0, n_contigs = 0, contig_chars = 0;
+    bool starts_known = false;    // n_starts counted for the current graph
     uint64_t *d_ctg_off = nullptr;
     char *d_ctg_chars = nullptr;
     uint64_t *d_ctg_score = nullptr, *d_ctg_stamp = nullptr;
@@ -1296,6 +1297,7 @@ static void free_build(dbg *h) {
     h->pruned = h->tipped = h->pull_reads_done = h->walked = h->walk_indexed = false;
     h->n_branch = h->n_pulled = h->tip_rounds = h->n_pull_reads = 0;
     h->n_starts = h->n_contigs = h->contig_chars = 0;
+    h->starts_known = false;
     h->n_kmer_inst = h->n_edge_inst = 0;
 }
 
@@ -1532,12 +1534,17 @@ static int finish_graph(dbg *h) {
         }
         h->stats.ms_csr = t.stop();
     }
-    // starts = nodes with indegree 0
-    {
-        uint64_t total = 0;
-        CHK(reduce_sum(h, h->n_nodes, FlagSet{h->d_flags, DBG_F_INDEG, 0}, &total));
-        h->n_starts = total;
-    }
+    h->starts_known = false;  // counted when first asked for (dbg_get_sizes, dbg_walk): the walk's input, not the build's
+    return DBG_OK;
+}
+
+// starts = nodes with indegree 0 (debruijn.py:334-336)
+static int ensure_starts(dbg *h) {
+    if (h->starts_known || !h->k) return DBG_OK;
+    uint64_t total = 0;
+    CHK(reduce_sum(h, h->n_nodes, FlagSet{h->d_flags, DBG_F_INDEG, 0}, &total));
+    h->n_starts = total;
+    h->starts_known = true;
     return DBG_OK;
 }
 
@@ -2264,6 +2271,7 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
     h->n_contigs = h->contig_chars = 0;
     h->walked = false;
     h->walk_indexed = false;
+    { const int rs = ensure_starts(h); if (rs != DBG_OK) return rs; }
     const uint64_t ns = h->n_starts;
     const bool use_jump = !final_mode && h->n_nodes >= h->walk_jump_min && ns;
     uint32_t *starts = nullptr;
@@ -2414,6 +2422,10 @@ extern "C" int dbg_walk(dbg_t *h, int final_mode, uint64_t max_chars) {
 
 extern "C" int dbg_get_sizes(dbg_t *h, dbg_sizes_t *o) {
     if (!h || !o) return DBG_E_ARG;
+    if (h->k && h->n_nodes && !h->starts_known) {
+        HIPCHK(h, hipSetDevice(h->device));
+        CHK(ensure_starts(h));
+    }
     memset(o, 0, sizeof(*o));
     o->k = h->k;
     o->abi_version = DBG_ABI_VERSION;

@@ -426,14 +426,8 @@ __global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__
     __syncthreads();
     const uint64_t beg = P.start[seg] + sidx * MS_SC;
     const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
-    for (uint64_t i0 = beg; i0 < end; i0 += 256 * 8) {  // eight loads in flight per thread, then their LDS atomics
-        uint64_t v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = w1[min(i0 + (uint64_t)(j * 256 + threadIdx.x), end - 1)];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            if (i0 + (uint64_t)(j * 256 + threadIdx.x) < end) atomicAdd(&hist[ms_child(v[j], shift, nb, fbits)], 1u);
-    }
+    for (uint64_t i = beg + threadIdx.x; i < end; i += 256)
+        atomicAdd(&hist[ms_child(w1[i], shift, nb, fbits)], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256) cmat[(uint64_t)blockIdx.x * nb + b] = hist[b];
 }
@@ -526,19 +520,15 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
         uint64_t r0[MS_CH / MS_NT], r1[MS_CH / MS_NT];
         ST rs[MS_CH / MS_NT];
         uint32_t rk[MS_CH / MS_NT];
-        // all loads of the chunk first, unconditionally (a clamped index instead of a branch): behind `if (q < n)` the
-        // compiler issued load - wait - rank per record, eight memory round trips in a row (66 % of the kernel)
-#pragma unroll
-        for (int i = 0; i < MS_CH / MS_NT; ++i) {
-            const int q = min(i * MS_NT + (int)threadIdx.x, n - 1);
-            r0[i] = in_w0[c0 + q];
-            r1[i] = in_w1[c0 + q];
-            if (HAS_ST) rs[i] = in_st[c0 + q];
-        }
 #pragma unroll
         for (int i = 0; i < MS_CH / MS_NT; ++i) {
             const int q = i * MS_NT + threadIdx.x;
-            if (q < n) rk[i] = atomicAdd(&s.hist[ms_child(r1[i], shift, nb, fbits)], 1u);
+            if (q < n) {
+                r0[i] = in_w0[c0 + q];
+                r1[i] = in_w1[c0 + q];
+                if (HAS_ST) rs[i] = in_st[c0 + q];
+                rk[i] = atomicAdd(&s.hist[ms_child(r1[i], shift, nb, fbits)], 1u);
+            }
         }
         __syncthreads();
         MS_TICK(2);
