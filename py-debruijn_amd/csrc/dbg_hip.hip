@@ -298,6 +298,13 @@ static int reduce_sum(dbg *h, uint64_t n, F f, uint64_t *h_total) {
     return DBG_OK;
 }
 
+struct OccBytes32 {  // occupied slots among 32 one-byte flags (each 0 or 1)
+    const uint8_t *occ;
+    __device__ uint64_t operator()(uint64_t w) const {
+        const uint4 a = reinterpret_cast<const uint4 *>(occ)[2 * w], b = reinterpret_cast<const uint4 *>(occ)[2 * w + 1];
+        return __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(b.x) + __popc(b.y) + __popc(b.z) + __popc(b.w);
+    }
+};
 struct PopcWords {
     const uint32_t *w;
     __device__ uint64_t operator()(uint64_t i) const { return __popc(w[i]); }
@@ -1774,7 +1781,8 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
     const uint64_t pk_words = (h->n_bytes + 31) / 32, n_occ = cap / 32;
     uint64_t *pk = nullptr;
     WSlot *tab = nullptr;
-    uint32_t *tcnt = nullptr, *occ = nullptr, *word_rank = nullptr;
+    uint32_t *tcnt = nullptr, *word_rank = nullptr;
+    uint8_t *occ = nullptr;  // one byte per slot
     auto cleanup = [&]() {};  // everything lives in the grow-only arena (hipMalloc of tens of GB costs seconds)
     int rc = DBG_OK;
     uint64_t sc[4] = {0, 0, 0, 0};
@@ -1783,17 +1791,17 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         if ((rc = buf_ensure(h, h->ar_wide[0], (pk_words + 3) * 8)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot))) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[2], cap * 16)) != DBG_OK) break;
-        if ((rc = buf_ensure(h, h->ar_wide[3], n_occ * 4)) != DBG_OK) break;
+        if ((rc = buf_ensure(h, h->ar_wide[3], cap)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[4], n_occ * 4)) != DBG_OK) break;
         pk = (uint64_t *)h->ar_wide[0].p;
         tab = (WSlot *)h->ar_wide[1].p;
         tcnt = (uint32_t *)h->ar_wide[2].p;
-        occ = (uint32_t *)h->ar_wide[3].p;
+        occ = (uint8_t *)h->ar_wide[3].p;
         word_rank = (uint32_t *)h->ar_wide[4].p;
         (void)hipMemsetAsync(pk + pk_words, 0, 3 * 8, h->stream);
         (void)hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream);
         (void)hipMemsetAsync(tcnt, 0, cap * 16, h->stream);
-        (void)hipMemsetAsync(occ, 0, n_occ * 4, h->stream);
+        (void)hipMemsetAsync(occ, 0, cap, h->stream);
         (void)hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream);
         if (pk_words)
             hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
@@ -1815,7 +1823,7 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
 
         Timer tg(h->stream);
         uint64_t total = 0;
-        if ((rc = exclusive_scan(h, n_occ, PopcWords{occ}, word_rank, &total)) != DBG_OK) break;
+        if ((rc = exclusive_scan(h, n_occ, OccBytes32{occ}, word_rank, &total)) != DBG_OK) break;
         if (total >= 0xFFFFFFFFull) { h->err = "more than 2^32-1 nodes"; rc = DBG_E_CAPACITY; break; }
         h->n_nodes = total;
         if ((rc = buf_ensure(h, h->ar_node[0], total * 8)) != DBG_OK) break;
@@ -3196,13 +3204,14 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     const uint64_t n_occ = cap / 32;
     CHK(buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot)));
     CHK(buf_ensure(h, h->ar_wide[2], cap * 16));
-    CHK(buf_ensure(h, h->ar_wide[3], n_occ * 4));
+    CHK(buf_ensure(h, h->ar_wide[3], cap));
     CHK(buf_ensure(h, h->ar_wide[4], n_occ * 4));
     WSlot *tab = (WSlot *)h->ar_wide[1].p;
-    uint32_t *tcnt = (uint32_t *)h->ar_wide[2].p, *occ = (uint32_t *)h->ar_wide[3].p, *word_rank = (uint32_t *)h->ar_wide[4].p;
+    uint32_t *tcnt = (uint32_t *)h->ar_wide[2].p, *word_rank = (uint32_t *)h->ar_wide[4].p;
+    uint8_t *occ = (uint8_t *)h->ar_wide[3].p;
     HIPCHK(h, hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream));
     HIPCHK(h, hipMemsetAsync(tcnt, 0, cap * 16, h->stream));
-    HIPCHK(h, hipMemsetAsync(occ, 0, n_occ * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(occ, 0, cap, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
     Timer tc(h->stream);
     for (int r = 0; r < n_shards; ++r) {
@@ -3222,7 +3231,7 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     h->n_kmer_inst = n_rec;
     h->n_edge_inst = n_edge;
     uint64_t total = 0;
-    CHK(exclusive_scan(h, n_occ, PopcWords{occ}, word_rank, &total));
+    CHK(exclusive_scan(h, n_occ, OccBytes32{occ}, word_rank, &total));
     if (total >= (1ull << 29) - 16) { h->err = "a shard holds at most 2^29 nodes"; return DBG_E_CAPACITY; }
     h->n_nodes = total;
     CHK(buf_ensure(h, h->ar_node[0], total * 8));
