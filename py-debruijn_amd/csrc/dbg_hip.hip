@@ -1767,8 +1767,10 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
 }
 
 // ---- 32 <= k <= 63 over ACGT: two-word k-mers (see dbg_wide.h for the table protocol)
-static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
-    if (h->n_bytes >= (1ull << 46)) { h->err = "reads too large for 48-bit stamps"; return DBG_E_CAPACITY; }
+// packed: the four successor counters of a slot are 16-bit fields of its spare word; a counter that overflows reports it
+// and the caller builds again with the separate 32-bit counters
+static int build_wide_once(dbg *h, int k, uint64_t table_capacity_hint, bool packed, bool *overflow) {
+    if (h->n_bytes >= (1ull << 43)) { h->err = "reads too large for the 44-bit positions of the table's protocol word"; return DBG_E_CAPACITY; }
     // table slots: the k-mer instances (an upper bound of the distinct k-mers) / 0.7, any multiple of 1024 -- memset and
     // compaction scan are proportional to the table
     uint64_t want = table_capacity_hint;
@@ -1790,17 +1792,17 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         Timer t(h->stream);
         if ((rc = buf_ensure(h, h->ar_wide[0], (pk_words + 3) * 8)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[1], cap * sizeof(WSlot))) != DBG_OK) break;
-        if ((rc = buf_ensure(h, h->ar_wide[2], cap * 16)) != DBG_OK) break;
+        if (!packed && (rc = buf_ensure(h, h->ar_wide[2], cap * 16)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[3], cap)) != DBG_OK) break;
         if ((rc = buf_ensure(h, h->ar_wide[4], n_occ * 4)) != DBG_OK) break;
         pk = (uint64_t *)h->ar_wide[0].p;
         tab = (WSlot *)h->ar_wide[1].p;
-        tcnt = (uint32_t *)h->ar_wide[2].p;
+        tcnt = packed ? nullptr : (uint32_t *)h->ar_wide[2].p;
         occ = (uint8_t *)h->ar_wide[3].p;
         word_rank = (uint32_t *)h->ar_wide[4].p;
         (void)hipMemsetAsync(pk + pk_words, 0, 3 * 8, h->stream);
-        (void)hipMemsetAsync(tab, 0xFF, cap * sizeof(WSlot), h->stream);
-        (void)hipMemsetAsync(tcnt, 0, cap * 16, h->stream);
+        hipLaunchKernelGGL(k_wtab_init, dim3(grid_for(cap, 256)), dim3(256), 0, h->stream, tab, cap);
+        if (tcnt) (void)hipMemsetAsync(tcnt, 0, cap * 16, h->stream);
         (void)hipMemsetAsync(occ, 0, cap, h->stream);
         (void)hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream);
         if (pk_words)
@@ -1818,6 +1820,7 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         if (e != hipSuccess || hipGetLastError() != hipSuccess) { h->err = "k_wcount failed"; rc = DBG_E_HIP; break; }
         if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; rc = DBG_E_ALPHABET; break; }
         if (sc[0] & 2) { h->err = "hash table capacity exceeded"; rc = DBG_E_CAPACITY; break; }
+        if (sc[0] & 32) { *overflow = true; rc = DBG_E_CAPACITY; h->err = "successor counter overflow"; break; }
         h->n_kmer_inst = sc[1];
         h->n_edge_inst = sc[2];
 
@@ -1844,7 +1847,7 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
         h->nodes_in_arena = true;
         hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ * 32, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
-                           h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
+                           h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags, 1);
         h->stats.ms_compact = tg.stop();
         Timer ts(h->stream);
         if (total)
@@ -1855,6 +1858,16 @@ static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
         if (e != hipSuccess || hipGetLastError() != hipSuccess) { h->err = std::string("wide build: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
     } while (false);
     cleanup();
+    return rc;
+}
+
+static int build_wide(dbg *h, int k, uint64_t table_capacity_hint) {
+    bool overflow = false;
+    int rc = build_wide_once(h, k, table_capacity_hint, true, &overflow);
+    if (rc != DBG_OK && overflow) {
+        rc = build_wide_once(h, k, table_capacity_hint, false, &overflow);
+        if (rc == DBG_OK) h->err.clear();
+    }
     return rc;
 }
 
@@ -3252,7 +3265,7 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
     h->nodes_in_arena = true;
     hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ * 32, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
-                       h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags);
+                       h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags, 0);
     // successors inside this shard only (ids local, untagged): the gathered graph resolves all of them (dbg_import_graph)
     if (total)
         hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap, k, total,

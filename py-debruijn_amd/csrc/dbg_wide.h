@@ -112,6 +112,15 @@ __device__ inline bool tile_inst(const TileLds &t, int j, int k, WInst &o) {
     return true;
 }
 
+// empty table: protocol word and key cache all ones (no k-mer has the top bits of `hi` set), spare word 0 (packed counters)
+__global__ __launch_bounds__(256) void k_wtab_init(WSlot *tab, uint64_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    uint4 *q = reinterpret_cast<uint4 *>(tab + i);
+    q[0] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    q[1] = make_uint4(~0u, ~0u, 0u, 0u);
+}
+
 // The table takes any number of slots (a multiple of 1024), not only powers of two: its memset and the compaction scan are
 // proportional to it (2^31 slots x 48 B for 1.26e9 wanted = 16.8 ms of memset per build).  Home slot = high product.
 __device__ inline uint64_t whome(uint64_t hv, uint64_t cap) { return __umul64hi(hv, cap); }
@@ -134,11 +143,16 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
         WInst in;
         if (!tile_inst(t, j, k, in)) continue;
         if (in.at_end && in.s0) continue;  // read of length exactly k: contributes nothing [:126]
-        const uint64_t stamp = (p << 1) | (in.s0 ^ 1u);
+        // protocol word: position, indegree flag, and this instance's own out-edge (has one, which base).  The edge of
+        // the instance a slot ends up pointing at is implicit -- k_wgather adds it -- so a k-mer seen once (most of them,
+        // with sequencing errors) costs one atomic, the claim, and no counter update.
+        const uint64_t stamp = (p << 4) | ((uint64_t)(in.s0 ^ 1u) << 3) | ((uint64_t)(in.at_end ^ 1u) << 2) |
+                               (in.at_end ? 0u : in.next);
         n_k += 1;
         n_e += in.at_end ^ 1u;
         const uint64_t hv = k128_hash(in.key);
         const unsigned long long mine = ((hv & 0xFFFFull) << 48) | stamp;
+        unsigned long long explicit_edge = mine;  // whose out-edge this thread adds to the counters (W_EMPTY: nobody's)
         uint64_t slot = whome(hv, cap);
         bool found = false;
         for (uint64_t probe = 0; probe < cap; ++probe) {
@@ -150,6 +164,7 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
                     __hip_atomic_store(&s->lo, (unsigned long long)in.key.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&s->hi, (unsigned long long)in.key.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     occ[slot] = 1;  // one byte per slot: a plain store (an atomicOr per new node was 4.6e8 more global atomics)
+                    explicit_edge = W_EMPTY;  // the slot points at this instance: its edge is implicit
                     found = true;
                     break;
                 }
@@ -158,10 +173,14 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
                 const unsigned long long clo = __hip_atomic_load(&s->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned long long chi = __hip_atomic_load(&s->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((clo == in.key.lo && chi == in.key.hi) ||
-                    k128_eq(packed_kmer(pk, (cur & W_STAMP_MASK) >> 1, k), in.key)) {
+                    k128_eq(packed_kmer(pk, (cur & W_STAMP_MASK) >> 4, k), in.key)) {
                     // the smaller value is the earlier instance.  Most instances are not the first of their k-mer
-                    // (30x coverage) and skip the atomic: the slot only ever decreases
-                    if (mine < cur) atomicMin(&s->ref, mine);
+                    // (30x coverage) and skip the atomic: the slot only ever decreases.  An instance that takes the
+                    // slot over adds the edge of the one it displaced (each value is displaced exactly once).
+                    if (mine < cur) {
+                        const unsigned long long old = atomicMin(&s->ref, mine);
+                        if (old > mine) explicit_edge = old;
+                    }
                     found = true;
                     break;
                 }
@@ -169,7 +188,15 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
             slot = wnext(slot, cap);
         }
         if (!found) { atomicOr(&scalars[0], 2ull); continue; }  // table full
-        if (!in.at_end) atomicAdd(&tcnt[slot * 4 + in.next], 1u);
+        if (explicit_edge != W_EMPTY && (explicit_edge & 4ull)) {
+            const uint32_t nx = (uint32_t)(explicit_edge & 3ull);
+            if (tcnt) {
+                atomicAdd(&tcnt[slot * 4 + nx], 1u);
+            } else {  // four 16-bit counters in the slot's spare word: same sector as the probe, no second random access
+                const unsigned long long old = atomicAdd(&tab[slot].pad, 1ull << (16 * nx));
+                if (((old >> (16 * nx)) & 0xFFFFull) == 0xFFFFull) atomicOr(&scalars[0], 32ull);  // rebuild with 32-bit counters
+            }
+        }
     }
     // one update per workgroup and counter: these are same-address atomics (serialised chip-wide, ~12 ns each)
     uint64_t tot_k, tot_e;
@@ -185,7 +212,7 @@ __global__ __launch_bounds__(256) void k_wcount(const char *__restrict__ bases, 
 __global__ __launch_bounds__(256) void k_wgather(WSlot *tab, const uint32_t *__restrict__ tcnt,
                                                  const uint8_t *occ, const uint32_t *word_rank, uint64_t n_words,
                                                  uint64_t *keys_lo, uint64_t *keys_hi,
-                                                 uint64_t *stamps, uint32_t *cnt, uint8_t *flags) {
+                                                 uint64_t *stamps, uint32_t *cnt, uint8_t *flags, int implicit_edge) {
     // one thread per SLOT: neighbouring lanes read neighbouring sectors and write neighbouring nodes (one thread per
     // 32 slots walked them alone, every access a sector of its own: 41 ms for 4.6e8 nodes).  word_rank[w] = occupied
     // slots before slot 32 w; the slot count is a multiple of 1024, so a wave is inside the table as a whole.
@@ -198,11 +225,22 @@ __global__ __launch_bounds__(256) void k_wgather(WSlot *tab, const uint32_t *__r
     const uint32_t lane = threadIdx.x & 63, word = (uint32_t)(wave_mask >> (lane & 32)), bit = lane & 31;
     const uint32_t node = word_rank[w] + __popc(word & ((1u << bit) - 1u));
     const WSlot sl = tab[slot];  // the key cache is complete: the count kernel has finished
-    const uint64_t st = sl.ref & W_STAMP_MASK;
+    uint64_t st = sl.ref & W_STAMP_MASK;
+    uint4 c = (tcnt || !implicit_edge)
+                  ? reinterpret_cast<const uint4 *>(tcnt)[slot]
+                  : make_uint4((uint32_t)(sl.pad & 0xFFFF), (uint32_t)((sl.pad >> 16) & 0xFFFF),
+                               (uint32_t)((sl.pad >> 32) & 0xFFFF), (uint32_t)(sl.pad >> 48));
+    if (implicit_edge) {  // k_wcount's protocol word: position << 4 | indegree flag << 3 | has edge << 2 | base
+        if (st & 4) {
+            const uint32_t nx = (uint32_t)(st & 3);
+            c.x += nx == 0; c.y += nx == 1; c.z += nx == 2; c.w += nx == 3;
+        }
+        st = ((st >> 4) << 1) | ((st >> 3) & 1);
+    }
     keys_lo[node] = sl.lo;
     keys_hi[node] = sl.hi;
     stamps[node] = st;
-    reinterpret_cast<uint4 *>(cnt)[node] = reinterpret_cast<const uint4 *>(tcnt)[slot];
+    reinterpret_cast<uint4 *>(cnt)[node] = c;
     flags[node] = (uint8_t)(st & 1);
     tab[slot].ref = (sl.ref & ~W_STAMP_MASK) | node;
 }

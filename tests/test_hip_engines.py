@@ -155,3 +155,23 @@ def test_capacity_retry_when_the_estimate_is_low():
     g2.set_reads(reads.reshape(-1), off)
     g2.build(31)
     assert g2.stats()["count_launches"] == 1
+
+
+def test_two_word_counter_overflow_falls_back_to_32_bit_counters():
+    """k > 31 keeps the four successor counters of a k-mer as 16-bit fields of its table slot; an edge seen more than
+    65 535 times reports the overflow and the build runs again with separate 32-bit counters -- same graph."""
+    rng = np.random.default_rng(5)
+    one = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 40)
+    reads = np.tile(one, (70000, 1))
+    reads[:500] = synth.reads_ascii(9, 2000, 500, 40, 0.02)  # some ordinary reads next to the 69 500 copies
+    off = np.arange(0, reads.size + 1, 40, dtype=np.uint64)
+    for k in (33, 39):
+        want = orc_c.build(reads.reshape(-1), off, k)
+        assert want["counts"].max() > 65535
+        g = _dbg.Graph()
+        g.set_reads(reads.reshape(-1), off)
+        g.build(k)
+        keys, stamps, counts, flags, succ, keys_raw = table(g, k)
+        o = np.argsort(g.export_nodes()[1], kind="stable")
+        assert np.array_equal(keys, want["keys"]) and np.array_equal(g.export_keys_hi()[o], want["keys_hi"])
+        assert np.array_equal(stamps, want["stamps"]) and np.array_equal(counts, want["counts"])
