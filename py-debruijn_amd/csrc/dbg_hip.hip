@@ -3210,6 +3210,8 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     uint64_t n_rec = 0;
     std::vector<uint64_t> seg(n_shards);
     for (int r = 0; r < n_shards; ++r) { seg[r] = n_rec; n_rec += recv_counts[r]; }
+    for (int r = 0; r < n_shards; ++r)
+        if (stamp_base[r] >= (1ull << 42)) { h->err = "reads too large for the 44-bit positions of the table's protocol word"; return DBG_E_CAPACITY; }
     h->k = k;
     h->stats.n_records = n_rec;
     Timer t_total(h->stream);
@@ -3265,7 +3267,7 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
     h->nodes_in_arena = true;
     hipLaunchKernelGGL(k_wgather, dim3(grid_for(n_occ * 32, 256)), dim3(256), 0, h->stream, tab, tcnt, occ, word_rank, n_occ,
-                       h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags, 0);
+                       h->d_keys, h->d_keys_hi, h->d_stamps, h->d_cnt, h->d_flags, 1);
     // successors inside this shard only (ids local, untagged): the gathered graph resolves all of them (dbg_import_graph)
     if (total)
         hipLaunchKernelGGL(k_wsucc, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, tab, cap, k, total,

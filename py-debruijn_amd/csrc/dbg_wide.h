@@ -446,6 +446,7 @@ __global__ __launch_bounds__(256) void k_ws_insert(const uint64_t *__restrict__ 
     const uint32_t next = (uint32_t)(t_hi[i] >> 62);
     const unsigned long long gstamp = stamp_base2 + (t_st[i] & 0xFFFFFFFFull);
     const bool has_succ = (t_st[i] >> 32) & 1ull;
+    const unsigned long long word = (gstamp << 3) | ((unsigned long long)has_succ << 2) | (has_succ ? next : 0u);
     uint64_t slot = whome(k128_hash(key), cap);
     for (uint64_t probe = 0; probe < cap; ++probe) {
         WSlot *s = tab + slot;
@@ -467,8 +468,14 @@ __global__ __launch_bounds__(256) void k_ws_insert(const uint64_t *__restrict__ 
             mine_now = (clo == key.lo && chi == key.hi) || (t_lo[c] == key.lo && (t_hi[c] & WS_HI_MASK) == key.hi);
         }
         if (mine_now) {
-            if (gstamp < __hip_atomic_load(&s->ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&s->ref, gstamp);
-            if (has_succ) atomicAdd(&tcnt[slot * 4 + next], 1u);
+            // same protocol word as k_wcount (position << 4 | indegree flag << 3 | has edge << 2 | base): the edge of the
+            // instance the slot ends up pointing at is implicit (k_wgather adds it), a taker adds the displaced one's
+            unsigned long long explicit_edge = word;
+            if (word < __hip_atomic_load(&s->ref, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                const unsigned long long old = atomicMin(&s->ref, word);
+                if (old > word) explicit_edge = old;  // W_EMPTY (first taker): bit 2 set, but nobody's edge
+            }
+            if (explicit_edge != W_EMPTY && (explicit_edge & 4ull)) atomicAdd(&tcnt[slot * 4 + (explicit_edge & 3ull)], 1u);
             return;
         }
         slot = wnext(slot, cap);

@@ -41,7 +41,9 @@ def exchange_counts(dist, counts, device):
     return [int(x) for x in recv.tolist()]
 
 
-MAX_MESSAGE_BYTES = (1 << 31) - 4096  # per (source, destination) pair and call; larger transfers go in rounds
+# per (source, destination) pair and call; larger transfers go in rounds.  1 GiB: over nccl a self-copy of 2 GiB - 4 KiB
+# still arrived damaged (one-rank sharded build of 4 M reads at k = 63: 1.77e8 nodes instead of 1.83e8), 1 GiB is exact
+MAX_MESSAGE_BYTES = 1 << 30
 
 
 def _alltoallv_once(dist, tensor, send_counts, recv_counts):
@@ -59,8 +61,8 @@ def alltoallv(dist, tensor, send_counts, recv_counts):
     """Variable all-to-all of a 1-D tensor laid out contiguously in destination order
     (all_to_all_single with split sizes; staged through the host for gloo).
 
-    A (source, destination) message of 4 GiB or more is not safe with every backend (observed: a 7 GB
-    self-copy over nccl arrived truncated), so pairs above MAX_MESSAGE_BYTES are moved in rounds of that
+    A large (source, destination) message is not safe with every backend (observed over nccl: a 7 GB
+    self-copy arrived truncated, a 2 GiB one damaged), so pairs above MAX_MESSAGE_BYTES are moved in rounds of that
     size; the number of rounds is agreed on with one all-reduce.
     """
     limit = max(1, MAX_MESSAGE_BYTES // tensor.element_size())

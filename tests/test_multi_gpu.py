@@ -110,3 +110,17 @@ def test_four_ranks_on_one_gpu_two_word_kmers(tmp_path):
     """BASELINE.json configs[4] in miniature: k = 63 over four ranks (the k-mer instances travel)."""
     shards = run_ranks("gpu", 4, tmp_path, 63, 8000, 150)
     check(shards, 4, 63, 8000, 150)
+
+
+@pytest.mark.gpu
+def test_one_rank_over_rccl_equals_the_single_build_with_multi_round_exchange():
+    """The exchange itself over nccl (= RCCL), at a size where a (source, destination) message exceeds
+    MAX_MESSAGE_BYTES and goes in rounds: 4 M reads at k = 63 are 3.5e8 k-mer instance tuples, 2.8 GB per array.
+    (A 2 GiB self-copy over nccl arrived damaged; the node and edge totals then differ from the single build.)"""
+    env = dict(os.environ, READS="4", K="63", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "tools", "shard_check.py")], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("4000000 ")]
+    assert lines and lines[-1].endswith(" OK"), out.stdout[-2000:]
