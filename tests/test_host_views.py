@@ -1,0 +1,94 @@
+"""Host logic of the drop-in (CPU only): the read-only Mapping views that replace the dicts for large graphs.
+
+The arrays a GPU build would export are derived here from the oracle, put into a shuffled "table order" next to the
+dict-order permutation (what dbg_export_dict_order returns), and the views over them must equal the oracle's dicts --
+order, lookups, membership -- without ever seeing the arrays in dict order."""
+import contextlib
+import io
+from collections import Counter
+
+import numpy as np
+import pytest
+
+import _dbg
+import debruijn as prod
+from conftest import case_reads, load_golden
+from oracle import dbg_oracle as orc
+from oracle import orc_c
+
+CODE_CHAR = "ACTG"  # code -> base of the 2-bit path
+
+
+def pack(reads):
+    blob = "".join(reads).encode("ascii")
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum([len(r) for r in reads], out=off[1:])
+    return np.frombuffer(blob, dtype=np.uint8), off
+
+
+@pytest.mark.parametrize("name", ["dna_small_k5_e1_t2", "dna_small_k9_e1_t1", "dna_med_k21_e1_t2", "dna_small_k33_e1_t2",
+                                  "hand_tips_order_t2_nonfinal", "hand_cycle_rho_t1_nonfinal"])
+def test_views_over_table_order_arrays_equal_the_oracle_dicts(name):
+    case = load_golden(name)
+    reads, inp = case_reads(case), case["inputs"]
+    k, thr = inp["k"], inp["threshold"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        V0, E0 = orc.graph_from_reads(list(reads), k)                       # unpruned: successor lists with repeats
+        (V, E), pull, branch, pulled, ect = orc.construct_graph(list(reads), k, threshold=thr, final=False)
+    res = orc_c.build(*pack(reads), k)
+    n = res["n_nodes"]
+    labels = list(V.keys())
+    assert n == len(labels)
+    code = {c: i for i, c in enumerate(CODE_CHAR)}
+    rank_mc = np.full((n, 4), 0, dtype=np.uint8)
+    rank_fs = np.full((n, 4), 0, dtype=np.uint8)
+    keep = np.zeros(n, dtype=np.uint32)
+    flags = (res["stamps"] & np.uint64(1)).astype(np.uint8)
+    pulled_set = set(pulled)
+    for i, lab in enumerate(labels):
+        cnt = Counter(E0.get(lab, []))
+        mc = [code[s[-1]] for s, _ in cnt.most_common()]
+        fs = [code[s[-1]] for s in cnt]
+        rank_mc[i] = mc + [c for c in range(4) if c not in mc]              # DNA ranks all four codes
+        rank_fs[i] = fs + [c for c in range(4) if c not in fs]
+        if lab in pulled_set:
+            flags[i] |= _dbg.F_PULLED
+        else:
+            for s in E[lab]:
+                keep[i] |= 1 << code[s[-1]]
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)                                               # table row r holds dict-order node perm[r]
+    order = np.argsort(res["stamps"][perm], kind="stable").astype(np.int64)  # == dbg_export_dict_order
+    wide = 2 * k > 64
+    store = prod._NodeStore(k, CODE_CHAR.encode(), 2, order, res["keys"][perm], res["keys_hi"][perm] if wide else None,
+                            res["counts"][perm], rank_mc[perm], rank_fs[perm], flags[perm], keep[perm])
+    Vv, Ev, Cv = prod._LazyVertices(store), prod._LazyEdges(store), prod._LazyEdgeCounts(store)
+    assert list(Vv) == labels and len(Vv) == n
+    assert [(Vv[v].indegree, Vv[v].outdegree) for v in labels] == [(V[v].indegree, V[v].outdegree) for v in labels]
+    assert list(Ev) == list(E) and dict(Ev) == E and len(Ev) == len(E)
+    assert list(Cv.items()) == list(ect.items()) and len(Cv) == len(ect)
+    for v in labels[:40]:
+        assert v in Vv and (v in Ev) == (v in E)
+    for bogus in ("", "N" * k, "A" * (k + 1), None, 3):
+        assert bogus not in Vv and bogus not in Ev and bogus not in Cv
+    some_edge = next(iter(ect))
+    assert Cv[some_edge] == ect[some_edge] and (some_edge[:-1] + "N") not in Cv
+
+
+def test_lazy_contigs_sequence_protocol():
+    """LazyContigs fetches texts by index in the reference's order; here against a stand-in for the device handle."""
+    texts = {0: b"ACGT", 1: b"TTTTT", 2: b"GG"}
+
+    class Handle:
+        def export_contig_text(self, index, length):
+            assert length == len(texts[index])
+            return texts[index]
+
+    off = np.array([0, 4, 9, 11], dtype=np.uint64)
+    score = np.array([7, 9, 1], dtype=np.uint64)
+    order = np.array([2, 0, 1])
+    lazy = prod.LazyContigs(Handle(), order, off, score)
+    assert len(lazy) == 3 and list(lazy) == ["GG", "ACGT", "TTTTT"] and lazy.scores == [1, 7, 9] and lazy.lengths == [2, 4, 5]
+    assert lazy[-1] == "TTTTT" and lazy[0:2] == ["GG", "ACGT"] and "ACGT" in lazy
+    with pytest.raises(IndexError):
+        lazy[3]
