@@ -82,6 +82,10 @@ struct dbg {
     // walk
     uint64_t n_starts = 0, n_contigs = 0, contig_chars = 0;
     bool starts_known = false;    // n_starts counted for the current graph
+    // engine 0, single GPU: the bucketed super-k-mer records of the last build (arena-owned, valid until the next build /
+    // extraction): dbg_refine_edge_order re-reads them bucket by bucket instead of streaming the reads against a global set
+    struct { const uint64_t *w0 = nullptr, *w1 = nullptr; const void *st = nullptr; int st_bytes = 0;
+             const uint64_t *b_start = nullptr, *b_cnt = nullptr; bool valid = false; } sk_src;
     uint64_t *d_ctg_off = nullptr;
     char *d_ctg_chars = nullptr;
     uint64_t *d_ctg_score = nullptr, *d_ctg_stamp = nullptr;
@@ -1083,6 +1087,75 @@ __device__ inline void refine_node(uint64_t slot, uint32_t node, const unsigned 
     fsorder[node] = (uint8_t)(f[0] | (f[1] << 2) | (f[2] << 4) | (f[3] << 6));
 }
 
+// The same per range of the partitioned build: the multi-successor nodes of one range (a few dozen) go into an LDS set,
+// the bucket's own super-k-mer records are expanded against it, LDS atomicMin keeps the first stamp of every out-edge.
+// No pass over the reads, no global set: 30 ms -> a few ms at 10 M reads.  A range with more than RF_SLOTS / 2 such nodes
+// (low-complexity input) reports it and the caller takes the streaming path for the whole graph.
+constexpr int RF_SLOTS = 1024;
+template <class ST>
+__global__ __launch_bounds__(256) void k_sk_refine(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ b_start,
+                                                   const uint64_t *__restrict__ b_cnt, const uint64_t *__restrict__ rec_w0,
+                                                   const uint64_t *__restrict__ rec_w1, const ST *__restrict__ rec_st, int k,
+                                                   const uint64_t *__restrict__ keys, const uint32_t *__restrict__ cnt,
+                                                   uint8_t *order, uint8_t *fsorder, unsigned long long *flag) {
+    __shared__ unsigned long long skey[RF_SLOTS];
+    __shared__ uint32_t snode[RF_SLOTS];
+    __shared__ ST sest[RF_SLOTS * 4];
+    __shared__ uint32_t n_multi;
+    const SkRange rg = ranges[blockIdx.x];
+    if (rg.node_cnt == 0) return;
+    for (int i = threadIdx.x; i < RF_SLOTS; i += 256) skey[i] = EMPTY_KEY;
+    for (int i = threadIdx.x; i < RF_SLOTS * 4; i += 256) sest[i] = (ST)~(ST)0;
+    if (threadIdx.x == 0) n_multi = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < rg.node_cnt; j += 256) {
+        const uint64_t node = rg.node_base + j;
+        const uint4 c = reinterpret_cast<const uint4 *>(cnt)[node];
+        if ((c.x != 0) + (c.y != 0) + (c.z != 0) + (c.w != 0) < 2) continue;
+        if (atomicAdd(&n_multi, 1u) >= RF_SLOTS / 2) continue;  // reported below
+        const unsigned long long key = keys[node];
+        uint32_t slot = slot_hash(key) >> 22;
+        for (;;) {  // at most half full: a free slot exists
+            if (atomicCAS(&skey[slot], EMPTY_KEY, key) == EMPTY_KEY) { snode[slot] = (uint32_t)node; break; }
+            slot = (slot + 1) & (RF_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    const uint32_t nm = n_multi;
+    if (nm == 0) return;
+    if (nm > RF_SLOTS / 2) { if (threadIdx.x == 0) atomicOr(flag, 1ull); return; }
+    const uint64_t r_beg = b_start[rg.bucket], r_n = b_cnt[rg.bucket];
+    for (uint64_t r = threadIdx.x; r < r_n; r += 256) {
+        const uint64_t w0 = rec_w0[r_beg + r], w1 = rec_w1[r_beg + r];
+        const ST st0 = rec_st[r_beg + r];
+        const int len = (int)((w1 >> 1) & 31) + 1;
+        const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+        const int n_edges = len - 1 + (int)(w1 & 1);  // the last k-mer of the record has a successor only if the flag says so
+        for (int i = 0; i < n_edges; ++i) {
+            const uint64_t win = rec_window(w0, hi, i);
+            const unsigned long long kmer = win >> (64 - 2 * k);
+            uint32_t slot = slot_hash(kmer) >> 22;
+            for (;;) {
+                const unsigned long long cur = skey[slot];
+                if (cur == EMPTY_KEY) break;
+                if (cur == kmer) {
+                    const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
+                    atomicMin(&sest[slot * 4 + b], i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0);
+                    break;
+                }
+                slot = (slot + 1) & (RF_SLOTS - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int slot = threadIdx.x; slot < RF_SLOTS; slot += 256) {
+        if (skey[slot] == EMPTY_KEY) continue;
+        unsigned long long est[4];
+        for (int b = 0; b < 4; ++b) est[b] = (unsigned long long)sest[slot * 4 + b];
+        refine_node(0, snode[slot], est, cnt, order, fsorder);
+    }
+}
+
 // set_keys == nullptr: the set holds node ids only (two-word k-mers), NO_NODE marks a free slot
 __global__ __launch_bounds__(256) void k_order_refine(uint64_t cap, const unsigned long long *set_keys,
                                                       const uint32_t *set_node, const unsigned long long *estamp,
@@ -1300,6 +1373,7 @@ static void free_build(dbg *h) {
     dev_free(h->d_ctg_seq); dev_free(h->d_ctg_start); dev_free(h->d_lift);
     h->lift_levels = 0;
     h->partial_graph = false;
+    h->sk_src.valid = false;
     h->k = 0; h->cap = 0; h->n_nodes = h->n_edges = 0;
     h->pruned = h->tipped = h->pull_reads_done = h->walked = h->walk_indexed = false;
     h->n_branch = h->n_pulled = h->tip_rounds = h->n_pull_reads = 0;
@@ -1990,6 +2064,25 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
     if (!h->n_nodes) { h->order_exact = true; return DBG_OK; }
     hipLaunchKernelGGL(k_fsorder_default, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_order,
                        h->d_fsorder);
+    if (h->sk_src.valid && !h->d_keys_hi && h->sk_n_ranges) {  // partitioned build: per range, from the bucket's own records
+        unsigned long long *flag = (unsigned long long *)(h->d_scalars + 48);
+        HIPCHK(h, hipMemsetAsync(flag, 0, 8, h->stream));
+        const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;
+        if (h->sk_src.st_bytes == 4)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_refine<uint32_t>), dim3((unsigned)h->sk_n_ranges), dim3(256), 0, h->stream, ranges,
+                               h->sk_src.b_start, h->sk_src.b_cnt, h->sk_src.w0, h->sk_src.w1, (const uint32_t *)h->sk_src.st,
+                               h->k, h->d_keys, h->d_cnt, h->d_order, h->d_fsorder, flag);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_refine<uint64_t>), dim3((unsigned)h->sk_n_ranges), dim3(256), 0, h->stream, ranges,
+                               h->sk_src.b_start, h->sk_src.b_cnt, h->sk_src.w0, h->sk_src.w1, (const uint64_t *)h->sk_src.st,
+                               h->k, h->d_keys, h->d_cnt, h->d_order, h->d_fsorder, flag);
+        HIPCHK(h, hipGetLastError());
+        unsigned long long crowded = 0;
+        HIPCHK(h, hipMemcpyAsync(&crowded, flag, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (!crowded) { h->order_exact = true; return DBG_OK; }
+        // a range with hundreds of multi-successor nodes: the streaming pass below recomputes every node
+    }
     uint64_t n_multi = 0;
     CHK(reduce_sum(h, h->n_nodes, MultiSucc{h->d_cnt}, &n_multi));
     if (n_multi && h->d_keys_hi) {  // two-word k-mers: the set holds node ids, keys are compared by reference
@@ -3064,6 +3157,11 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     }
     // geometry the answer stage of a sharded build needs again
     h->sk_T = T; h->sk_l1 = l1; h->sk_l2 = l2_pow; h->sk_nb2 = fb2 ? nb2 : 0; h->sk_n_ranges = n_ranges; h->sk_cap = CAP;
+    if (!shard_bits) {
+        h->sk_src.w0 = w0[where]; h->sk_src.w1 = w1[where]; h->sk_src.st = st[where]; h->sk_src.st_bytes = (int)sizeof(ST);
+        h->sk_src.b_start = b_start; h->sk_src.b_cnt = b_cnt;
+        h->sk_src.valid = n_rec != 0;
+    }
     return DBG_OK;
 }
 
