@@ -109,7 +109,9 @@ int dbg_abi_version(void);
  * "lds_slots" 2048 or 4096 slots of the per-bucket LDS table; "walk_jump_min_nodes" see dbg_walk;
  * "phase_limit" timing ablation of the count kernel (the build then fails on purpose);
  * "estimate_scale_pct" test hook: scales the distinct-k-mer estimate that sizes the node arrays (a low value
- * makes the first count launch run out of room and exercises the retry; dbg_stats_t.count_launches). */
+ * makes the first count launch run out of room and exercises the retry; dbg_stats_t.count_launches);
+ * "refine_streaming" 1: dbg_refine_edge_order takes its pass over the reads even when the bucketed records of the build
+ * are there (test hook: both ways must agree). */
 int dbg_set_option(dbg_t *h, const char *name, int64_t value);
 
 /* ---- reads (replaces the `reads` list argument, debruijn.py:206; FASTA

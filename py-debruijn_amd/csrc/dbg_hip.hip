@@ -121,6 +121,7 @@ struct dbg {
     };
     Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
+    bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
     uint64_t sk_n_ranges = 0;
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -1835,6 +1836,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     if (n == "estimate_scale_pct" && value >= 1 && value <= 1000) { h->est_scale_pct = (int)value; return DBG_OK; }
     if (n == "target_distinct" && value >= 0 && value <= 4096) { h->target_distinct = (int)value; return DBG_OK; }
+    if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -2064,7 +2066,7 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
     if (!h->n_nodes) { h->order_exact = true; return DBG_OK; }
     hipLaunchKernelGGL(k_fsorder_default, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes, h->d_order,
                        h->d_fsorder);
-    if (h->sk_src.valid && !h->d_keys_hi && h->sk_n_ranges) {  // partitioned build: per range, from the bucket's own records
+    if (h->sk_src.valid && !h->d_keys_hi && h->sk_n_ranges && !h->refine_streaming) {  // partitioned build: per range, from the bucket's own records
         unsigned long long *flag = (unsigned long long *)(h->d_scalars + 48);
         HIPCHK(h, hipMemsetAsync(flag, 0, 8, h->stream));
         const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;

@@ -175,3 +175,25 @@ def test_two_word_counter_overflow_falls_back_to_32_bit_counters():
         o = np.argsort(g.export_nodes()[1], kind="stable")
         assert np.array_equal(keys, want["keys"]) and np.array_equal(g.export_keys_hi()[o], want["keys_hi"])
         assert np.array_equal(stamps, want["stamps"]) and np.array_equal(counts, want["counts"])
+
+
+@pytest.mark.parametrize("k,err", [(21, 0.02), (31, 0.01), (13, 0.03)])
+def test_edge_order_from_bucket_records_equals_the_pass_over_the_reads(k, err):
+    """dbg_refine_edge_order has two implementations for the partitioned build (per range from the bucket's records;
+    streaming the reads against a global set): same rank bytes for every node with two or more successors."""
+    reads = synth.reads_ascii(31, 60000, 30000, 100, err)
+    off = np.arange(0, reads.size + 1, 100, dtype=np.uint64)
+    got = []
+    for streaming in (0, 1):
+        g = _dbg.Graph()
+        g.set_option("refine_streaming", streaming)
+        g.set_reads(reads.reshape(-1), off)
+        g.build(k)
+        g.refine_edge_order()
+        _, stamps, counts, _ = g.export_nodes()
+        o = np.argsort(stamps, kind="stable")
+        mc, fs = g.export_orders()
+        multi = (counts[o] != 0).sum(axis=1) >= 2
+        got.append((mc[o][multi], fs[o][multi]))
+    assert got[0][0].shape[0] > 100
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
