@@ -791,6 +791,81 @@ __global__ __launch_bounds__(256) void k_pull_reads(const char *__restrict__ bas
     }
 }
 
+constexpr int RF_SLOTS = 1024;  // LDS set of the per-range kernels (k_sk_pull, k_sk_refine): at most half full
+// a9 for the partitioned build: per range, the range's branch nodes (usually none or one) go into an LDS set and the
+// bucket's own super-k-mer records are expanded against it; a hit marks the read that holds the instance.  Buckets
+// without a branch node are skipped, nothing streams the reads.  Reads of length exactly k have no record (they
+// contribute nothing to the graph, debruijn.py:126) but can still contain a branch k-mer: k_pull_len_k.
+template <class ST>
+__global__ __launch_bounds__(256) void k_sk_pull(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ b_start,
+                                                 const uint64_t *__restrict__ b_cnt, const uint64_t *__restrict__ rec_w0,
+                                                 const uint64_t *__restrict__ rec_w1, const ST *__restrict__ rec_st, int k,
+                                                 const uint64_t *__restrict__ keys, const uint8_t *__restrict__ flags,
+                                                 const uint64_t *__restrict__ offsets, uint64_t n_reads, uint8_t *read_flags,
+                                                 unsigned long long *flag) {
+    __shared__ unsigned long long skey[RF_SLOTS];
+    __shared__ uint32_t n_branch;
+    const SkRange rg = ranges[blockIdx.x];
+    if (rg.node_cnt == 0) return;
+    for (int i = threadIdx.x; i < RF_SLOTS; i += 256) skey[i] = EMPTY_KEY;
+    if (threadIdx.x == 0) n_branch = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < rg.node_cnt; j += 256) {
+        const uint64_t node = rg.node_base + j;
+        if (!(flags[node] & DBG_F_BRANCH)) continue;
+        if (atomicAdd(&n_branch, 1u) >= RF_SLOTS / 2) continue;  // reported below
+        const unsigned long long key = keys[node];
+        uint32_t slot = slot_hash(key) >> 22;
+        while (atomicCAS(&skey[slot], EMPTY_KEY, key) != EMPTY_KEY) slot = (slot + 1) & (RF_SLOTS - 1);
+    }
+    __syncthreads();
+    const uint32_t nb = n_branch;
+    if (nb == 0) return;
+    if (nb > RF_SLOTS / 2) { if (threadIdx.x == 0) atomicOr(flag, 1ull); return; }
+    const uint64_t r_beg = b_start[rg.bucket], r_n = b_cnt[rg.bucket];
+    for (uint64_t r = threadIdx.x; r < r_n; r += 256) {
+        const uint64_t w0 = rec_w0[r_beg + r], w1 = rec_w1[r_beg + r];
+        const int len = (int)((w1 >> 1) & 31) + 1;
+        const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+        for (int i = 0; i < len; ++i) {
+            const unsigned long long kmer = rec_window(w0, hi, i) >> (64 - 2 * k);
+            uint32_t slot = slot_hash(kmer) >> 22;
+            bool hit = false;
+            for (;;) {
+                const unsigned long long cur = skey[slot];
+                if (cur == EMPTY_KEY) break;
+                if (cur == kmer) { hit = true; break; }
+                slot = (slot + 1) & (RF_SLOTS - 1);
+            }
+            if (!hit) continue;
+            const uint64_t p = (uint64_t)(rec_st[r_beg + r] >> 1) + (uint64_t)i;  // byte position of the instance
+            uint64_t lo = 0, up = n_reads;  // offsets[lo] <= p < offsets[up]
+            while (up - lo > 1) {
+                const uint64_t mid = (lo + up) >> 1;
+                if (offsets[mid] <= p) lo = mid; else up = mid;
+            }
+            read_flags[lo] = 1;
+        }
+    }
+}
+
+// reads of length exactly k against the global branch set
+__global__ __launch_bounds__(256) void k_pull_len_k(const char *__restrict__ bases, const uint64_t *__restrict__ offsets,
+                                                    uint64_t n_reads, int k, const uint64_t *__restrict__ btab, uint64_t cap_mask,
+                                                    uint8_t *read_flags) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || offsets[r + 1] - offsets[r] != (uint64_t)k) return;
+    uint64_t kmer = 0;
+    for (int i = 0; i < k; ++i) kmer = (kmer << 2) | (((uint64_t)(uint8_t)bases[offsets[r] + i] >> 1) & 3ull);
+    uint64_t slot = kmer_hash(kmer) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        const uint64_t cur = btab[slot];
+        if (cur == kmer) { read_flags[r] = 1; return; }
+        if (cur == EMPTY_KEY) return;
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
 struct ByteAt {
     const uint8_t *p;
     __device__ uint64_t operator()(uint64_t i) const { return p[i] != 0; }
@@ -1092,7 +1167,6 @@ __device__ inline void refine_node(uint64_t slot, uint32_t node, const unsigned 
 // the bucket's own super-k-mer records are expanded against it, LDS atomicMin keeps the first stamp of every out-edge.
 // No pass over the reads, no global set: 30 ms -> a few ms at 10 M reads.  A range with more than RF_SLOTS / 2 such nodes
 // (low-complexity input) reports it and the caller takes the streaming path for the whole graph.
-constexpr int RF_SLOTS = 1024;
 template <class ST>
 __global__ __launch_bounds__(256) void k_sk_refine(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ b_start,
                                                    const uint64_t *__restrict__ b_cnt, const uint64_t *__restrict__ rec_w0,
@@ -2356,7 +2430,31 @@ extern "C" int dbg_mark_pull_reads(dbg_t *h) {
         } else {
         hipLaunchKernelGGL(k_branch_insert, dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream, h->n_nodes,
                            h->d_flags, h->d_keys, (unsigned long long *)h->d_btab, bcap - 1);
-        if (h->D == GEN_D)
+        bool by_range = false;
+        if (h->D != GEN_D && h->sk_src.valid && h->sk_n_ranges && !h->refine_streaming) {  // partitioned build: per range
+            unsigned long long *flag = (unsigned long long *)(h->d_scalars + 48);
+            HIPCHK(h, hipMemsetAsync(flag, 0, 8, h->stream));
+            const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;
+            if (h->sk_src.st_bytes == 4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_pull<uint32_t>), dim3((unsigned)h->sk_n_ranges), dim3(256), 0, h->stream,
+                                   ranges, h->sk_src.b_start, h->sk_src.b_cnt, h->sk_src.w0, h->sk_src.w1,
+                                   (const uint32_t *)h->sk_src.st, h->k, h->d_keys, h->d_flags, h->d_offsets, h->n_reads,
+                                   h->d_read_flags, flag);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_pull<uint64_t>), dim3((unsigned)h->sk_n_ranges), dim3(256), 0, h->stream,
+                                   ranges, h->sk_src.b_start, h->sk_src.b_cnt, h->sk_src.w0, h->sk_src.w1,
+                                   (const uint64_t *)h->sk_src.st, h->k, h->d_keys, h->d_flags, h->d_offsets, h->n_reads,
+                                   h->d_read_flags, flag);
+            hipLaunchKernelGGL(k_pull_len_k, dim3(grid_for(h->n_reads, 256)), dim3(256), 0, h->stream, h->d_bases, h->d_offsets,
+                               h->n_reads, h->k, h->d_btab, bcap - 1, h->d_read_flags);
+            HIPCHK(h, hipGetLastError());
+            unsigned long long crowded = 0;
+            HIPCHK(h, hipMemcpyAsync(&crowded, flag, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            by_range = !crowded;  // else: the pass over the reads below marks every read again (flags only ever go to 1)
+        }
+        if (by_range) {
+        } else if (h->D == GEN_D)
             hipLaunchKernelGGL(k_g_pull_reads, dim3((unsigned)std::min<uint64_t>(tiles * 32, 1u << 16)), dim3(256), 0, h->stream,
                                h->d_bases, h->n_bytes, h->d_startbits, h->k, h->d_lut, h->d_btab, bcap - 1, h->d_offsets,
                                h->n_reads, h->d_read_flags);

@@ -178,7 +178,7 @@ def test_two_word_counter_overflow_falls_back_to_32_bit_counters():
 
 
 @pytest.mark.parametrize("k,err", [(21, 0.02), (31, 0.01), (13, 0.03)])
-def test_edge_order_from_bucket_records_equals_the_pass_over_the_reads(k, err):
+def test_edge_order_and_pull_reads_from_bucket_records_equal_the_pass_over_the_reads(k, err):
     """dbg_refine_edge_order has two implementations for the partitioned build (per range from the bucket's records;
     streaming the reads against a global set): same rank bytes for every node with two or more successors."""
     reads = synth.reads_ascii(31, 60000, 30000, 100, err)
@@ -194,6 +194,10 @@ def test_edge_order_from_bucket_records_equals_the_pass_over_the_reads(k, err):
         o = np.argsort(stamps, kind="stable")
         mc, fs = g.export_orders()
         multi = (counts[o] != 0).sum(axis=1) >= 2
-        got.append((mc[o][multi], fs[o][multi]))
-    assert got[0][0].shape[0] > 100
+        g.prune(2)
+        g.remove_tips()
+        g.mark_pull_reads()  # the same two ways: per range from the records / all k-mers of the reads against a global set
+        got.append((mc[o][multi], fs[o][multi], g.export_pull_reads(), g.sizes()["n_pull_reads"]))
+    assert got[0][0].shape[0] > 100 and got[0][3] > 10
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    assert got[0][3] == got[1][3] and np.array_equal(got[0][2], got[1][2])
