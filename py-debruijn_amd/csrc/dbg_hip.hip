@@ -119,7 +119,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
@@ -1443,7 +1443,8 @@ static void free_build(dbg *h) {
     dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_deg);
     h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
     h->csr_built = false;
-    dev_free(h->d_pull_rank); dev_free(h->d_read_flags);
+    h->d_pull_rank = nullptr;  // arena-owned (ar_tips)
+    dev_free(h->d_read_flags);
     dev_free(h->d_ctg_off); dev_free(h->d_ctg_chars); dev_free(h->d_ctg_score); dev_free(h->d_ctg_stamp);
     dev_free(h->d_ctg_seq); dev_free(h->d_ctg_start); dev_free(h->d_lift);
     h->lift_levels = 0;
@@ -1502,6 +1503,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_walk) buf_free(b);
     for (auto &b : h->ar_wide) buf_free(b);
     for (auto &b : h->ar_refine) buf_free(b);
+    for (auto &b : h->ar_tips) buf_free(b);
     buf_free(h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
@@ -2345,17 +2347,18 @@ static int remove_tips_impl(dbg *h, const G &g) {
     Timer t(h->stream);
     h->tip_rounds = 0;
     h->n_pulled = 0;
-    dev_free(h->d_pull_rank);
-    CHK(dev_alloc(h, &h->d_pull_rank, h->n_nodes));
+    // grow-only arena: a hipFree + hipMalloc of the two n_nodes-sized arrays per call cost up to 150 ms at 3.6e8 nodes
+    CHK(buf_ensure(h, h->ar_tips[0], (h->n_nodes ? h->n_nodes : 1) * 8));
+    h->d_pull_rank = (uint64_t *)h->ar_tips[0].p;
     if (h->n_nodes)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fill<uint64_t>), dim3(grid_for(h->n_nodes, 256)), dim3(256), 0, h->stream,
                            h->d_pull_rank, h->n_nodes, ~0ull);
     if (h->n_branch) {
-        uint32_t *pend[2] = {nullptr, nullptr};
-        unsigned long long *owner = nullptr;
-        CHK(dev_alloc(h, &pend[0], h->n_branch));
-        CHK(dev_alloc(h, &pend[1], h->n_branch));
-        CHK(dev_alloc(h, &owner, h->n_nodes));
+        CHK(buf_ensure(h, h->ar_tips[1], h->n_branch * 4));
+        CHK(buf_ensure(h, h->ar_tips[2], h->n_branch * 4));
+        CHK(buf_ensure(h, h->ar_tips[3], h->n_nodes * 8));
+        uint32_t *pend[2] = {(uint32_t *)h->ar_tips[1].p, (uint32_t *)h->ar_tips[2].p};
+        unsigned long long *owner = (unsigned long long *)h->ar_tips[3].p;
         unsigned long long *ctr = (unsigned long long *)(h->d_scalars + 24);
         HIPCHK(h, hipMemsetAsync(ctr, 0, 16, h->stream));
         uint64_t n_pending = 0;  // branch nodes, ascending id
@@ -2378,9 +2381,6 @@ static int remove_tips_impl(dbg *h, const G &g) {
             h->n_pulled = c2[1];
             cur ^= 1;
         }
-        (void)hipFree(pend[0]);
-        (void)hipFree(pend[1]);
-        (void)hipFree(owner);
     }
     h->stats.ms_tips = t.stop();
     h->tipped = true;
