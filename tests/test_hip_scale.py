@@ -252,3 +252,32 @@ def test_reads_beyond_2_gib_use_64bit_stamps():
     code = ((reads[(pos[idx][:, None] + np.arange(k, dtype=np.uint64)[None, :]).astype(np.int64)] >> 1) & 3).astype(np.uint64)
     shifts = (2 * (k - 1 - np.arange(k, dtype=np.uint64))).astype(np.uint64)
     assert np.array_equal((code << shifts[None, :]).sum(axis=1, dtype=np.uint64), keys[idx])
+
+
+def test_per_range_edge_order_and_pull_reads_with_64bit_stamps():
+    """The per-range kernels behind dbg_refine_edge_order / dbg_mark_pull_reads in their 64-bit-stamp form (reads beyond
+    2 GiB): same rank bytes and the same pulled reads as the passes over the reads."""
+    import ctypes as C
+    n, L, k, G = 15_000_000, 150, 31, 75_000_000
+    res = []
+    for streaming in (0, 1):
+        g = _dbg.Graph()
+        g.set_option("refine_streaming", streaming)
+        g.synth_reads(3, G, n, L, 0.004)
+        assert g.sizes()["n_bytes"] >= 1 << 31
+        g.build(k)
+        g.refine_edge_order()
+        nn = g.sizes()["n_nodes"]
+        mc, fs = np.empty(nn, dtype=np.uint8), np.empty(nn, dtype=np.uint8)
+        g._chk(g._lib.dbg_export_orders(g._h, mc.ctypes.data_as(C.c_void_p), fs.ctypes.data_as(C.c_void_p)))
+        order = g.export_dict_order()  # node ids inside a bucket differ from run to run: compare in first-occurrence order
+        mc, fs = mc[order], fs[order]
+        g.prune(2)
+        g.remove_tips()
+        g.mark_pull_reads()
+        sz = g.sizes()
+        res.append((mc, fs, g.export_pull_reads(), sz["n_pull_reads"], sz["n_branch"]))
+        g.close()
+    assert res[0][4] == res[1][4] > 1000 and res[0][3] == res[1][3] > 1000
+    assert np.array_equal(res[0][2], res[1][2])
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
