@@ -92,3 +92,53 @@ def test_lazy_contigs_sequence_protocol():
     assert lazy[-1] == "TTTTT" and lazy[0:2] == ["GG", "ACGT"] and "ACGT" in lazy
     with pytest.raises(IndexError):
         lazy[3]
+
+
+@pytest.mark.parametrize("name", ["peptide_k3_nonfinal", "peptide_k4_nonfinal"])
+def test_views_for_a_generic_alphabet(name):
+    """The same for the generic engine's layout: 5 bits per character, [n][32] count and rank arrays, 0xFF beyond the
+    out-degree."""
+    case = load_golden(name)
+    reads, inp = case_reads(case), case["inputs"]
+    k, thr = inp["k"], inp["threshold"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        V0, E0 = orc.graph_from_reads(list(reads), k)
+        (V, E), pull, branch, pulled, ect = orc.construct_graph(list(reads), k, threshold=thr, final=False)
+    alphabet = "".join(sorted(set("".join(reads))))  # codes in byte order, like dbg_get_alphabet
+    code = {c: i for i, c in enumerate(alphabet)}
+    labels = list(V.keys())
+    n = len(labels)
+    keys = np.zeros(n, dtype=np.uint64)
+    counts = np.zeros((n, 32), dtype=np.uint32)
+    rank_mc = np.full((n, 32), 0xFF, dtype=np.uint8)
+    rank_fs = np.full((n, 32), 0xFF, dtype=np.uint8)
+    keep = np.zeros(n, dtype=np.uint32)
+    flags = np.array([V[v].indegree for v in labels], dtype=np.uint8)
+    pulled_set = set(pulled)
+    for i, lab in enumerate(labels):
+        v = 0
+        for ch in lab:
+            v = (v << 5) | code[ch]
+        keys[i] = v
+        cnt = Counter(E0.get(lab, []))
+        for s, c in cnt.items():
+            counts[i, code[s[-1]]] = c
+        mc = [code[s[-1]] for s, _ in cnt.most_common()]
+        fs = [code[s[-1]] for s in cnt]
+        rank_mc[i, :len(mc)] = mc
+        rank_fs[i, :len(fs)] = fs
+        if lab in pulled_set:
+            flags[i] |= _dbg.F_PULLED
+        else:
+            for s in E[lab]:
+                keep[i] |= 1 << code[s[-1]]
+    take = np.random.default_rng(5).permutation(n)  # table row r holds dict-order node take[r]
+    order = np.argsort(take).astype(np.int64)        # row of dict-order node i (what dbg_export_dict_order returns)
+    store = prod._NodeStore(k, alphabet.encode(), 5, order, keys[take], None, counts[take], rank_mc[take], rank_fs[take],
+                            flags[take], keep[take])
+    Vv, Ev, Cv = prod._LazyVertices(store), prod._LazyEdges(store), prod._LazyEdgeCounts(store)
+    assert list(Vv) == labels
+    assert [(Vv[v].indegree, Vv[v].outdegree) for v in labels] == [(V[v].indegree, V[v].outdegree) for v in labels]
+    assert dict(Ev) == E and list(Ev) == list(E)
+    assert list(Cv.items()) == list(ect.items())
+    assert ("?" * k) not in Vv and (labels[0] + "?") not in Cv
