@@ -68,6 +68,13 @@ struct dbg {
     bool csr_built = false;       // rowptr/col/ecnt already written by k_sk_count
     uint64_t *d_rowptr = nullptr;
     uint32_t *d_col = nullptr, *d_ecnt = nullptr;
+    // engine 0 writes ONE representation in the build: keys, stamps (32-bit while the reads stay below 2 GiB), one byte
+    // per node (indegree | present bases << 1) and the CSR with 32-bit row pointers.  The dense per-base views above
+    // (d_cnt, d_succ, d_order, 64-bit d_stamps / d_rowptr, plain d_flags) are derived by ensure_dense() on first use.
+    bool dense_pending = false;
+    uint32_t *d_rowptr32 = nullptr;
+    void *d_stamps_st = nullptr;
+    int stamps_st_bytes = 0;
 
     // prune / tips
     bool pruned = false, tipped = false;
@@ -119,11 +126,12 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[7], ar_misc[9], ar_csr[3], ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
-    uint64_t sk_n_ranges = 0;
+    uint64_t sk_n_ranges = 0, sk_n_buckets = 0;
+    SkGeom sk_geom{};            // hash -> bucket mapping of the last partitioned build (k_succ_resolve)
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
     bool partial_graph = false;   // the node table is one shard of several: successor ids point into other handles
     // branch k-mer lookup (pull-out reads)
@@ -1442,6 +1450,8 @@ static void free_build(dbg *h) {
     dev_free(h->d_keys); dev_free(h->d_stamps); dev_free(h->d_cnt); dev_free(h->d_flags);
     dev_free(h->d_order); dev_free(h->d_succ); dev_free(h->d_deg);
     h->d_rowptr = nullptr; h->d_col = nullptr; h->d_ecnt = nullptr;  // arena-owned (ar_csr)
+    h->d_rowptr32 = nullptr; h->d_stamps_st = nullptr; h->stamps_st_bytes = 0;
+    h->dense_pending = false;
     h->csr_built = false;
     h->d_pull_rank = nullptr;  // arena-owned (ar_tips)
     dev_free(h->d_read_flags);
@@ -1499,6 +1509,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_node) buf_free(b);
     for (auto &b : h->ar_misc) buf_free(b);
     for (auto &b : h->ar_csr) buf_free(b);
+    buf_free(h->ar_dir);
     for (auto &b : h->ar_shard) buf_free(b);
     for (auto &b : h->ar_walk) buf_free(b);
     for (auto &b : h->ar_wide) buf_free(b);
@@ -1693,6 +1704,39 @@ static int finish_graph(dbg *h) {
         h->stats.ms_csr = t.stop();
     }
     h->starts_known = false;  // counted when first asked for (dbg_get_sizes, dbg_walk): the walk's input, not the build's
+    return DBG_OK;
+}
+
+// Engine 0 builds keys + stamps + CSR only (SkCountOut); the dense per-base views the traversal kernels and the
+// exports read are derived here, once, the first time something asks for them.
+static int ensure_dense(dbg *h) {
+    if (!h->dense_pending) return DBG_OK;
+    const uint64_t n = h->n_nodes, cap = n ? n : 1;
+    CHK(buf_ensure(h, h->ar_node[2], cap * 16));
+    CHK(buf_ensure(h, h->ar_node[4], cap));
+    CHK(buf_ensure(h, h->ar_node[5], cap * 16));
+    CHK(buf_ensure(h, h->ar_csr[0], (cap + 1) * 8));
+    const bool widen = h->stamps_st_bytes == 4;
+    if (widen) CHK(buf_ensure(h, h->ar_node[1], cap * 8));
+    h->d_cnt = (uint32_t *)h->ar_node[2].p;
+    h->d_order = (uint8_t *)h->ar_node[4].p;
+    h->d_succ = (uint32_t *)h->ar_node[5].p;
+    h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
+    if (widen) h->d_stamps = (uint64_t *)h->ar_node[1].p;
+    if (n) {
+        if (widen)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense_from_csr<uint32_t>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n,
+                               (const uint32_t *)h->d_stamps_st, h->d_rowptr32, h->d_col, h->d_ecnt, h->d_flags, h->d_stamps,
+                               h->d_rowptr, h->d_cnt, h->d_succ, h->d_order);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense_from_csr<uint64_t>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream, n,
+                               (const uint64_t *)h->d_stamps_st, h->d_rowptr32, h->d_col, h->d_ecnt, h->d_flags,
+                               (uint64_t *)nullptr, h->d_rowptr, h->d_cnt, h->d_succ, h->d_order);
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_rowptr + n, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->dense_pending = false;
     return DBG_OK;
 }
 
@@ -2136,6 +2180,7 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
     if (!h || !h->k) return DBG_E_ARG;
     if (h->partial_graph) { h->err = kPartialGraph; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     if (h->D == GEN_D) return DBG_OK;  // the generic engine ranks by per-edge first-seen positions at build time
     dev_free(h->d_fsorder);
     CHK(dev_alloc(h, &h->d_fsorder, h->n_nodes));
@@ -2224,6 +2269,7 @@ extern "C" int dbg_refine_edge_order(dbg_t *h) {
 extern "C" int dbg_export_orders(dbg_t *h, uint8_t *order, uint8_t *fsorder) {
     if (!h || !h->k) return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     if (h->D == GEN_D) {  // one byte per rank: [n_nodes][32] successor codes, 0xFF beyond the out-degree
         if (order && h->n_nodes) HIPCHK(h, hipMemcpyAsync(order, h->d_rank_mc, h->n_nodes * GEN_D, hipMemcpyDeviceToHost, h->stream));
         if (fsorder && h->n_nodes) HIPCHK(h, hipMemcpyAsync(fsorder, h->d_rank_fs, h->n_nodes * GEN_D, hipMemcpyDeviceToHost, h->stream));
@@ -2247,6 +2293,7 @@ __global__ __launch_bounds__(256) void k_iota32(uint64_t n, uint32_t *out) {
 extern "C" int dbg_export_dict_order(dbg_t *h, uint32_t *order) {
     if (!h || !h->k || !order) { if (h) h->err = "dbg_build must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     const uint64_t n = h->n_nodes;
     if (!n) return DBG_OK;
     if (n > 0x7FFFFFFFull) { h->err = "too many nodes for one sort"; return DBG_E_CAPACITY; }
@@ -2285,6 +2332,7 @@ __global__ __launch_bounds__(256) void k_keepmask_from_flags(uint64_t n, const u
 extern "C" int dbg_export_keepmask(dbg_t *h, uint32_t *keepmask) {
     if (!h || !h->pruned || !keepmask) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     if (!h->n_nodes) return DBG_OK;
     if (h->D == GEN_D) {
         HIPCHK(h, hipMemcpyAsync(keepmask, h->d_keepmask, h->n_nodes * 4, hipMemcpyDeviceToHost, h->stream));
@@ -2320,6 +2368,7 @@ extern "C" int dbg_prune(dbg_t *h, double threshold) {
     if (threshold == 0.0) { h->err = "threshold must be non-zero (the reference divides by it)"; return DBG_E_ARG; }
     if (h->partial_graph) { h->err = kPartialGraph; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     Timer t(h->stream);
     HIPCHK(h, hipMemsetAsync(h->d_scalars + 16, 0, 8, h->stream));
     if (h->n_nodes && h->D == GEN_D) {
@@ -2393,6 +2442,7 @@ static GDna dna_view(const dbg *h) { return GDna{h->d_keys, h->d_keys_hi, h->d_f
 extern "C" int dbg_remove_tips(dbg_t *h) {
     if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     if (h->D == GEN_D) return remove_tips_impl(h, gen_view(h));
     return remove_tips_impl(h, dna_view(h));
 }
@@ -2400,6 +2450,7 @@ extern "C" int dbg_remove_tips(dbg_t *h) {
 extern "C" int dbg_mark_pull_reads(dbg_t *h) {
     if (!h || !h->pruned) { if (h) h->err = "dbg_prune must run first"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     Timer t(h->stream);
     dev_free(h->d_read_flags);
     CHK(dev_alloc(h, &h->d_read_flags, h->n_reads));
@@ -2673,6 +2724,7 @@ extern "C" int dbg_get_stats(dbg_t *h, dbg_stats_t *o) {
 extern "C" int dbg_export_nodes(dbg_t *h, uint64_t *keys, uint64_t *stamps, uint32_t *counts, uint8_t *flags) {
     if (!h || !h->k) return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     if (keys && !h->d_keys) memset(keys, 0, h->n_nodes * 8);  // k-mers kept by reference (generic alphabet, k >= 12): see stamps
     else D2H(h, keys, h->d_keys, h->n_nodes * 8);
     D2H(h, stamps, h->d_stamps, h->n_nodes * 8);
@@ -2697,6 +2749,7 @@ extern "C" int dbg_export_keys_hi(dbg_t *h, uint64_t *keys_hi) {
 extern "C" int dbg_export_succ(dbg_t *h, uint32_t *succ) {
     if (!h || !h->k) return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     D2H(h, succ, h->d_succ, h->n_nodes * 4 * h->D);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DBG_OK;
@@ -2705,6 +2758,7 @@ extern "C" int dbg_export_succ(dbg_t *h, uint32_t *succ) {
 extern "C" int dbg_export_csr(dbg_t *h, uint64_t *row_ptr, uint32_t *col, uint32_t *cnt) {
     if (!h || !h->k) return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     D2H(h, row_ptr, h->d_rowptr, (h->n_nodes + 1) * 8);
     D2H(h, col, h->d_col, h->n_edges * 4);
     D2H(h, cnt, h->d_ecnt, h->n_edges * 4);
@@ -2846,6 +2900,8 @@ extern "C" int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_byte
 extern "C" int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const void **d_stamps,
                                 const void **d_flags, const void **d_succ) {
     if (!h || !h->k) return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
     if (d_keys) *d_keys = h->d_keys;
     if (d_counts) *d_counts = h->d_cnt;
     if (d_stamps) *d_stamps = h->d_stamps;
@@ -3106,22 +3162,18 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
     auto ensure_node_arrays = [&]() -> int {
         CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
-        CHK(buf_ensure(h, h->ar_node[1], node_cap * 8));
-        CHK(buf_ensure(h, h->ar_node[2], node_cap * 16));
+        CHK(buf_ensure(h, h->ar_node[sizeof(ST) == 8 ? 1 : 7], node_cap * sizeof(ST)));
         CHK(buf_ensure(h, h->ar_node[3], node_cap));
-        CHK(buf_ensure(h, h->ar_node[4], node_cap));
-        CHK(buf_ensure(h, h->ar_node[5], node_cap * 16));
         h->d_keys = (uint64_t *)h->ar_node[0].p;
-        h->d_stamps = (uint64_t *)h->ar_node[1].p;
-        h->d_cnt = (uint32_t *)h->ar_node[2].p;
+        h->d_stamps_st = h->ar_node[sizeof(ST) == 8 ? 1 : 7].p;
+        h->stamps_st_bytes = (int)sizeof(ST);
+        h->d_stamps = sizeof(ST) == 8 ? (uint64_t *)h->d_stamps_st : nullptr;
         h->d_flags = (uint8_t *)h->ar_node[3].p;
-        h->d_order = (uint8_t *)h->ar_node[4].p;
-        h->d_succ = (uint32_t *)h->ar_node[5].p;
         h->nodes_in_arena = true;
-        CHK(buf_ensure(h, h->ar_csr[0], (node_cap + 1) * 8));
+        CHK(buf_ensure(h, h->ar_csr[3], (node_cap + 1) * 4));
         CHK(buf_ensure(h, h->ar_csr[1], edge_cap * 4));
         CHK(buf_ensure(h, h->ar_csr[2], edge_cap * 4));
-        h->d_rowptr = (uint64_t *)h->ar_csr[0].p;
+        h->d_rowptr32 = (uint32_t *)h->ar_csr[3].p;
         h->d_col = (uint32_t *)h->ar_csr[1].p;
         h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
         return DBG_OK;
@@ -3132,22 +3184,25 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     const uint64_t range_cap = n_buckets + 4096 + n_inst / (CAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
+    CHK(buf_ensure(h, h->ar_dir, range_cap * (CAP / 64) * sizeof(SkDirEnt)));
+    SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
     for (int attempt = 0; attempt < 3; ++attempt) {
         CHK(ensure_node_arrays());
         for (int set = 0; set < 2; ++set) {
             CHK(buf_ensure(h, h->ar_q[set][0], q_cap * 8));
-            CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
             CHK(buf_ensure(h, h->ar_q[set][2], q_cap * 4));
+            if (shard_bits) CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
             qk[set] = (uint64_t *)h->ar_q[set][0].p;
             qm[set] = (uint64_t *)h->ar_q[set][1].p;
             qc[set] = (uint32_t *)h->ar_q[set][2].p;
+            if (!shard_bits) break;  // the second set is the owner split's output
         }
         Timer t(h->stream);
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
-        SkCountOut out{h->d_keys, h->d_stamps, h->d_cnt, h->d_flags, h->d_order, h->d_succ, node_cap,
-                       h->d_rowptr, h->d_col, h->d_ecnt, edge_cap, qk[0], qm[0], qc[0], q_cap,
-                       ranges, n_buckets, range_cap, shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev};
+        SkCountOut out{h->d_keys, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
+                       qk[0], qc[0], q_cap, ranges, n_buckets, range_cap, dirs,
+                       shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev};
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3186,26 +3241,28 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
     h->n_nodes = sc[4] & 0xFFFFFFFFull;
     h->n_edges = sc[4] >> 32;
-    HIPCHK(h, hipMemcpyAsync(h->d_rowptr + h->n_nodes, &h->n_edges, 8, hipMemcpyHostToDevice, h->stream));
+    {
+        const uint32_t ne32 = (uint32_t)h->n_edges;
+        HIPCHK(h, hipMemcpyAsync(h->d_rowptr32 + h->n_nodes, &ne32, 4, hipMemcpyHostToDevice, h->stream));
+    }
     h->csr_built = true;
+    h->dense_pending = true;
     uint64_t n_q = sc[5];
     const uint64_t n_ranges = n_buckets + sc[6];
     h->stats.n_queries = n_q;
+    SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, shard_bits, my_shard};
 
-    // ---- K6-K8: successors that live in another bucket (of this shard: answered here; of another
-    //      shard: grouped by owner and parked for the exchange)
+    // ---- K6: successors that live in another bucket.  Of this shard: the asker looks them up through the target
+    //      range's directory (k_succ_resolve).  Of another shard: grouped by owner and parked for the exchange.
     {
         Timer t(h->stream);
-        if (n_q) {
-            hipLaunchKernelGGL(k_q_bucket, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, qk[0], qm[0], n_q, k, m);
-            HIPCHK(h, hipGetLastError());
-        }
-        CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 64 * 16 + 16));
-        uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets;
-        uint64_t *q_seg = q_cnt + n_buckets;  // [0..1]: one input segment; [2..]: per-owner children
         uint64_t root[2] = {0, n_q};
         int qset = 0;
         if (shard_bits && n_q) {  // group by owner shard = top shard_bits of the bucket hash
+            hipLaunchKernelGGL(k_q_bucket, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, qk[0], qm[0], n_q, k, m);
+            HIPCHK(h, hipGetLastError());
+            CHK(buf_ensure(h, h->ar_misc[7], 64 * 16 + 16));
+            uint64_t *q_seg = (uint64_t *)h->ar_misc[7].p;  // [0..1]: one input segment; [2..]: per-owner children
             const int nsh = 1 << shard_bits;
             HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
             uint64_t *o_start = q_seg + 2, *o_cnt = o_start + nsh;
@@ -3218,12 +3275,10 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             HIPCHK(h, hipMemcpyAsync(sh.q_start.data(), o_start, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipMemcpyAsync(sh.q_cnt.data(), o_cnt, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
-            // park everything (keys, metas, CSR positions, grouped by owner) before the local group is shuffled further
+            // park keys and CSR positions (grouped by owner): the exchange reads them, the next build reuses ar_q
             CHK(buf_ensure(h, h->ar_shard[0], n_q * 8));
-            CHK(buf_ensure(h, h->ar_shard[1], n_q * 8));
             CHK(buf_ensure(h, h->ar_shard[3], n_q * 4));
             HIPCHK(h, hipMemcpyAsync(h->ar_shard[0].p, qk[1], n_q * 8, hipMemcpyDeviceToDevice, h->stream));
-            HIPCHK(h, hipMemcpyAsync(h->ar_shard[1].p, qm[1], n_q * 8, hipMemcpyDeviceToDevice, h->stream));
             HIPCHK(h, hipMemcpyAsync(h->ar_shard[3].p, qc[1], n_q * 4, hipMemcpyDeviceToDevice, h->stream));
             root[0] = sh.q_start[my_shard];
             root[1] = sh.q_cnt[my_shard];
@@ -3233,21 +3288,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             qset = 1;
         }
         if (n_q) {
-            HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
-            uint64_t *qk2[2] = {qk[qset], qk[qset ^ 1]}, *qm2[2] = {qm[qset], qm[qset ^ 1]};
-            uint32_t *qc2[2] = {qc[qset], qc[qset ^ 1]};
-            int qwhere = 0;
-            if (T > 0) {
-                CHK((multisplit_two_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, n_q, qk2, qm2, qc2, 40, l1, l2_pow, q_start,
-                                                          q_cnt, &qwhere, fb2 ? nb2 : 0)));
-            } else {
-                HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
-                HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
-            }
-            auto kern = k_q_answer<CAP>;
-            hipLaunchKernelGGL(kern, dim3((unsigned)n_ranges), dim3(256), 0, h->stream, ranges, q_start, q_cnt,
-                               qk2[qwhere], qm2[qwhere], qc2[qwhere], h->d_keys, h->d_succ, h->d_col,
-                               shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_succ_resolve<CAP>), dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream,
+                               qk[qset] + root[0], qc[qset] + root[0], n_q, geom, ranges, n_buckets, n_ranges, dirs, h->d_keys,
+                               h->n_nodes, h->d_col, shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -3257,6 +3300,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     }
     // geometry the answer stage of a sharded build needs again
     h->sk_T = T; h->sk_l1 = l1; h->sk_l2 = l2_pow; h->sk_nb2 = fb2 ? nb2 : 0; h->sk_n_ranges = n_ranges; h->sk_cap = CAP;
+    h->sk_geom = geom; h->sk_n_buckets = n_buckets;
     if (!shard_bits) {
         h->sk_src.w0 = w0[where]; h->sk_src.w1 = w1[where]; h->sk_src.st = st[where]; h->sk_src.st_bytes = (int)sizeof(ST);
         h->sk_src.b_start = b_start; h->sk_src.b_cnt = b_cnt;
@@ -3321,20 +3365,12 @@ __global__ __launch_bounds__(256) void k_stamp_globalize(const uint32_t *__restr
     }
 }
 
-__global__ __launch_bounds__(256) void k_q_prepare(const uint64_t *__restrict__ keys, uint64_t n, int k, int m,
-                                                   uint64_t *meta) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) meta[i] = ((uint64_t)kmer_bucket22(keys[i], k, m) << 40) | i;
-}
-
-__global__ __launch_bounds__(256) void k_apply_remote(const uint64_t *__restrict__ meta, const uint32_t *__restrict__ qcol,
-                                                      const uint32_t *__restrict__ ans, uint64_t n, uint32_t tag,
-                                                      uint32_t *succ, uint32_t *col, unsigned long long *scalars) {
+__global__ __launch_bounds__(256) void k_apply_remote(const uint32_t *__restrict__ qcol, const uint32_t *__restrict__ ans,
+                                                      uint64_t n, uint32_t tag, uint32_t *col, unsigned long long *scalars) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t a = ans[i];
     if (a == NO_NODE || a >= (1u << 29)) { atomicOr(&scalars[0], 256ull); return; }
-    succ[meta[i] & ((1ull << 40) - 1)] = tag | a;
     col[qcol[i]] = tag | a;
 }
 
@@ -3592,36 +3628,14 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     HIPCHK(h, hipSetDevice(h->device));
     if (!n) return DBG_OK;
     unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
-    const int k = h->k, m = sk_m_for_k(k);
-    uint64_t *qk[2], *qm[2];
-    for (int set = 0; set < 2; ++set) {
-        CHK(buf_ensure(h, h->ar_q[set][0], (n + 16) * 8));
-        CHK(buf_ensure(h, h->ar_q[set][1], (n + 16) * 8));
-        qk[set] = (uint64_t *)h->ar_q[set][0].p;
-        qm[set] = (uint64_t *)h->ar_q[set][1].p;
-    }
-    HIPCHK(h, hipMemcpyAsync(qk[0], d_q_keys, n * 8, hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(k_q_prepare, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, qk[0], n, k, m, qm[0]);
     HIPCHK(h, hipMemsetAsync(d_answers, 0xFF, n * 4, h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-    const uint64_t n_buckets = 1ull << h->sk_T;
-    CHK(buf_ensure(h, h->ar_misc[7], n_buckets * 16 + 64 * 16 + 16));
-    uint64_t *q_start = (uint64_t *)h->ar_misc[7].p, *q_cnt = q_start + n_buckets, *q_seg = q_cnt + n_buckets;
-    const uint64_t root[2] = {0, n};
-    HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
-    uint32_t *dummy[2] = {nullptr, nullptr};
-    int qwhere = 0;
-    if (h->sk_T > 0) {
-        CHK((multisplit_two_level<uint32_t, false>(h, q_seg, q_seg + 1, 1, n, qk, qm, dummy, 40, h->sk_l1, h->sk_l2, q_start,
-                                                   q_cnt, &qwhere, h->sk_nb2)));
-    } else {
-        HIPCHK(h, hipMemcpyAsync(q_start, root, 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipMemcpyAsync(q_cnt, root + 1, 8, hipMemcpyHostToDevice, h->stream));
-    }
     const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;
-    auto kern = k_q_answer<4096>;
-    hipLaunchKernelGGL(kern, dim3((unsigned)h->sk_n_ranges), dim3(256), 0, h->stream, ranges, q_start, q_cnt, qk[qwhere],
-                       qm[qwhere], (const uint32_t *)nullptr, h->d_keys, (uint32_t *)d_answers, (uint32_t *)nullptr, 0u, sc_dev);
+    const SkDirEnt *dirs = (const SkDirEnt *)h->ar_dir.p;
+    if (!ranges || !dirs || h->sk_cap != 4096) { h->err = "dbg_shard_build must run first"; return DBG_E_ARG; }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_succ_resolve<4096>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream,
+                       (const uint64_t *)d_q_keys, (const uint32_t *)nullptr, n, h->sk_geom, ranges, h->sk_n_buckets,
+                       h->sk_n_ranges, dirs, h->d_keys, h->n_nodes, (uint32_t *)d_answers, 0u, sc_dev);
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;
     HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -3768,15 +3782,14 @@ extern "C" int dbg_shard_apply(dbg_t *h, const void *d_answers) {
     ShardState &sh = shard_of(h);
     Timer t(h->stream);
     HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-    // local successor ids already carry this shard's tag (k_sk_count / k_q_answer wrote them tagged)
-    const uint64_t *meta = (const uint64_t *)h->ar_shard[1].p;
+    // local successor ids already carry this shard's tag (k_sk_count / k_succ_resolve wrote them tagged)
     const uint32_t *qcol = (const uint32_t *)h->ar_shard[3].p;
     for (int d = 0; d < sh.n_shards; ++d) {
         if (d == sh.my_shard || !sh.q_cnt[d]) continue;
         if (!d_answers) { h->err = "answers missing"; return DBG_E_ARG; }
-        hipLaunchKernelGGL(k_apply_remote, dim3(grid_for(sh.q_cnt[d], 256)), dim3(256), 0, h->stream, meta + sh.q_start[d],
-                           qcol + sh.q_start[d], (const uint32_t *)d_answers + sh.q_start[d], sh.q_cnt[d],
-                           (uint32_t)d << 29, h->d_succ, h->d_col, (unsigned long long *)h->d_scalars);
+        hipLaunchKernelGGL(k_apply_remote, dim3(grid_for(sh.q_cnt[d], 256)), dim3(256), 0, h->stream, qcol + sh.q_start[d],
+                           (const uint32_t *)d_answers + sh.q_start[d], sh.q_cnt[d], (uint32_t)d << 29, h->d_col,
+                           (unsigned long long *)h->d_scalars);
     }
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;

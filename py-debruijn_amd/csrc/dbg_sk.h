@@ -672,7 +672,9 @@ struct CntLds {
     uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
     int stk_n;
     uint32_t overflow, n_local /* nodes | edges << 16 while the list is built */, n_q, fail, n_flat;
-    unsigned long long gbase, qbase, ebase;
+    unsigned long long gbase, qbase, ebase, ri;
+    unsigned long long dir_mask[CAP / 64];  // occupancy of every 64-slot block of the final table
+    uint16_t dir_base[CAP / 64];            // local node index of the block's first node
 };
 
 // k-mer i of a record: 32-base window starting at base i (first base in bits 63:62)
@@ -692,21 +694,36 @@ __device__ inline int lds_find(const unsigned long long *keys, uint64_t key) {
     return -1;
 }
 
+// Directory of one counted range: per 64-slot block of its LDS table the occupancy mask and the node id of the
+// block's first node.  The nodes of a block are written in slot order, so (mask, base) turn a slot into a node id and
+// k_succ_resolve can repeat the table's linear probing against the node keys in HBM -- a successor that lives in
+// another bucket costs the asker two dependent reads instead of a trip through a multisplit of all such queries.
+struct SkDirEnt {
+    unsigned long long mask;
+    uint32_t base;
+    uint32_t pad;
+};
+static_assert(sizeof(SkDirEnt) == 16, "directory entry");
+
+// What the count kernel writes: the graph in ONE representation -- node keys, first-occurrence stamps, one byte per
+// node (indegree flag | bases that occur << 1) and the CSR rows (rowptr, successor id, count).  The dense per-base views
+// (counts[n][4], succ[n][4], rank bytes) that the traversal kernels read are derived from it on first use
+// (k_dense_from_csr): writing both cost 2.7x the bytes and a third of the kernel's vector instructions.
 struct SkCountOut {
-    uint64_t *keys, *stamps;
-    uint32_t *cnt;
-    uint8_t *flags, *order;
-    uint32_t *succ;
+    uint64_t *keys;
+    void *stamps;              // ST[node_cap]
+    uint8_t *flags;            // (stamp & 1) | present-base mask << 1
     uint64_t node_cap;
-    uint64_t *rowptr;          // CSR: first edge of every node
-    uint32_t *col, *ecnt;      // CSR: successor id (NO_NODE until k_q_answer fills a cross-bucket one), count
+    uint32_t *rowptr;          // CSR: first edge of every node (edges < 2^32 - 16 is enforced)
+    uint32_t *col, *ecnt;      // CSR: successor id (NO_NODE until k_succ_resolve fills a cross-bucket one), count
     uint64_t edge_cap;
-    uint64_t *q_key, *q_meta;  // cross-bucket successors: k-mer, bucket << 40 | dense succ slot
+    uint64_t *q_key;           // cross-bucket successors: the successor k-mer ...
     uint32_t *q_col;           // ... and the CSR position to patch
     uint64_t q_cap;
     SkRange *ranges;        // [0, n_buckets): the unsplit range of each bucket; beyond: ranges of split buckets
     uint64_t n_buckets;
     uint64_t range_cap;
+    SkDirEnt *dirs;            // [range_cap][CAP / 64]
     uint32_t id_tag;           // OR-ed into every successor id written (sharded builds: owner << 29)
     unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | edges (high 32) [5] queries [6] extra ranges
 };
@@ -949,6 +966,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     deg = (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
                 }
                 const unsigned long long mask = __ballot(occ);
+                if ((threadIdx.x & 63) == 0) s.dir_mask[i >> 6] = mask;
                 if (mask) {
                     // exclusive prefix of deg (0..4) over the wave: four ballots, no cross-lane scan
                     uint32_t eexc = 0, etot = 0;
@@ -961,6 +979,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     uint32_t base = 0;
                     if ((threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
                     base = __builtin_amdgcn_readfirstlane(base);
+                    if ((threadIdx.x & 63) == 0) s.dir_base[i >> 6] = (uint16_t)base;
                     if (occ) {
                         const uint32_t li = (base & 0xFFFFu) + lanes_below(mask);
                         s.idx[i] = (uint16_t)li;
@@ -1011,9 +1030,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     unsigned long long code;
                     if (qi < CNT_QBUF) {
                         s.q_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
-                        // local dense slot (li*4+b) in bits 0..15, bucket-relative CSR column in bits 16..31
-                        s.q_meta[qi] = ((unsigned long long)li * 4 + b) |
-                                       ((unsigned long long)(s.eoff[li] + __popc(nz_all & ((1u << b) - 1u))) << 16);
+                        s.q_meta[qi] = s.eoff[li] + __popc(nz_all & ((1u << b) - 1u));  // bucket-relative CSR column
                         code = 0xFFFEull;
                     } else {
                         code = 0x8000ull | (qi - CNT_QBUF);
@@ -1036,6 +1053,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     ri = orr.n_buckets + atomicAdd(&orr.scalars[6], 1ull);
                     if (ri >= orr.range_cap) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
                 }
+                s.ri = ri;
                 if (!s.fail) {
                     SkRange rg;
                     rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
@@ -1055,6 +1073,13 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             const auto &ow = *fresh_args(outp);  // loaded here, not kept in SGPRs across the whole bucket loop
             // ---- write nodes and their CSR rows: consecutive lanes -> consecutive nodes; every slot read is
             //      cleared for the next bucket
+            if (threadIdx.x < CAP / 64) {  // the range's directory (k_succ_resolve)
+                SkDirEnt de;
+                de.mask = s.dir_mask[threadIdx.x];
+                de.base = (uint32_t)(gbase + s.dir_base[threadIdx.x]);
+                de.pad = 0;
+                ow.dirs[s.ri * (CAP / 64) + threadIdx.x] = de;
+            }
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
                 if ((uint32_t)(u * CNT_NT) >= n_local) break;
@@ -1065,39 +1090,25 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 const uint64_t node = gbase + li;
                 const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
                 const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-                const uint64_t stamp = (uint64_t)s.stamp[i];
+                const ST stamp = s.stamp[i];
                 s.keys[i] = EMPTY_KEY;
                 s.stamp[i] = (ST)~(ST)0;
                 reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
                 ow.keys[node] = key;
-                ow.stamps[node] = stamp;
-                reinterpret_cast<uint4 *>(ow.cnt)[node] = c4;
-                ow.flags[node] = (uint8_t)(stamp & 1);
-                // rank of every code by (count descending, ASCII order A C G T = codes 0 1 3 2 ascending): six
-                // pair comparisons, no data-dependent register indexing (the insertion sort compiled to ~80 selects)
-                uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-                { const uint32_t f = c[0] >= c[1]; r1 += f; r0 += 1u - f; }
-                { const uint32_t f = c[0] >= c[3]; r3 += f; r0 += 1u - f; }
-                { const uint32_t f = c[0] >= c[2]; r2 += f; r0 += 1u - f; }
-                { const uint32_t f = c[1] >= c[3]; r3 += f; r1 += 1u - f; }
-                { const uint32_t f = c[1] >= c[2]; r2 += f; r1 += 1u - f; }
-                { const uint32_t f = c[3] >= c[2]; r2 += f; r3 += 1u - f; }
-                (void)r0;  // code 0 contributes no bits wherever it ranks
-                ow.order[node] = (uint8_t)((1u << (2 * r1)) | (2u << (2 * r2)) | (3u << (2 * r3)));
-                uint32_t sc[4];
+                reinterpret_cast<ST *>(ow.stamps)[node] = stamp;
+                ow.flags[node] = (uint8_t)((uint32_t)(stamp & 1) | ((c[0] != 0) << 1) | ((c[1] != 0) << 2) | ((c[2] != 0) << 3) |
+                                           ((c[3] != 0) << 4));
                 uint64_t e = ebase + s.eoff[li];
-                ow.rowptr[node] = e;
+                ow.rowptr[node] = (uint32_t)e;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
-                    sc[b] = v < 0x8000u ? ((uint32_t)(gbase + v) | ow.id_tag) : NO_NODE;
                     if (c[b]) {
-                        ow.col[e] = sc[b];
+                        const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
+                        ow.col[e] = v < 0x8000u ? ((uint32_t)(gbase + v) | ow.id_tag) : NO_NODE;
                         ow.ecnt[e] = c[b];
                         ++e;
                     }
                 }
-                reinterpret_cast<uint4 *>(ow.succ)[node] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
             }
             // ---- queries out (the cursor has had the whole node pass to come back)
             if (threadIdx.x == 64 && nq) {
@@ -1110,10 +1121,8 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 const auto &oq = *fresh_args(outp);
                 const uint64_t qbase = s.qbase;
                 for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)CNT_QBUF); i += CNT_NT) {
-                    const unsigned long long meta = s.q_meta[i];
                     oq.q_key[qbase + i] = s.q_key[i];
-                    oq.q_meta[qbase + i] = (meta & ~0xFFFFFFFFull) | ((meta & 0xFFFFull) + gbase * 4);
-                    oq.q_col[qbase + i] = (uint32_t)(ebase + ((meta >> 16) & 0xFFFFull));
+                    oq.q_col[qbase + i] = (uint32_t)(ebase + s.q_meta[i]);
                 }
                 if (nq > (uint32_t)CNT_QBUF) {  // rare: queries that did not fit the staging, straight from the registers
 #pragma unroll
@@ -1129,7 +1138,6 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                                 const uint64_t node = gbase + li;
                                 const uint64_t skey = ((oq.keys[node] << 2) | (uint64_t)b) & kmask;
                                 oq.q_key[qbase + qi] = skey;
-                                oq.q_meta[qbase + qi] = node * 4 + b;
                                 oq.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
                             }
                             if (v != 0xFFFFu) ++rank;  // every base that occurs owns one CSR column
@@ -1144,83 +1152,121 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
     }
 }
 
-// target bucket of every cross-bucket query: bits 40.. of q_meta (what the query multisplit sorts by)
+// ------------------------------------------------------------------------------------------------
+// K6: successors that live in another bucket, resolved by the asker.
+// ------------------------------------------------------------------------------------------------
+// How the 22-bit bucket hash of a minimizer maps to a bucket index (the two multisplit levels of the build).
+struct SkGeom {
+    int k, m;
+    int l1;       // level 1: top l1 bits of the hash
+    int nb2;      // children of level 2 (1: no second level)
+    int fb2;      // != 0: level 2 scales the fb2 low bits of the hash into [0, nb2); 0: plain bit field of l2_pow bits
+    int l2_pow;
+    int shard_bits, my_shard;  // sharded builds: owner = top shard_bits of the hash
+};
+
+__host__ __device__ inline uint64_t sk_bucket_of(uint32_t bh, const SkGeom &g) {
+    const uint32_t b1 = g.l1 ? bh >> (SK_BUCKET_BITS - g.l1) : 0u;
+    if (g.nb2 <= 1) return b1;
+    uint32_t b2;
+    if (g.fb2) b2 = (uint32_t)(((uint64_t)(bh & ((1u << g.fb2) - 1u)) * (uint32_t)g.nb2) >> g.fb2);
+    else b2 = (bh >> (SK_BUCKET_BITS - g.l1 - g.l2_pow)) & (uint32_t)(g.nb2 - 1);
+    return (uint64_t)b1 * (uint32_t)g.nb2 + b2;
+}
+
+// sort key of the owner split of a sharded build: bucket hash of every query in bits 40.. of q_meta
 __global__ __launch_bounds__(256) void k_q_bucket(const uint64_t *__restrict__ q_key, uint64_t *q_meta, uint64_t n, int k, int m) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) q_meta[i] = (q_meta[i] & ((1ull << 40) - 1)) | ((uint64_t)kmer_bucket22(q_key[i], k, m) << 40);
+    if (i < n) q_meta[i] = ((uint64_t)kmer_bucket22(q_key[i], k, m) << 40) | i;
+}
+
+// Node id of k-mer `key` in the counted range `ri`: the table's linear probing, replayed on the directory.  A key
+// sits at or after its home slot with every slot in between occupied, and the nodes of a 64-slot block are stored
+// in slot order from dir.base on -- so the probe is one directory entry (16 bytes) and a run of consecutive keys.
+template <int CAP>
+__device__ inline uint32_t dir_find(const SkDirEnt *__restrict__ dirs, uint64_t ri, const uint64_t *__restrict__ keys,
+                                    uint64_t n_nodes, uint64_t key) {
+    constexpr int NBLK = CAP / 64;
+    uint32_t slot = slot_of<CAP>(key);
+    for (int blocks = 0; blocks <= NBLK; ++blocks) {
+        const SkDirEnt de = dirs[ri * NBLK + (slot >> 6)];
+        const int bit = (int)(slot & 63);
+        const unsigned long long run_bits = de.mask >> bit;
+        if (!(run_bits & 1ull)) return NO_NODE;
+        const int avail = 64 - bit;
+        const int run = (~run_bits) ? min(avail, __ffsll((unsigned long long)~run_bits) - 1) : avail;
+        const uint64_t idx = (uint64_t)de.base + (uint64_t)__popcll(de.mask & ((1ull << bit) - 1ull));
+        if (idx + run > n_nodes) return NO_NODE;
+        for (int t = 0; t < run; ++t)
+            if (keys[idx + t] == key) return (uint32_t)(idx + t);
+        if (run < avail) return NO_NODE;  // an empty slot ends the probe run
+        slot = (slot + (uint32_t)run) & (CAP - 1);
+    }
+    return NO_NODE;
+}
+
+// out[q_col ? q_col[i] : i] = node id of q_key[i] (| id_tag).  One thread per query.
+template <int CAP>
+__global__ __launch_bounds__(256) void k_succ_resolve(const uint64_t *__restrict__ q_key, const uint32_t *__restrict__ q_col,
+                                                      uint64_t n, SkGeom g, const SkRange *__restrict__ ranges,
+                                                      uint64_t n_buckets, uint64_t n_ranges,
+                                                      const SkDirEnt *__restrict__ dirs, const uint64_t *__restrict__ keys,
+                                                      uint64_t n_nodes, uint32_t *out, uint32_t id_tag,
+                                                      unsigned long long *scalars) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = q_key[i];
+    const uint64_t bucket = sk_bucket_of(kmer_bucket22(key, g.k, g.m), g);
+    uint32_t id = NO_NODE;
+    if (bucket < n_buckets) {
+        uint64_t ri = bucket;
+        bool have = ranges[bucket].node_cnt != 0;
+        if (!have) {  // the bucket overflowed its table and was counted in hash sub-ranges (rare): find the one of this key
+            const uint32_t sh = sub_hash(key);
+            for (uint64_t r = n_buckets; r < n_ranges && !have; ++r) {
+                const SkRange rg = ranges[r];
+                if (rg.bucket == (uint32_t)bucket && rg.node_cnt && (sh & rg.mask) == rg.val) { ri = r; have = true; }
+            }
+        }
+        if (have) id = dir_find<CAP>(dirs, ri, keys, n_nodes, key);
+    }
+    if (id == NO_NODE) { atomicOr(&scalars[0], 128ull); return; }  // every successor k-mer exists as a node
+    out[q_col ? q_col[i] : i] = id | id_tag;
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8: answer the cross-bucket successor queries of one counted range
+// Dense per-base views of the CSR the count kernel wrote (first use by a traversal kernel or an export)
 // ------------------------------------------------------------------------------------------------
-// The LDS table holds the QUERIES of the range's bucket (about a tenth of its node count) and the range's
-// node keys stream past it: a node that nobody asks for costs one LDS read (its home slot is empty), the
-// table is 10 KB instead of 40 KB (8 workgroups per CU instead of 4: this kernel is a chain of dependent
-// global loads, occupancy is what hides them) and there is no 4096-slot clear per range.
-constexpr int ANS_SLOTS = 1024;  // query slots per pass
-constexpr int ANS_CHUNK = 512;   // queries per pass: the table stays at most half full, probes always end
-struct AnsLds {
-    unsigned long long keys[ANS_SLOTS];
-    uint16_t qi[ANS_SLOTS];  // slot -> query index within the pass (equal keys take separate slots)
-    uint32_t n_want, n_hit;
-};
-
-template <int CAP /* table size of the count kernel: not used here */>
-__global__ __launch_bounds__(256) void k_q_answer(const SkRange *__restrict__ ranges, const uint64_t *__restrict__ q_start,
-                                                  const uint64_t *__restrict__ q_cnt, const uint64_t *__restrict__ q_key,
-                                                  const uint64_t *__restrict__ q_meta, const uint32_t *__restrict__ q_col,
-                                                  const uint64_t *__restrict__ keys, uint32_t *succ, uint32_t *col,
-                                                  uint32_t id_tag, unsigned long long *scalars) {
-    __shared__ AnsLds s;
-    const SkRange rg = ranges[blockIdx.x];
-    if (rg.node_cnt == 0) return;  // bucket that was empty or was split into sub-ranges
-    const uint64_t qn = q_cnt[rg.bucket];
-    if (qn == 0) return;
-    const uint64_t qb = q_start[rg.bucket];
-    for (uint64_t c0 = 0; c0 < qn; c0 += ANS_CHUNK) {
-        const uint32_t nc = (uint32_t)min((uint64_t)ANS_CHUNK, qn - c0);
-        __syncthreads();  // the previous pass is done with the table
-        for (int i = threadIdx.x; i < ANS_SLOTS; i += 256) s.keys[i] = EMPTY_KEY;
-        if (threadIdx.x == 0) { s.n_want = 0; s.n_hit = 0; }
-        __syncthreads();
-        for (uint32_t i0 = 0; i0 < nc; i0 += 256) {  // uniform trip count
-            const uint32_t i = i0 + threadIdx.x;
-            unsigned long long skey = 0;
-            bool mine = i < nc;
-            if (mine) {
-                skey = q_key[qb + c0 + i];
-                if (rg.mask && (sub_hash(skey) & rg.mask) != rg.val) mine = false;  // another sub-range of the bucket
-            }
-            const unsigned long long m = __ballot(mine);
-            if (m && lanes_below(m) == 0 && mine) atomicAdd(&s.n_want, (uint32_t)__popcll(m));
-            if (mine) {
-                uint32_t slot = slot_hash(skey) >> 22;
-                while (atomicCAS(&s.keys[slot], EMPTY_KEY, skey) != EMPTY_KEY) slot = (slot + 1) & (ANS_SLOTS - 1);
-                s.qi[slot] = (uint16_t)i;
-            }
-        }
-        __syncthreads();
-        if (s.n_want) {  // uniform
-            for (uint32_t j = threadIdx.x; j < rg.node_cnt; j += 256) {
-                const unsigned long long key = keys[rg.node_base + j];
-                uint32_t slot = slot_hash(key) >> 22;
-                for (;;) {
-                    const unsigned long long cur = s.keys[slot];
-                    if (cur == EMPTY_KEY) break;
-                    if (cur == key) {  // every query for this k-mer sits in the same probe run
-                        const uint64_t q = qb + c0 + s.qi[slot];
-                        const uint32_t id = (uint32_t)(rg.node_base + j) | id_tag;
-                        succ[q_meta[q] & ((1ull << 40) - 1)] = id;
-                        if (col) col[q_col[q]] = id;
-                        atomicAdd(&s.n_hit, 1u);
-                    }
-                    slot = (slot + 1) & (ANS_SLOTS - 1);
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0 && s.n_hit != s.n_want) atomicOr(&scalars[0], 128ull);  // every successor exists as a node
+template <class ST>
+__global__ __launch_bounds__(256) void k_dense_from_csr(uint64_t n_nodes, const ST *__restrict__ stamps_in,
+                                                        const uint32_t *__restrict__ rowptr32, const uint32_t *__restrict__ col,
+                                                        const uint32_t *__restrict__ ecnt, uint8_t *flags, uint64_t *stamps64,
+                                                        uint64_t *rowptr64, uint32_t *cnt, uint32_t *succ, uint8_t *order) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const uint32_t f = flags[i];
+    uint32_t e = rowptr32[i];
+    uint32_t c[4], sc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        c[b] = 0;
+        sc[b] = NO_NODE;
+        if ((f >> (1 + b)) & 1u) { c[b] = ecnt[e]; sc[b] = col[e]; ++e; }
     }
+    reinterpret_cast<uint4 *>(cnt)[i] = make_uint4(c[0], c[1], c[2], c[3]);
+    reinterpret_cast<uint4 *>(succ)[i] = make_uint4(sc[0], sc[1], sc[2], sc[3]);
+    flags[i] = (uint8_t)(f & 1u);
+    if (stamps64) stamps64[i] = (uint64_t)stamps_in[i];
+    rowptr64[i] = rowptr32[i];
+    // rank of every code by (count descending, ASCII order A C G T = codes 0 1 3 2 ascending): six pair comparisons
+    uint32_t r1 = 0, r2 = 0, r3 = 0;
+    { const uint32_t q = c[0] >= c[1]; r1 += q; }
+    { const uint32_t q = c[0] >= c[3]; r3 += q; }
+    { const uint32_t q = c[0] >= c[2]; r2 += q; }
+    { const uint32_t q = c[1] >= c[3]; r3 += q; r1 += 1u - q; }
+    { const uint32_t q = c[1] >= c[2]; r2 += q; r1 += 1u - q; }
+    { const uint32_t q = c[3] >= c[2]; r2 += q; r3 += 1u - q; }
+    order[i] = (uint8_t)((1u << (2 * r1)) | (2u << (2 * r2)) | (3u << (2 * r3)));
 }
 
 }  // namespace dbgk
