@@ -45,7 +45,7 @@ typedef struct dbg dbg_t;
 #define DBG_E_CAPACITY (-4) /* hash table or an output limit was exceeded */
 #define DBG_E_NOMEM (-5)    /* host or device allocation failed */
 
-#define DBG_ABI_VERSION 1
+#define DBG_ABI_VERSION 2
 
 /* node flag bits (dbg_export_nodes: flags[]) */
 #define DBG_F_INDEG 0x01u    /* Node.indegree (0 or 1), debruijn.py:134,141-142 */
@@ -219,13 +219,19 @@ int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const
  * st uint32); send_counts[n_shards] records go to each owner, contiguous and in owner order */
 int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
                       const void **d_st);
+/* records per level-1 bucket (the 512 top-9-bit groups of the bucket hash) of the last dbg_shard_extract, k <= 31:
+ * owner d holds the buckets [d * 512 / n_shards, (d + 1) * 512 / n_shards), in order, so send_counts[d] is their sum */
+int dbg_shard_bucket_counts(dbg_t *h, uint64_t *counts512);
 /* step 2: records received from rank r are recv_counts[r] consecutive entries (rank order);
  * stamp_base[r] = bytes of reads held by ranks < r.  Builds the shard's node table.  Successor
  * k-mers owned by other shards: device array *d_q_keys (uint64), group of owner d at
- * [q_starts[d], q_starts[d] + q_counts[d]) */
+ * [q_starts[d], q_starts[d] + q_counts[d]).
+ * sender_bucket_counts: NULL, or [n_shards][512 / n_shards] -- for every sender its dbg_shard_bucket_counts entries of
+ * the buckets THIS shard owns.  With it the receiver skips the first multisplit level (the senders did it before the
+ * exchange) and rebases the stamps inside the second one. */
 int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w0, const void *d_w1, const void *d_st32,
                     const uint64_t *recv_counts, const uint64_t *stamp_base, uint64_t *q_starts, uint64_t *q_counts,
-                    const void **d_q_keys);
+                    const void **d_q_keys, const uint64_t *sender_bucket_counts);
 /* step 3: node ids (uint32, device) of n successor k-mers other ranks asked this shard about */
 int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void *d_answers);
 /* step 4: d_answers (uint32, device) laid out like *d_q_keys of step 2; completes successors + CSR */

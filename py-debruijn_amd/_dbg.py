@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DBG_LIB") or os.path.join(_HERE, "libdbg_hip.so")  # 
 DBG_OK, DBG_E_ARG, DBG_E_HIP, DBG_E_ALPHABET, DBG_E_CAPACITY, DBG_E_NOMEM = 0, -1, -2, -3, -4, -5
 F_INDEG, F_KEEP_MASK, F_KEEP_SHIFT, F_BRANCH, F_PULLED = 0x01, 0x1E, 1, 0x20, 0x40
 NO_NODE = 0xFFFFFFFF
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
@@ -29,7 +29,7 @@ SYMBOLS = (
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_keys_hi",
     "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
-    "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
+    "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
 )
 
@@ -115,7 +115,8 @@ def load_library():
         "dbg_export_contig_text": (C.c_int, [H, C.c_uint64, vp, C.c_uint64]),
         "dbg_device_views": (C.c_int, [H] + [C.POINTER(vp)] * 5),
         "dbg_shard_extract": (C.c_int, [H, C.c_int, C.c_int, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
-        "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp)]),
+        "dbg_shard_bucket_counts": (C.c_int, [H, u64p]),
+        "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_shard_apply": (C.c_int, [H, vp]),
         "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp, vp]),
@@ -366,16 +367,29 @@ class Graph:
     def sizes_device(self):
         return getattr(self, "_device_index", default_device())
 
-    def shard_build(self, k, n_shards, my_shard, w0, w1, st, recv_counts, stamp_base):
-        """Received records (torch tensors) -> (q_starts, q_counts, query key tensor grouped by owner)."""
+    def shard_bucket_counts(self):
+        """Records per level-1 bucket (512) of the last shard_extract (k <= 31): owners are contiguous ranges of them."""
+        out = (C.c_uint64 * 512)()
+        self._chk(self._lib.dbg_shard_bucket_counts(self._h, out))
+        return [int(x) for x in out]
+
+    def shard_build(self, k, n_shards, my_shard, w0, w1, st, recv_counts, stamp_base, sender_bucket_counts=None):
+        """Received records (torch tensors) -> (q_starts, q_counts, query key tensor grouped by owner).
+        sender_bucket_counts[r] = sender r's record counts for the 512 / n_shards level-1 buckets this shard owns
+        (from its shard_bucket_counts): the build then starts at the second multisplit level."""
         rc = (C.c_uint64 * n_shards)(*[int(x) for x in recv_counts])
         sb = (C.c_uint64 * n_shards)(*[int(x) for x in stamp_base])
         qs, qc = (C.c_uint64 * n_shards)(), (C.c_uint64 * n_shards)()
         pk = C.c_void_p()
+        sbc = None
+        if sender_bucket_counts is not None and int(k) <= 31:
+            flat = [int(x) for row in sender_bucket_counts for x in row]
+            assert len(flat) == 512, "one count per (sender, owned level-1 bucket)"
+            sbc = (C.c_uint64 * 512)(*flat)
         self._keep = [w0, w1, st]
         self._chk(self._lib.dbg_shard_build(self._h, int(k), int(n_shards), int(my_shard), C.c_void_p(w0.data_ptr()),
                                             C.c_void_p(w1.data_ptr()), C.c_void_p(st.data_ptr()), rc, sb, qs, qc,
-                                            C.byref(pk)))
+                                            C.byref(pk), sbc))
         self._keep = []
         qs, qc = [int(x) for x in qs], [int(x) for x in qc]
         total = max([a + b for a, b in zip(qs, qc)] + [0])

@@ -147,6 +147,7 @@ struct ShardState {
     std::vector<uint64_t> q_start, q_cnt;   // remote queries grouped by owner (own group: count 0)
     uint64_t n_remote = 0;
     uint64_t n_kmer_inst_local = 0;          // k-mer instances of the reads this rank extracted
+    std::vector<uint64_t> l1_counts;         // records per level-1 bucket (512) of the last dbg_shard_extract
 };
 static ShardState &shard_of(dbg *h);
 
@@ -2882,6 +2883,14 @@ extern "C" int dbg_debug_ms_prof(unsigned long long *out8, int reset) {  // expe
 }
 #endif
 
+#ifdef DBG_CNT_PROF
+extern "C" int dbg_debug_cnt_prof(unsigned long long *out32, int reset) {  // experiment builds only (tools/cnt_prof.py)
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(dbgk::g_cnt_prof), 256) != hipSuccess) return DBG_E_HIP;
+    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dbgk::g_cnt_prof), z, 256) != hipSuccess) return DBG_E_HIP; }
+    return DBG_OK;
+}
+#endif
+
 extern "C" int dbg_device_keys_hi(dbg_t *h, const void **d_keys_hi) {
     if (!h || !h->k || !d_keys_hi) return DBG_E_ARG;
     *d_keys_hi = h->d_keys_hi;
@@ -2921,78 +2930,47 @@ struct CeilDiv {
 
 // One multisplit level: segments (p_start/p_cnt, device) -> children (c_start/c_cnt, device,
 // n_groups * nb entries), records moved from in_* to out_*.
-template <class ST, bool HAS_ST>
-static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_cnt, uint32_t n_seg, bool one_group,
-                            uint64_t total, const uint64_t *in_w0, const uint64_t *in_w1, const ST *in_st,
+template <class ST, bool HAS_ST, class STI = ST>
+static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_cnt, uint32_t n_seg, uint32_t spg,
+                            uint64_t total, const uint64_t *in_w0, const uint64_t *in_w1, const STI *in_st,
                             uint64_t *out_w0, uint64_t *out_w1, ST *out_st, int shift, int nb, uint64_t *c_start,
-                            uint64_t *c_cnt, dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs, int fbits = 0) {
+                            uint64_t *c_cnt, dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs, int fbits = 0,
+                            const uint64_t *seg_add = nullptr, unsigned long long *d_sums = nullptr) {
+    // spg: segments per group (n_seg: all segments form one group; 1: every segment is its own group)
     CHK(buf_ensure(h, b_scpre, (uint64_t)(n_seg + 1) * 8));
     uint64_t *sc_pre = (uint64_t *)b_scpre.p;
     uint64_t nsc = 0;
     CHK(exclusive_scan(h, n_seg, CeilDiv{p_cnt, (uint64_t)MS_SC}, sc_pre, &nsc));
     HIPCHK(h, hipMemcpyAsync(sc_pre + n_seg, &nsc, 8, hipMemcpyHostToDevice, h->stream));
-    MsParents P{p_start, p_cnt, sc_pre, n_seg, one_group ? 1u : 0u};
+    MsParents P{p_start, p_cnt, sc_pre, n_seg, spg};
     const uint64_t n_log = nsc * (uint64_t)nb;
     CHK(buf_ensure(h, b_cmat, n_log * 4));
     CHK(buf_ensure(h, b_offs, n_log * 8));
     uint32_t *cmat = (uint32_t *)b_cmat.p;
     uint64_t *offs = (uint64_t *)b_offs.p;
     if (nsc) {
-        hipLaunchKernelGGL(k_ms_hist, dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb, fbits, cmat);
+        if (d_sums)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ms_hist<true>), dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb,
+                               fbits, cmat, d_sums);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ms_hist<false>), dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb,
+                               fbits, cmat, (unsigned long long *)nullptr);
         HIPCHK(h, hipGetLastError());
         uint64_t tot = 0;
         CHK(exclusive_scan(h, n_log, MsLogical{P, cmat, nb}, offs, &tot));
         if (tot != total) { h->err = "multisplit: histogram total mismatch"; return DBG_E_HIP; }
     }
-    const uint64_t n_child = (uint64_t)(one_group ? 1 : n_seg) * nb;
+    const uint64_t n_child = (uint64_t)(n_seg / spg) * nb;
     hipLaunchKernelGGL(k_ms_children, dim3(grid_for(n_child, 256)), dim3(256), 0, h->stream, P, offs, nb, total, c_start,
                        c_cnt);
     if (nsc) {
-        auto kern = k_ms_scatter<ST, HAS_ST>;
+        auto kern = k_ms_scatter<ST, HAS_ST, STI>;
         const size_t lds = sizeof(MsLds<ST>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(MS_NT), lds, h->stream, P, in_w0, in_w1, in_st, shift, nb, fbits, offs,
-                           out_w0, out_w1, out_st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nsc), dim3(MS_NT), lds, h->stream, P, in_w0, in_w1, in_st, seg_add, shift, nb,
+                           fbits, offs, out_w0, out_w1, out_st);
     }
     HIPCHK(h, hipGetLastError());
-    return DBG_OK;
-}
-
-// Two-level split of the records in the given segments by the top (l1 + l2) bits of the 22-bit
-// bucket hash that sits at bit `field_lo` of w1.  Level 1 always runs (with l1 == 0 it only
-// compacts the segments into one range).  On return the records are in set `*where` of the
-// ping-pong buffers and final_start/final_cnt (2^(l1+l2) entries) describe the buckets.
-template <class ST, bool HAS_ST>
-static int multisplit_two_level(dbg *h, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
-                                uint64_t total, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], int field_lo, int l1,
-                                int l2, uint64_t *final_start, uint64_t *final_cnt, int *where, int nb2 = 0) {
-    // nb2 > 0: the second level has nb2 children (any number up to 1024) taken from ALL the hash bits below level 1
-    int cur = 0;
-    const int top = field_lo + SK_BUCKET_BITS;
-    const int nb1 = 1 << l1;
-    uint64_t *cs, *cc;
-    if (nb2 > 0) l2 = 1;
-    if (l2 > 0) {
-        CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
-        cs = (uint64_t *)h->ar_misc[1].p;
-        cc = cs + nb1;
-    } else {
-        cs = final_start;
-        cc = final_cnt;
-    }
-    CHK((multisplit_level<ST, HAS_ST>(h, seg_start, seg_cnt, n_seg, true, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
-                                       w1[cur ^ 1], st[cur ^ 1], top - l1, nb1, cs, cc, h->ar_misc[2], h->ar_misc[3],
-                                       h->ar_misc[4])));
-    cur ^= 1;
-    if (l2 > 0) {
-        const int fb = nb2 > 0 ? SK_BUCKET_BITS - l1 : 0;
-        const int nb = nb2 > 0 ? nb2 : 1 << l2;
-        CHK((multisplit_level<ST, HAS_ST>(h, cs, cc, (uint32_t)nb1, false, total, w0[cur], w1[cur], st[cur], w0[cur ^ 1],
-                                           w1[cur ^ 1], st[cur ^ 1], nb2 > 0 ? top - SK_BUCKET_BITS : top - l1 - l2, nb,
-                                           final_start, final_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb)));
-        cur ^= 1;
-    }
-    *where = cur;
     return DBG_OK;
 }
 
@@ -3069,6 +3047,16 @@ static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2]
 }
 
 
+// What a sharded build knows about the records it received when every sender split its records by the 512
+// level-1 buckets before the exchange (dbg_shard_extract does): the receiver then starts at level 2.
+struct Presplit {
+    int n_senders = 0;
+    const uint64_t *counts = nullptr;     // host, [n_senders][512 / n_shards]: records of (sender, owned level-1 bucket)
+    const uint64_t *recv_off = nullptr;   // host, [n_senders]: first record of every sender in the received arrays
+    const uint64_t *stamp_add = nullptr;  // host, [n_senders]: 2 x byte offset of the sender's reads in the concatenation
+    const uint32_t *in_st32 = nullptr;    // device: rank-local stamps of the received records
+};
+
 // ---- stages 2..: records given as segments of (in_w0, in_w1, in_st) -> node arrays + successors.
 // The ping-pong sets w0/w1/st (arena) must hold n_rec records; n_inst bounds the distinct k-mers.
 // shard_bits > 0: only buckets whose top shard_bits equal my_shard hold records (the caller made
@@ -3077,7 +3065,10 @@ template <class ST, int CAP>
 static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
                                   uint64_t n_rec, uint64_t n_inst, uint64_t n_edge_inst, const uint64_t *in_w0,
                                   const uint64_t *in_w1, const ST *in_st, uint64_t *w0[2], uint64_t *w1[2], ST *st[2],
-                                  uint64_t node_capacity_hint, int shard_bits, int my_shard) {
+                                  uint64_t node_capacity_hint, int shard_bits, int my_shard,
+                                  const Presplit *pre = nullptr) {
+    // pre: n_inst / n_edge_inst come in as upper bounds (the senders did not count per owner) and are replaced by the
+    // exact sums of the level-2 histogram pass before anything is sized from them
     const int m = sk_m_for_k(k);
     unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
     uint64_t sc[8] = {0};
@@ -3093,7 +3084,8 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         while (T < T_MAX && (double)(1ull << T) < want) ++T;
     }
     if (T < shard_bits) T = shard_bits;
-    int l1 = T < 9 ? T : (T >= 20 ? 10 : 9), l2 = T - l1;  // level 1 is fixed before the estimate refines T
+    if (pre) T = std::min(19, std::max(9, T));  // the senders split by 9 bits; the second level has at most 1024 children
+    int l1 = T < 9 ? T : (T >= 20 && !pre ? 10 : 9), l2 = T - l1;  // level 1 is fixed before the estimate refines T
     int nb2 = 0;                                            // children of the second level (0: not decided yet)
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
@@ -3102,9 +3094,33 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     double est_distinct = 0.0;  // distinct k-mers of this shard, from the level-1 sample (0 = unknown)
     const int top = 6 + SK_BUCKET_BITS;
     Timer t_part(h->stream);
-    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, true, n_rec, in_w0, in_w1, in_st, w0[1], w1[1], st[1],
-                                    top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
-    where = 1;
+    // presplit: the level-2 input segments, bucket-major: segment (bucket b, sender r) = index (b - b_lo) * n_senders + r
+    const int bps = pre ? nb1 >> shard_bits : 0;  // level-1 buckets this shard owns
+    const uint64_t b_lo = pre ? (uint64_t)my_shard * bps : 0;
+    uint64_t *ps_start = nullptr, *ps_cnt = nullptr, *ps_add = nullptr;
+    uint32_t ps_n = 0;
+    if (pre) {
+        ps_n = (uint32_t)(bps * pre->n_senders);
+        std::vector<uint64_t> hs((size_t)ps_n * 3);
+        for (int r = 0; r < pre->n_senders; ++r) {
+            uint64_t at = pre->recv_off[r];
+            for (int b = 0; b < bps; ++b) {
+                const size_t i = (size_t)b * pre->n_senders + r;
+                hs[i] = at;
+                hs[ps_n + i] = pre->counts[(size_t)r * bps + b];
+                hs[2 * (size_t)ps_n + i] = pre->stamp_add[r];
+                at += pre->counts[(size_t)r * bps + b];
+            }
+        }
+        CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)ps_n * 3 * 8));
+        ps_start = (uint64_t *)h->ar_misc[0].p; ps_cnt = ps_start + ps_n; ps_add = ps_cnt + ps_n;
+        HIPCHK(h, hipMemcpyAsync(ps_start, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // hs goes out of scope
+    } else {
+        CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, in_w0, in_w1, in_st, w0[1], w1[1], st[1],
+                                        top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+        where = 1;
+    }
     if (auto_T && l1 >= 9 && n_rec) {  // refine T from a sample: the first level-1 bucket this shard owns
         const uint32_t probe_bucket = shard_bits ? (uint32_t)my_shard << (l1 - shard_bits) : 0u;
         const uint64_t inst_bucket = (uint64_t)((double)n_inst * own / nb1) * 2 + 1024;
@@ -3113,14 +3129,26 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         CHK(buf_ensure(h, h->ar_misc[8], set_cap * 8));
         HIPCHK(h, hipMemsetAsync(h->ar_misc[8].p, 0xFF, set_cap * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_scalars + 40, 0, 16, h->stream));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_estimate_distinct<ST>), dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt,
-                           probe_bucket, w0[1], w1[1], k, (unsigned long long *)h->ar_misc[8].p, set_cap - 1,
-                           (unsigned long long *)(h->d_scalars + 40));
+        if (pre) {  // the probe bucket's records sit in one segment per sender
+            for (int r = 0; r < pre->n_senders; ++r)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_estimate_distinct<ST>), dim3(128), dim3(256), 0, h->stream, ps_start, ps_cnt,
+                                   (uint32_t)r, in_w0, in_w1, k, (unsigned long long *)h->ar_misc[8].p, set_cap - 1,
+                                   (unsigned long long *)(h->d_scalars + 40));
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_estimate_distinct<ST>), dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt,
+                               probe_bucket, w0[1], w1[1], k, (unsigned long long *)h->ar_misc[8].p, set_cap - 1,
+                               (unsigned long long *)(h->d_scalars + 40));
+        }
         uint64_t est[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(est, h->d_scalars + 40, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (est[0]) {
-            const double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
+            double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
+            if (pre) {  // scale the sample by records: the instance total is not known yet
+                uint64_t probe_recs = 0;
+                for (int r = 0; r < pre->n_senders; ++r) probe_recs += pre->counts[(size_t)r * bps];
+                distinct = probe_recs ? (double)est[1] * (double)n_rec / (double)probe_recs * own : 0.0;
+            }
             est_distinct = distinct / own;
             // the second level takes any number of children up to 1024 (all hash bits below level 1, scaled): the
             // bucket count follows the estimate instead of jumping by powers of two
@@ -3130,6 +3158,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         }
     }
     if (nb2 == 0 && l2 > 0) nb2 = 1 << l2;  // forced or small geometries: a power of two, plain bit fields
+    if (pre && l2 == 0) { l2 = 1; nb2 = 1; }  // the received records still have to be gathered bucket by bucket
     const int fb2 = (nb2 > 0 && (nb2 & (nb2 - 1)) != 0) || (auto_T && l1 >= 9 && nb2 > 1) ? SK_BUCKET_BITS - l1 : 0;
     const uint64_t n_buckets = l2 > 0 ? (uint64_t)nb1 * (uint64_t)nb2 : (uint64_t)nb1;
     T = 0;
@@ -3139,8 +3168,25 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     uint64_t *b_start = (uint64_t *)h->ar_misc[5].p, *b_cnt = b_start + n_buckets;
     if (l2 > 0) {
         const int sh2 = fb2 ? top - SK_BUCKET_BITS : top - l1 - l2_pow;
-        CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, false, n_rec, w0[1], w1[1], st[1], w0[0], w1[0],
-                                        st[0], sh2, nb2, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
+        if (pre) {
+            // only the level-1 buckets this shard owns have records: their children sit at [b_lo * nb2, ...)
+            HIPCHK(h, hipMemsetAsync(b_start, 0, n_buckets * 16, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_scalars + 56, 0, 16, h->stream));
+            CHK((multisplit_level<ST, true, uint32_t>(h, ps_start, ps_cnt, ps_n, (uint32_t)pre->n_senders, n_rec, in_w0, in_w1,
+                                                      pre->in_st32, w0[0], w1[0], st[0], sh2, nb2, b_start + b_lo * nb2,
+                                                      b_cnt + b_lo * nb2, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2,
+                                                      ps_add, (unsigned long long *)(h->d_scalars + 56))));
+            uint64_t sums[2] = {0, 0};
+            HIPCHK(h, hipMemcpyAsync(sums, h->d_scalars + 56, 16, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            n_inst = sums[0];
+            n_edge_inst = sums[1];
+            h->n_kmer_inst = n_inst;
+            h->n_edge_inst = n_edge_inst;
+        } else {
+            CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, 1, n_rec, w0[1], w1[1], st[1], w0[0], w1[0],
+                                            st[0], sh2, nb2, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
+        }
         where = 0;
     } else {
         HIPCHK(h, hipMemcpyAsync(b_start, c1_start, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -3266,7 +3312,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             const int nsh = 1 << shard_bits;
             HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
             uint64_t *o_start = q_seg + 2, *o_cnt = o_start + nsh;
-            CHK((multisplit_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, true, n_q, qk[0], qm[0], qc[0], qk[1], qm[1], qc[1],
+            CHK((multisplit_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, 1, n_q, qk[0], qm[0], qc[0], qk[1], qm[1], qc[1],
                                                   40 + SK_BUCKET_BITS - shard_bits, nsh, o_start, o_cnt, h->ar_misc[2],
                                                   h->ar_misc[3], h->ar_misc[4])));
             ShardState &sh = shard_of(h);
@@ -3539,7 +3585,7 @@ extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_c
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
     Timer t(h->stream);
-    CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, true, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
+    CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
                                           st[1], 6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2],
                                           h->ar_misc[3], h->ar_misc[4])));
     std::vector<uint64_t> cnt(nb1);
@@ -3556,12 +3602,22 @@ extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_c
     sh.n_shards = n_shards;
     sh.k = k;
     sh.n_kmer_inst_local = h->n_kmer_inst;
+    sh.l1_counts = cnt;
+    return DBG_OK;
+}
+
+extern "C" int dbg_shard_bucket_counts(dbg_t *h, uint64_t *counts512) {
+    if (!h || !counts512 || !h->shard_state) return DBG_E_ARG;
+    ShardState &sh = shard_of(h);
+    if (sh.l1_counts.size() != 512) { h->err = "dbg_shard_extract (k <= 31) must run first"; return DBG_E_ARG; }
+    memcpy(counts512, sh.l1_counts.data(), 512 * 8);
     return DBG_OK;
 }
 
 extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w0, const void *d_w1,
                                const void *d_st32, const uint64_t *recv_counts, const uint64_t *stamp_base,
-                               uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys) {
+                               uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys,
+                               const uint64_t *sender_bucket_counts) {
     CHK(shard_args_ok(h, k, n_shards));
     if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !q_starts || !q_counts || !d_q_keys)
         return DBG_E_ARG;
@@ -3574,10 +3630,8 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
     uint64_t n_rec = 0;
     std::vector<uint64_t> seg((size_t)n_shards * 2);
     for (int r = 0; r < n_shards; ++r) { seg[r] = n_rec; seg[n_shards + r] = recv_counts[r]; n_rec += recv_counts[r]; }
-    CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_shards * 16));
-    uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_shards;
-    HIPCHK(h, hipMemcpyAsync(seg_start, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, h->stream));
-    // arena sets for 64-bit stamps; the rebased stamps of the received records go to ar_shard[2]
+    free_build(h);  // node arrays of an earlier build on this handle (the record arenas stay)
+    // arena sets for 64-bit stamps
     uint64_t *w0[2], *w1[2], *st[2];
     for (int set = 0; set < 2; ++set) {
         CHK(buf_ensure(h, h->ar_rec[set][0], (n_rec + 16) * 8));
@@ -3587,31 +3641,64 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
         w1[set] = (uint64_t *)h->ar_rec[set][1].p;
         st[set] = (uint64_t *)h->ar_rec[set][2].p;
     }
-    CHK(buf_ensure(h, h->ar_shard[2], (n_rec + 16) * 8));
-    uint64_t *st64 = (uint64_t *)h->ar_shard[2].p;
-    HIPCHK(h, hipMemsetAsync(h->d_scalars + 56, 0, 16, h->stream));
-    for (int r = 0; r < n_shards; ++r) {
-        if (!recv_counts[r]) continue;
-        const unsigned grid = (unsigned)std::min<uint64_t>(grid_for(recv_counts[r], 256), 8192);
-        hipLaunchKernelGGL(k_stamp_globalize, dim3(grid), dim3(256), 0, h->stream, (const uint32_t *)d_st32 + seg[r],
-                           (const uint64_t *)d_w1 + seg[r], recv_counts[r], stamp_base[r] << 1, st64 + seg[r],
-                           (unsigned long long *)(h->d_scalars + 56));
-    }
-    HIPCHK(h, hipGetLastError());
-    uint64_t sums[2] = {0, 0};
-    HIPCHK(h, hipMemcpyAsync(sums, h->d_scalars + 56, 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    const uint64_t n_inst = sums[0], n_edge = sums[1];
     h->k = k;
     h->stats.n_records = n_rec;
-    Timer t_total(h->stream);
     ShardState &sh = shard_of(h);
     sh.n_shards = n_shards; sh.my_shard = my_shard; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
     sh.q_start.assign(n_shards, 0);
     sh.q_cnt.assign(n_shards, 0);
-    int rc = sk_count_from_segments<uint64_t, 4096>(h, k, seg_start, seg_cnt, (uint32_t)n_shards, n_rec, n_inst, n_edge,
+    int rc;
+    uint64_t n_inst = 0, n_edge = 0;
+    const bool presplit = sender_bucket_counts && (h->bucket_bits == 0 || h->bucket_bits >= 9);
+    Timer t_total(h->stream);
+    if (presplit) {
+        // every sender split its records by the 512 level-1 buckets (dbg_shard_extract) and says how many of each it
+        // sent: the receiver starts at level 2, which also rebases the rank-local stamps and counts the instances
+        const int bps = 512 >> shard_bits;
+        for (int r = 0; r < n_shards; ++r) {
+            uint64_t tot = 0;
+            for (int b = 0; b < bps; ++b) tot += sender_bucket_counts[(size_t)r * bps + b];
+            if (tot != recv_counts[r]) { h->err = "sender_bucket_counts do not add up to recv_counts"; return DBG_E_ARG; }
+        }
+        std::vector<uint64_t> add(n_shards);
+        for (int r = 0; r < n_shards; ++r) add[r] = stamp_base[r] << 1;
+        Presplit pre;
+        pre.n_senders = n_shards;
+        pre.counts = sender_bucket_counts;
+        pre.recv_off = seg.data();
+        pre.stamp_add = add.data();
+        pre.in_st32 = (const uint32_t *)d_st32;
+        const int w = k - sk_m_for_k(k) + 1;  // a record holds at most w k-mers
+        rc = sk_count_from_segments<uint64_t, 4096>(h, k, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w, n_rec * (uint64_t)w,
+                                                    (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)nullptr, w0,
+                                                    w1, st, 0, shard_bits, my_shard, &pre);
+        n_inst = h->n_kmer_inst;
+        n_edge = h->n_edge_inst;
+    } else {
+        CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_shards * 16));
+        uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_shards;
+        HIPCHK(h, hipMemcpyAsync(seg_start, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, h->stream));
+        // the rebased stamps of the received records go to ar_shard[2]
+        CHK(buf_ensure(h, h->ar_shard[2], (n_rec + 16) * 8));
+        uint64_t *st64 = (uint64_t *)h->ar_shard[2].p;
+        HIPCHK(h, hipMemsetAsync(h->d_scalars + 56, 0, 16, h->stream));
+        for (int r = 0; r < n_shards; ++r) {
+            if (!recv_counts[r]) continue;
+            const unsigned grid = (unsigned)std::min<uint64_t>(grid_for(recv_counts[r], 256), 8192);
+            hipLaunchKernelGGL(k_stamp_globalize, dim3(grid), dim3(256), 0, h->stream, (const uint32_t *)d_st32 + seg[r],
+                               (const uint64_t *)d_w1 + seg[r], recv_counts[r], stamp_base[r] << 1, st64 + seg[r],
+                               (unsigned long long *)(h->d_scalars + 56));
+        }
+        HIPCHK(h, hipGetLastError());
+        uint64_t sums[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(sums, h->d_scalars + 56, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        n_inst = sums[0];
+        n_edge = sums[1];
+        rc = sk_count_from_segments<uint64_t, 4096>(h, k, seg_start, seg_cnt, (uint32_t)n_shards, n_rec, n_inst, n_edge,
                                                     (const uint64_t *)d_w0, (const uint64_t *)d_w1, st64, w0, w1, st, 0,
                                                     shard_bits, my_shard);
+    }
     if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
     // the instance counters describe this shard's nodes from here on
     h->n_kmer_inst = n_inst;

@@ -386,16 +386,18 @@ constexpr int MS_MAX_NB = 1024;
 constexpr int MS_NT = DBG_MS_NT;      // threads of the scatter workgroup: its 90 KB of LDS allow one per CU, so the
                                       // workgroup itself has to bring the waves that hide the record loads
 
-// Input of one multisplit level: `n_seg` contiguous segments of the record arrays.  Either all
-// segments form ONE group (level 1: the per-workgroup output segments of k_sk_extract) or every
-// segment is its own group (level 2: the children of level 1).  A group is split into nb
-// children that are laid out contiguously, groups in order.
+// Input of one multisplit level: `n_seg` contiguous segments of the record arrays, in groups of `spg`
+// consecutive segments: all segments in ONE group (level 1: the per-workgroup output segments of
+// k_sk_extract), every segment its own group (level 2: the children of level 1), or one group per
+// level-1 bucket made of one segment per sender (level 2 of a sharded build: the senders split by
+// level 1 before the exchange, so the receiver starts here).  A group is split into nb children that
+// are laid out contiguously, groups in order.
 struct MsParents {
     const uint64_t *start;    // [n_seg]
     const uint64_t *cnt;      // [n_seg]
     const uint64_t *sc_pre;   // [n_seg + 1] super-chunks before segment i
     uint32_t n_seg;
-    uint32_t one_group;       // 1: all segments belong to one group
+    uint32_t spg;             // segments per group (n_seg: one group; 1: every segment its own)
 };
 
 // which segment owns super-chunk g, and which super-chunk of that segment it is
@@ -416,8 +418,11 @@ __device__ inline uint32_t ms_child(uint64_t w1, int shift, int nb, int fbits) {
     return fbits ? (uint32_t)(((uint64_t)(v & ((1u << fbits) - 1u)) * (uint32_t)nb) >> fbits) : (v & (uint32_t)(nb - 1));
 }
 
+// SUMS: also adds up the k-mer and edge instances the records carry (sums[0], sums[1]): a sharded build learns the
+// size of what it received in the pass it makes anyway
+template <bool SUMS>
 __global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__restrict__ w1, int shift, int nb, int fbits,
-                                                 uint32_t *cmat) {
+                                                 uint32_t *cmat, unsigned long long *sums) {
     __shared__ uint32_t hist[MS_MAX_NB];
     uint32_t seg;
     uint64_t sidx;
@@ -426,10 +431,22 @@ __global__ __launch_bounds__(256) void k_ms_hist(MsParents P, const uint64_t *__
     __syncthreads();
     const uint64_t beg = P.start[seg] + sidx * MS_SC;
     const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
-    for (uint64_t i = beg + threadIdx.x; i < end; i += 256)
-        atomicAdd(&hist[ms_child(w1[i], shift, nb, fbits)], 1u);
+    uint64_t n_inst = 0, n_edge = 0;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += 256) {
+        const uint64_t x = w1[i];
+        atomicAdd(&hist[ms_child(x, shift, nb, fbits)], 1u);
+        if (SUMS) { n_inst += ((x >> 1) & 31) + 1; n_edge += ((x >> 1) & 31) + (x & 1); }
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += 256) cmat[(uint64_t)blockIdx.x * nb + b] = hist[b];
+    if (SUMS) {
+        n_inst = wave_sum_u64(n_inst);
+        n_edge = wave_sum_u64(n_edge);
+        if ((threadIdx.x & 63) == 0) {
+            if (n_inst) atomicAdd(&sums[0], (unsigned long long)n_inst);
+            if (n_edge) atomicAdd(&sums[1], (unsigned long long)n_edge);
+        }
+    }
 }
 
 // logical scan order: group-major, then child bucket, then super-chunk inside the group
@@ -438,20 +455,17 @@ struct MsLogical {
     const uint32_t *cmat;
     int nb;
     __device__ uint64_t operator()(uint64_t L) const {
-        if (P.one_group) {
-            const uint64_t nsc = P.sc_pre[P.n_seg];
-            const uint64_t b = L / nsc, sc = L - b * nsc;
-            return cmat[sc * nb + b];
-        }
-        uint32_t lo = 0, hi = P.n_seg;  // lbase[g] = nb * sc_pre[g]
+        const uint32_t n_groups = P.n_seg / P.spg;
+        uint32_t lo = 0, hi = n_groups;  // lbase[g] = nb * sc_pre[g * spg]
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if ((uint64_t)nb * P.sc_pre[mid] <= L) lo = mid; else hi = mid;
+            if ((uint64_t)nb * P.sc_pre[mid * P.spg] <= L) lo = mid; else hi = mid;
         }
-        const uint64_t nsc = P.sc_pre[lo + 1] - P.sc_pre[lo];
-        const uint64_t r = L - (uint64_t)nb * P.sc_pre[lo];
+        const uint64_t g_lo = P.sc_pre[lo * P.spg];
+        const uint64_t nsc = P.sc_pre[(lo + 1) * P.spg] - g_lo;
+        const uint64_t r = L - (uint64_t)nb * g_lo;
         const uint64_t b = r / nsc, sidx = r - b * nsc;
-        return cmat[(P.sc_pre[lo] + sidx) * nb + b];
+        return cmat[(g_lo + sidx) * nb + b];
     }
 };
 
@@ -459,11 +473,11 @@ struct MsLogical {
 __global__ __launch_bounds__(256) void k_ms_children(MsParents P, const uint64_t *__restrict__ offs, int nb,
                                                      uint64_t total, uint64_t *c_start, uint64_t *c_cnt) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_groups = P.one_group ? 1u : P.n_seg;
+    const uint32_t n_groups = P.n_seg / P.spg;
     const uint64_t n_child = (uint64_t)n_groups * nb;
     if (i >= n_child) return;
     const uint32_t g = (uint32_t)(i / nb), b = (uint32_t)(i % nb);
-    const uint64_t g_lo = P.one_group ? 0 : P.sc_pre[g], g_hi = P.one_group ? P.sc_pre[P.n_seg] : P.sc_pre[g + 1];
+    const uint64_t g_lo = P.sc_pre[g * P.spg], g_hi = P.sc_pre[(g + 1) * P.spg];
     const uint64_t nsc = g_hi - g_lo;
     const uint64_t L = (uint64_t)nb * g_lo + (uint64_t)b * nsc;  // first logical element of this child
     const uint64_t Ln = L + nsc;                                   // ... of the next child
@@ -491,9 +505,12 @@ __device__ unsigned long long g_ms_prof[8];
 #define MS_TICK(i) do {} while (0)
 #endif
 
-template <class ST, bool HAS_ST>
+// STI: stamp type of the input (a sharded build receives rank-local 32-bit stamps and rebases them to global 64-bit
+// ones here: seg_add[segment] = 2 x the byte offset of the sender's reads in the rank-major concatenation)
+template <class ST, bool HAS_ST, class STI = ST>
 __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_t *__restrict__ in_w0,
-                                                    const uint64_t *__restrict__ in_w1, const ST *__restrict__ in_st,
+                                                    const uint64_t *__restrict__ in_w1, const STI *__restrict__ in_st,
+                                                    const uint64_t *__restrict__ seg_add,
                                                     int shift, int nb, int fbits, const uint64_t *__restrict__ offs,
                                                     uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_raw[];
@@ -504,9 +521,11 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
     uint32_t seg;
     uint64_t sidx;
     ms_locate(P, blockIdx.x, &seg, &sidx);
+    const ST st_add = (HAS_ST && seg_add) ? (ST)seg_add[seg] : (ST)0;
     MS_TICK(0);
     // position of this super-chunk inside its group, and the group's extent in the logical order
-    const uint64_t g_lo = P.one_group ? 0 : P.sc_pre[seg], g_hi = P.one_group ? P.sc_pre[P.n_seg] : P.sc_pre[seg + 1];
+    const uint32_t grp = seg / P.spg;
+    const uint64_t g_lo = P.sc_pre[grp * P.spg], g_hi = P.sc_pre[(grp + 1) * P.spg];
     const uint64_t nsc = g_hi - g_lo, gidx = (uint64_t)blockIdx.x - g_lo;
     const uint64_t lbase = (uint64_t)nb * g_lo;
     for (int b = threadIdx.x; b < nb; b += MS_NT) s.run[b] = offs[lbase + (uint64_t)b * nsc + gidx];
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
             if (q < n) {
                 r0[i] = in_w0[c0 + q];
                 r1[i] = in_w1[c0 + q];
-                if (HAS_ST) rs[i] = in_st[c0 + q];
+                if (HAS_ST) rs[i] = (ST)in_st[c0 + q] + st_add;
                 rk[i] = atomicAdd(&s.hist[ms_child(r1[i], shift, nb, fbits)], 1u);
             }
         }
@@ -645,11 +664,12 @@ __device__ inline uint32_t slot_of(uint64_t kmer) {
     return slot_hash(kmer) >> (CAP == 4096 ? 20 : 21);
 }
 
-// cross-bucket successor queries staged per workgroup; also the record staging depth.  With 64-bit
-// stamps the 4096-slot table leaves room for ~300 only (the edge-offset array took the rest).
+// cross-bucket successor queries staged per workgroup; also the record staging depth (a bucket holds ~530 records at
+// the default geometry: a bucket that fits one staging round pays the dedupe / quad list / insert barriers once).
+// With 64-bit stamps (sharded builds) the 4096-slot table leaves room for 640.
 template <class ST, int CAP>
 struct CntCfg {
-    static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 304 : 768) : 400;
+    static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 640 : 768) : 400;
     // 4096 slots fill the LDS: one 1024-thread workgroup per CU.  2048 slots: two 512-thread workgroups per CU
     // that run out of step, so one's barriers and LDS stalls overlap the other's work.
     static constexpr int NT = CAP == 4096 ? 1024 : 512;
@@ -663,8 +683,7 @@ struct CntLds {
     unsigned long long keys[CAP];
     uint32_t cnt[CAP * 4];
     ST stamp[CAP];
-    uint16_t idx[CAP];    // slot -> local node index
-    uint16_t list[CAP];   // local node index -> slot
+    uint16_t list[CAP];   // local node index -> slot (slot -> local node index: dir_base + rank in dir_mask)
     uint16_t eoff[CAP];   // local node index -> first CSR edge of the node, relative to the bucket
     unsigned long long q_key[CNT_QBUF];   // insert phase: staged record w0; afterwards: query keys
     unsigned long long q_meta[CNT_QBUF];  // insert phase: staged record w1; afterwards: query meta
@@ -675,6 +694,9 @@ struct CntLds {
     unsigned long long gbase, qbase, ebase, ri;
     unsigned long long dir_mask[CAP / 64];  // occupancy of every 64-slot block of the final table
     uint16_t dir_base[CAP / 64];            // local node index of the block's first node
+#ifdef DBG_CNT_PROF
+    unsigned long long prof[32];
+#endif
 };
 
 // k-mer i of a record: 32-base window starting at base i (first base in bits 63:62)
@@ -775,6 +797,15 @@ __device__ inline uint32_t wave_alloc_n(uint32_t *counter, uint32_t n) {
     return base + excl;
 }
 
+#ifdef DBG_CNT_PROF
+__device__ unsigned long long g_cnt_prof[32];
+#define CNT_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); s.prof[i] += now_ - clast_; clast_ = now_; } } while (0)
+#define CNT_SUBTICK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); s.prof[i] += now_ - csub_; csub_ = now_; } } while (0)
+#else
+#define CNT_TICK(i) do {} while (0)
+#define CNT_SUBTICK(i) do {} while (0)
+#endif
+
 template <class ST, int CAP>
 __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
@@ -790,13 +821,21 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
     constexpr int CNT_NT = CntCfg<ST, CAP>::NT;
     constexpr int NPT = CAP / CNT_NT;  // nodes per thread, upper bound
     constexpr int CNT_QBUF = CntCfg<ST, CAP>::QBUF;
-    static_assert(offsetof(LdsT, list) == offsetof(LdsT, idx) + sizeof(uint16_t) * CAP, "layout");
-    static_assert(CNT_QBUF * 5 <= 2 * CAP || CAP == 2048, "quad list must fit idx+list");
-    constexpr uint32_t STAGE = (CNT_QBUF * 5 <= 2 * CAP) ? CNT_QBUF : (2 * CAP) / 5;
+    // scratch of the insert phase lives in arrays that are only needed once the table is final: the dedupe set and
+    // then the quad list in eoff[], the multiplicities in list[].  A record holds at most w = k - m + 1 <= 19 k-mers:
+    // five quads.
+    static_assert(CNT_QBUF * 5 <= CAP, "quad list must fit eoff[]");
+    constexpr uint32_t STAGE = CNT_QBUF;
     static_assert(STAGE <= CNT_NT, "one staged record per thread");
+    static_assert(sizeof(LdsT) <= 160 * 1024, "LDS");
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    uint16_t *flat = s.idx;  // idx[] and list[] are adjacent and unused until the table is final
+    uint16_t *flat = s.eoff;
 
+#ifdef DBG_CNT_PROF
+    unsigned long long clast_ = clock64(), csub_ = clast_;
+    if (threadIdx.x < 32) s.prof[threadIdx.x] = 0;
+    __syncthreads();
+#endif
     bool clean = false;  // uniform: every slot of the table is EMPTY / zero / max
     uint64_t pf_w0 = 0, pf_w1 = 0;
     ST pf_st = 0;
@@ -836,6 +875,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
             if (!root) { cur_mask = s.stk_mask[stk_n]; cur_val = s.stk_val[stk_n]; }
             root = false;
             __syncthreads();  // the previous pass (or bucket) is done with the staging arrays and the table
+            CNT_TICK(0);
             if (!clean) {
                 for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
                     s.keys[i] = EMPTY_KEY;
@@ -860,15 +900,16 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                         s.st_stage[r] = rec_st[r_beg + c0 + r];
                     }
                 }
-                // dedupe scratch (idx[] / list[] are free until the table is final): hash set of record indices
+                // dedupe scratch (eoff[] / list[] are free until the table is final): hash set of record indices
                 // and the multiplicity of every representative
-                uint32_t *dd_tab = reinterpret_cast<uint32_t *>(s.idx);    // DD_SLOTS entries
+                uint32_t *dd_tab = reinterpret_cast<uint32_t *>(s.eoff);   // DD_SLOTS entries
                 uint32_t *dd_mult = reinterpret_cast<uint32_t *>(s.list);  // STAGE entries
-                constexpr uint32_t DD_SLOTS = CAP / 2;                      // sizeof(idx) / 4; >= 2 * STAGE
+                constexpr uint32_t DD_SLOTS = CAP / 2;                      // sizeof(eoff) / 4; >= 2 * STAGE
                 static_assert(DD_SLOTS >= 2 * STAGE && CAP / 2 >= STAGE, "dedupe scratch");
                 for (uint32_t i = threadIdx.x; i < DD_SLOTS; i += CNT_NT) dd_tab[i] = 0xFFFFFFFFu;
                 for (uint32_t i = threadIdx.x; i < n_st; i += CNT_NT) dd_mult[i] = 0;
                 __syncthreads();
+                CNT_TICK(1);
                 if (phase_limit == 1) { skip_rest = true; break; }  // clear + stage
                 if (s.overflow) break;  // uniform: read after the barrier
                 // ---- identical records (same window of the genome seen by several reads) collapse to one
@@ -892,6 +933,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     if (rep != r) atomicMin(&s.st_stage[rep], s.st_stage[r]);
                 }
                 __syncthreads();
+                CNT_TICK(2);
                 {  // quad list of the representatives (STAGE <= CNT_NT: one record per thread)
                     const uint32_t r = threadIdx.x;
                     uint32_t nquad = 0;
@@ -900,6 +942,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
                 }
                 __syncthreads();
+                CNT_TICK(3);
                 const uint32_t n_flat = s.n_flat;
                 for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += CNT_NT / 4) {
                     const uint32_t e = flat[f];
@@ -935,7 +978,9 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 }
             }
             if (skip_rest) break;
+            CNT_TICK(4);
             __syncthreads();
+            CNT_TICK(5);
             if (have_prefetch) {  // the registers are free: fetch the next bucket's records under the rest of this one
                 have_prefetch = false;
                 prefetch(bucket + gridDim.x);
@@ -982,13 +1027,14 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     if ((threadIdx.x & 63) == 0) s.dir_base[i >> 6] = (uint16_t)base;
                     if (occ) {
                         const uint32_t li = (base & 0xFFFFu) + lanes_below(mask);
-                        s.idx[i] = (uint16_t)li;
                         s.list[li] = (uint16_t)i;
                         s.eoff[li] = (uint16_t)((base >> 16) + eexc);
                     }
                 }
             }
+            CNT_TICK(6);
             __syncthreads();
+            CNT_TICK(7);
             if (phase_limit == 3) { skip_rest = true; break; }  // + dense list
             const uint32_t n_local = s.n_local & 0xFFFFu, n_edges_local = s.n_local >> 16;
             // ---- reservation of the node ids and CSR rows: one packed global atomic, issued now and consumed after
@@ -1016,14 +1062,21 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 }
                 const uint32_t nz_all = nz;
                 uint32_t missmask = 0;
+                if (u == 0) { CNT_TICK(8); CNT_SUBTICK(20); }
                 while (nz) {
                     const uint32_t b = __ffs(nz) - 1;
                     nz &= nz - 1;
                     const int f = lds_find<CAP>(s.keys, ((key << 2) | (uint64_t)b) & kmask);
-                    if (f >= 0) nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)s.idx[f] << (16 * b));
+                    if (f >= 0) {  // slot -> local node index: rank of the slot among the occupied ones of its 64-slot block
+                        const uint32_t ix = (uint32_t)s.dir_base[f >> 6] +
+                                            (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                        nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)ix << (16 * b));
+                    }
                     else missmask |= 1u << b;
                 }
+                if (u == 0) CNT_SUBTICK(13);
                 uint32_t qi = wave_alloc_n<4>(&s.n_q, (uint32_t)__popc(missmask));
+                if (u == 0) CNT_SUBTICK(14);
                 while (missmask) {
                     const uint32_t b = __ffs(missmask) - 1;
                     missmask &= missmask - 1;
@@ -1038,7 +1091,9 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | (code << (16 * b));
                     ++qi;
                 }
+                if (u == 0) CNT_SUBTICK(15);
             }
+            CNT_TICK(17);
             // ---- thread 0 turns the reservation into the bucket's bases before the barrier that ends the lookups: one
             //      barrier publishes both, and its serial work overlaps the other waves' lookups
             if (threadIdx.x == 0) {
@@ -1060,7 +1115,9 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     orr.ranges[ri] = rg;
                 }
             }
+            CNT_TICK(9);
             __syncthreads();
+            CNT_TICK(10);
             if (phase_limit == 4) { skip_rest = true; break; }  // + successor lookups
             const uint32_t nq = s.n_q;
             unsigned long long qgot = 0;
@@ -1110,12 +1167,14 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     }
                 }
             }
+            CNT_TICK(11);
             // ---- queries out (the cursor has had the whole node pass to come back)
             if (threadIdx.x == 64 && nq) {
                 s.qbase = qgot;
                 if (qgot + nq > (*fresh_args(outp)).q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&(*fresh_args(outp)).scalars[0], 64ull); s.fail = 1; }
             }
             __syncthreads();
+            CNT_TICK(12);
             if (s.fail) break;
             if (nq) {
                 const auto &oq = *fresh_args(outp);
@@ -1150,6 +1209,12 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
         if (failed || s.fail) return;  // s.fail was written before the last barrier every thread passed
         if (skip_rest) { clean = false; if (have_prefetch) prefetch(bucket + gridDim.x); }
     }
+#ifdef DBG_CNT_PROF
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 31; ++i) atomicAdd(&g_cnt_prof[i], s.prof[i]);
+        atomicAdd(&g_cnt_prof[31], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -101,37 +101,116 @@ def stamp_bases(dist, n_bytes, device):
     return bases
 
 
-def sharded_build(g, k, dist):
-    """Runs steps 1-5 on graph handle ``g`` (reads already set on every rank).  Returns ``g``."""
+def message_digests(t, counts):
+    """Wrapping 64-bit sum of the elements of every message of a 1-D integer tensor laid out as consecutive messages
+    of counts[d] elements -> int64 tensor [len(counts)] on t's device (no host sync)."""
+    out, pos = [], 0
+    for c in counts:
+        out.append(t[pos:pos + c].sum(dtype=torch.int64).reshape(1))
+        pos += c
+    return torch.cat(out) if out else torch.zeros(0, dtype=torch.int64, device=t.device)
+
+
+class ExchangeCheck:
+    """Integrity check of the all-to-alls of one sharded step.  An all-to-all has no checksum of its own: a damaged or
+    truncated message would come back as a wrong graph with rc 0 (seen once: messages above 2 GiB, see
+    MAX_MESSAGE_BYTES).  Every sender therefore digests each message it sends (message_digests), the digests travel
+    in a second, tiny all-to-all, and the receiver compares them with the digests of what arrived.  The comparisons
+    stay on the device; ``verify`` does the one host sync and raises."""
+
+    def __init__(self, dist):
+        self.dist, self.bad = dist, []
+
+    def alltoallv(self, tensor, send_counts, recv_counts, what):
+        dist = self.dist
+        out = alltoallv(dist, tensor, send_counts, recv_counts)
+        send = message_digests(tensor, send_counts)
+        if _is_gloo(dist):
+            recv = torch.empty(len(recv_counts), dtype=torch.int64)
+            dist.all_to_all_single(recv, send.cpu())
+            recv = recv.to(out.device)
+        else:
+            recv = torch.empty(len(recv_counts), dtype=torch.int64, device=send.device)
+            dist.all_to_all_single(recv, send)
+        self.bad.append((what, message_digests(out, recv_counts) != recv))
+        return out
+
+    def verify(self):
+        for what, flags in self.bad:
+            if flags.numel() and bool(flags.any().item()):
+                ranks = [r for r, f in enumerate(flags.tolist()) if f]
+                raise RuntimeError(f"sharded build: rank {self.dist.get_rank()} received damaged '{what}' messages from "
+                                   f"ranks {ranks} (digest of the received bytes != digest the sender computed)")
+        self.bad = []
+
+
+class _NoCheck:
+    def __init__(self, dist):
+        self.dist = dist
+
+    def alltoallv(self, tensor, send_counts, recv_counts, what):
+        return alltoallv(self.dist, tensor, send_counts, recv_counts)
+
+    def verify(self):
+        pass
+
+
+def sharded_build(g, k, dist, check=True):
+    """Runs steps 1-5 on graph handle ``g`` (reads already set on every rank).  Returns ``g``.
+    check: verify every exchanged message against a digest computed by its sender (ExchangeCheck); raises on damage."""
     w, me = dist.get_world_size(), dist.get_rank()
+    xc = ExchangeCheck(dist) if check else _NoCheck(dist)
     send_counts, (w0, w1, st) = g.shard_extract(k, w)
     device = w0.device
-    recv_counts = exchange_counts(dist, send_counts, device)
-    r_w0 = alltoallv(dist, w0, send_counts, recv_counts)
-    r_w1 = alltoallv(dist, w1, send_counts, recv_counts)
-    r_st = alltoallv(dist, st, send_counts, recv_counts)
-    bases = stamp_bases(dist, g.sizes()["n_bytes"], device)
+    # one small all-gather carries everything the ranks need to know about each other: the bytes of reads every rank
+    # holds (stamp bases) and, for k <= 31, how its records split over the 512 level-1 buckets -- the receive counts are
+    # sums of those, and the owner can start its build at the second multisplit level
+    presplit = k <= 31 and hasattr(g, "shard_bucket_counts")
+    meta = [g.sizes()["n_bytes"]] + (g.shard_bucket_counts() if presplit else list(send_counts))
+    metas = _all_gather_ints(dist, meta, device)
+    bases, acc = [], 0
+    for m_r in metas:
+        bases.append(acc)
+        acc += m_r[0]
+    sender_buckets = None
+    if presplit:
+        bps = 512 // w
+        sender_buckets = [m_r[1 + me * bps: 1 + (me + 1) * bps] for m_r in metas]
+        recv_counts = [sum(row) for row in sender_buckets]
+    else:
+        recv_counts = [m_r[1 + me] for m_r in metas]
+    r_w0 = xc.alltoallv(w0, send_counts, recv_counts, "records w0")
+    r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1")
+    r_st = xc.alltoallv(st, send_counts, recv_counts, "records st")
+    xc.verify()  # before anything is built from them
     if not _is_gloo(dist) and device.type == "cuda":
         torch.cuda.synchronize(device)  # the library works on its own stream
-    q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases)
+    if presplit:
+        q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases, sender_buckets)
+    else:
+        q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases)
 
     # successors owned by other shards: keys out, node ids back.  The library lists the queries
     # grouped by owner with its own group in between: pack the remote groups for the wire.
     q_recv = exchange_counts(dist, q_counts, device)
-    groups = [q_keys[s:s + c] for s, c in zip(q_starts, q_counts)]
-    packed = torch.cat(groups) if groups else q_keys[:0]
-    keys_in = alltoallv(dist, packed, q_counts, q_recv)
-    if not _is_gloo(dist) and device.type == "cuda":
-        torch.cuda.synchronize(device)
-    answers_out = g.shard_answer(keys_in)
-    back = alltoallv(dist, answers_out, q_recv, q_counts)
-    answers = torch.empty(q_keys.numel(), dtype=torch.int32, device=device)
-    off = 0
-    for s, c in zip(q_starts, q_counts):
-        answers[s:s + c] = back[off:off + c]
-        off += c
-    if not _is_gloo(dist) and device.type == "cuda":
-        torch.cuda.synchronize(device)
+    if sum(q_counts) + sum(q_recv):
+        groups = [q_keys[s:s + c] for s, c in zip(q_starts, q_counts)]
+        packed = torch.cat(groups) if groups else q_keys[:0]
+        keys_in = xc.alltoallv(packed, q_counts, q_recv, "successor queries")
+        if not _is_gloo(dist) and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        answers_out = g.shard_answer(keys_in)
+        back = xc.alltoallv(answers_out, q_recv, q_counts, "successor answers")
+        xc.verify()
+        answers = torch.empty(q_keys.numel(), dtype=torch.int32, device=device)
+        off = 0
+        for s, c in zip(q_starts, q_counts):
+            answers[s:s + c] = back[off:off + c]
+            off += c
+        if not _is_gloo(dist) and device.type == "cuda":
+            torch.cuda.synchronize(device)
+    else:  # one rank, or two-word k-mers: nothing to ask
+        answers = torch.empty(0, dtype=torch.int32, device=device)
     g.shard_apply(answers)
     return g
 

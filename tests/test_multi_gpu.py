@@ -13,6 +13,7 @@ import sys
 import numpy as np
 import pytest
 
+import inproc_dist
 import synth
 from oracle import orc_c
 
@@ -89,6 +90,76 @@ def test_exchange_logic_on_cpu_gloo(world, max_msg, tmp_path):
         has = m["counts"][:, code] != 0
         assert np.array_equal(m["keys"][m["succ"][has, code]], ((m["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
         assert np.all(m["succ"][~has, code] == 0xFFFFFFFF)
+
+
+def rank_reads(world, rank, n_reads, read_len):
+    per = n_reads // world
+    return synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01, first_read=rank * per)
+
+
+def test_eight_ranks_in_process_exchange_logic_on_cpu():
+    """Three owner bits (8 logical shards, host-side exchange): the real multi_gpu.sharded_build
+    on eight threads of this process around the numpy model of the device steps, checksummed exchanges included."""
+    import multi_gpu
+    import shard_worker
+    k, n_reads, read_len = 9, 128, 40
+
+    def one(dist, rank):
+        g = shard_worker.NumpyShardGraph([row.tobytes().decode() for row in rank_reads(8, rank, n_reads, read_len)], k)
+        multi_gpu.sharded_build(g, k, dist)
+        keys, stamps, counts, succ = g.export()
+        return {"keys": keys, "keys_hi": np.zeros_like(keys), "stamps": stamps, "counts": counts, "succ": succ}
+
+    check(inproc_dist.run_ranks(8, one), 8, k, n_reads, read_len)
+
+
+def test_damaged_exchange_is_detected():
+    """multi_gpu.ExchangeCheck: a message that arrives with one wrong word must raise, not build a wrong graph."""
+    import multi_gpu
+    import torch
+
+    class Corrupting(inproc_dist.InProcDist):
+        def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+            super().all_to_all_single(out, inp, out_splits, in_splits)
+            if out_splits is not None and self.get_rank() == 1 and out.numel() > 3:
+                out[3] += 1  # one flipped value in what rank 1 received
+
+    def one(dist, rank):
+        dist.__class__ = Corrupting
+        xc = multi_gpu.ExchangeCheck(dist)
+        t = torch.arange(10, dtype=torch.int64) + 100 * rank
+        xc.alltoallv(t, [5, 5], [5, 5], "test")
+        try:
+            xc.verify()
+        except RuntimeError as e:
+            return str(e)
+        return None
+
+    got = inproc_dist.run_ranks(2, one)
+    assert got[0] is None and got[1] is not None and "damaged" in got[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_reads,read_len", [(31, 24000, 150), (21, 8000, 100), (63, 8000, 150)])
+def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len):
+    """shard_bits = 3 through the C ABI before a real 8-GPU node sees it: eight handles on cuda:0, one thread per rank,
+    the real multi_gpu.sharded_build with an in-process exchange; union of the shards == the C oracle."""
+    import _dbg
+    import multi_gpu
+
+    def one(dist, rank):
+        reads = rank_reads(8, rank, n_reads, read_len)
+        g = _dbg.Graph(device=0)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
+        multi_gpu.sharded_build(g, k, dist)
+        keys, stamps, counts, _ = g.export_nodes()
+        out = {"keys": keys, "keys_hi": g.export_keys_hi(), "stamps": stamps, "counts": counts, "succ": g.export_succ()}
+        rp, col, cnt = g.export_csr()
+        assert np.array_equal(col, out["succ"][counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+        g.close()
+        return out
+
+    check(inproc_dist.run_ranks(8, one), 8, k, n_reads, read_len)
 
 
 @pytest.mark.gpu

@@ -29,12 +29,18 @@ for it in range(3):
     t_all = time.perf_counter()
     t0 = time.perf_counter(); send_counts, (w0, w1, st) = g.shard_extract(k, w); lap("shard_extract", t0)
     device = w0.device
-    t0 = time.perf_counter(); recv_counts = mg.exchange_counts(dist, send_counts, device); lap("exchange_counts", t0)
     t0 = time.perf_counter()
-    r_w0 = mg.alltoallv(dist, w0, send_counts, recv_counts); r_w1 = mg.alltoallv(dist, w1, send_counts, recv_counts)
-    r_st = mg.alltoallv(dist, st, send_counts, recv_counts); lap("alltoallv_records", t0)
-    t0 = time.perf_counter(); bases = mg.stamp_bases(dist, g.sizes()["n_bytes"], device); lap("stamp_bases", t0)
-    t0 = time.perf_counter(); q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases); lap("shard_build", t0)
+    metas = mg._all_gather_ints(dist, [g.sizes()["n_bytes"]] + g.shard_bucket_counts(), device)
+    bases = [0]
+    sender_buckets = [m_r[1:513] for m_r in metas]
+    recv_counts = [sum(row) for row in sender_buckets]
+    lap("meta_all_gather", t0)
+    xc = mg.ExchangeCheck(dist) if os.environ.get("CHECK", "1") == "1" else mg._NoCheck(dist)
+    t0 = time.perf_counter()
+    r_w0 = xc.alltoallv(w0, send_counts, recv_counts, "w0"); r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "w1")
+    r_st = xc.alltoallv(st, send_counts, recv_counts, "st"); xc.verify(); lap("alltoallv_records(+digests)", t0)
+    pre = sender_buckets if os.environ.get("PRESPLIT", "1") == "1" else None
+    t0 = time.perf_counter(); q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases, pre); lap("shard_build", t0)
     st_ = g.stats()
     T["  build phases"] = {x: round(st_[x], 2) for x in ("ms_partition", "ms_count", "ms_succ", "ms_build_total")}
     t0 = time.perf_counter(); q_recv = mg.exchange_counts(dist, q_counts, device)
