@@ -168,3 +168,118 @@ int orc_export2(const orc_t *o, uint64_t *keys, uint64_t *keys_hi, uint64_t *sta
 int orc_export(const orc_t *o, uint64_t *keys, uint64_t *stamps, uint32_t *counts) {
     return orc_export2(o, keys, NULL, stamps, counts);
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Multi-threaded variant of the same scan (k <= 31): the CPU baseline of bench.py on ALL host cores.
+ * Hash-partitioned: thread t owns the k-mers whose hash falls into its slice, scans every read, rolls every window
+ * (a shift and an or) and inserts only its own -- no locks, no atomics, nothing shared but the read-only input; each
+ * thread's table grows by doubling.  Same per-node results as orc_build (tests/test_oracle_c.py compares the digest).
+ * out[0] nodes, out[1] distinct edges, out[2] k-mer instances, out[3] edge instances,
+ * out[4] digest = sum over nodes of mix64(key ^ mix64(stamp) ^ mix64(cnt0 + 3 cnt1 + 5 cnt2 + 7 cnt3 + 1)).
+ * ------------------------------------------------------------------------------------------------------------ */
+#include <pthread.h>
+
+typedef struct {
+    const char *bases;
+    const uint64_t *offsets;
+    uint64_t n_reads;
+    int k, t, n_threads, rc;
+    uint64_t out[5];
+} orc_mt_job;
+
+static uint64_t orc_node_digest(uint64_t key, uint64_t stamp, const uint32_t *cnt) {
+    return mix64(key ^ mix64(stamp) ^ mix64((uint64_t)cnt[0] + 3ull * cnt[1] + 5ull * cnt[2] + 7ull * cnt[3] + 1));
+}
+
+static orc_slot *mt_find(orc_slot **ptab, uint64_t *pcap, uint64_t *pn, uint64_t key, uint64_t h) {
+    if ((*pn + 1) * 2 > *pcap) { /* grow: rehash into twice the slots */
+        const uint64_t ncap = *pcap * 2;
+        orc_slot *nt = (orc_slot *)malloc(ncap * sizeof(orc_slot));
+        if (!nt) return NULL;
+        memset(nt, 0xFF, ncap * sizeof(orc_slot));
+        for (uint64_t i = 0; i < *pcap; ++i) {
+            if ((*ptab)[i].key == ~0ULL) continue;
+            uint64_t j = hash_narrow((*ptab)[i].key) & (ncap - 1);
+            while (nt[j].key != ~0ULL) j = (j + 1) & (ncap - 1);
+            nt[j] = (*ptab)[i];
+        }
+        free(*ptab);
+        *ptab = nt;
+        *pcap = ncap;
+    }
+    const uint64_t mask = *pcap - 1;
+    uint64_t j = h & mask;
+    while ((*ptab)[j].key != ~0ULL && (*ptab)[j].key != key) j = (j + 1) & mask;
+    return &(*ptab)[j];
+}
+
+static void *mt_worker(void *arg) {
+    orc_mt_job *jb = (orc_mt_job *)arg;
+    const int k = jb->k;
+    const uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1);
+    uint64_t cap = 1 << 16, n = 0, n_inst = 0, n_einst = 0;
+    orc_slot *tab = (orc_slot *)malloc(cap * sizeof(orc_slot));
+    if (!tab) { jb->rc = -2; return NULL; }
+    memset(tab, 0xFF, cap * sizeof(orc_slot));
+    const uint64_t T = (uint64_t)jb->n_threads, me = (uint64_t)jb->t;
+    for (uint64_t r = 0; r < jb->n_reads; ++r) {
+        const uint64_t beg = jb->offsets[r], len = jb->offsets[r + 1] - beg;
+        if (len <= (uint64_t)k) continue; /* debruijn.py:126 */
+        const unsigned char *s = (const unsigned char *)jb->bases + beg;
+        uint64_t key = 0;
+        for (uint64_t i = 0; i <= len; ++i) {
+            const unsigned char c = i < len ? s[i] : 0;
+            if (i < len && c != 'A' && c != 'C' && c != 'G' && c != 'T') { jb->rc = -1; free(tab); return NULL; }
+            if (i >= (uint64_t)k) {
+                const uint64_t h = hash_narrow(key);
+                if ((((h >> 32) * T) >> 32) == me) { /* this thread's slice of the key space */
+                    const uint64_t pos = i - k;
+                    orc_slot *e = mt_find(&tab, &cap, &n, key, h);
+                    if (!e) { jb->rc = -2; free(tab); return NULL; }
+                    if (e->key == ~0ULL) {
+                        e->key = key;
+                        e->stamp = ((beg + pos) << 1) | (pos != 0);
+                        e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;
+                        ++n;
+                    }
+                    ++n_inst;
+                    if (i < len) { e->cnt[(c >> 1) & 3]++; ++n_einst; }
+                }
+            }
+            key = ((key << 2) | ((c >> 1) & 3)) & kmask;
+        }
+    }
+    uint64_t edges = 0, dig = 0;
+    for (uint64_t i = 0; i < cap; ++i) {
+        if (tab[i].key == ~0ULL) continue;
+        for (int b = 0; b < 4; ++b) edges += tab[i].cnt[b] != 0;
+        dig += orc_node_digest(tab[i].key, tab[i].stamp, tab[i].cnt);
+    }
+    free(tab);
+    jb->out[0] = n; jb->out[1] = edges; jb->out[2] = n_inst; jb->out[3] = n_einst; jb->out[4] = dig;
+    return NULL;
+}
+
+/* 0 on success, -1 byte outside ACGT, -2 allocation or thread failure, -3 bad argument */
+int orc_build_mt(const char *bases, const uint64_t *offsets, uint64_t n_reads, int k, int n_threads, uint64_t *out5) {
+    if (k < 1 || k > 31 || n_threads < 1 || n_threads > 4096 || !out5) return -3;
+    orc_mt_job *jobs = (orc_mt_job *)calloc((size_t)n_threads, sizeof(orc_mt_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    if (!jobs || !th) { free(jobs); free(th); return -2; }
+    int rc = 0, started = 0;
+    for (int t = 0; t < n_threads; ++t) {
+        jobs[t].bases = bases; jobs[t].offsets = offsets; jobs[t].n_reads = n_reads;
+        jobs[t].k = k; jobs[t].t = t; jobs[t].n_threads = n_threads;
+        if (pthread_create(&th[t], NULL, mt_worker, &jobs[t])) { rc = -2; break; }
+        ++started;
+    }
+    for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+    for (int i = 0; i < 5; ++i) out5[i] = 0;
+    for (int t = 0; t < started; ++t) {
+        if (jobs[t].rc && !rc) rc = jobs[t].rc;
+        for (int i = 0; i < 5; ++i) out5[i] += jobs[t].out[i];
+    }
+    free(jobs);
+    free(th);
+    return rc;
+}

@@ -24,6 +24,8 @@ def lib():
             getattr(l, n).argtypes = [C.c_void_p]
         l.orc_export2.restype = C.c_int
         l.orc_export2.argtypes = [C.c_void_p] * 5
+        l.orc_build_mt.restype = C.c_int
+        l.orc_build_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
         _lib = l
     return _lib
 
@@ -52,3 +54,35 @@ def build(bases, offsets, k, export=True):
         return out
     finally:
         l.orc_free(h)
+
+
+M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    x = x.astype(np.uint64)
+    x ^= x >> np.uint64(33); x *= np.uint64(0xff51afd7ed558ccd)
+    x ^= x >> np.uint64(33); x *= np.uint64(0xc4ceb9fe1a85ec53)
+    x ^= x >> np.uint64(33)
+    return x
+
+
+def digest(keys, stamps, counts):
+    """The node digest orc_build_mt returns, from exported arrays (numpy; wraps modulo 2**64)."""
+    with np.errstate(over="ignore"):
+        c = counts.astype(np.uint64)
+        w = c[:, 0] + np.uint64(3) * c[:, 1] + np.uint64(5) * c[:, 2] + np.uint64(7) * c[:, 3] + np.uint64(1)
+        return int(_mix64(keys ^ _mix64(stamps) ^ _mix64(w)).sum(dtype=np.uint64))
+
+
+def build_mt(bases, offsets, k, n_threads):
+    """Multi-threaded build (k <= 31): totals and the node digest only -- bench.py's cpu_baseline on all host cores."""
+    l = lib()
+    b = np.ascontiguousarray(np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else bases)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    out = np.zeros(5, dtype=np.uint64)
+    rc = l.orc_build_mt(b.ctypes.data, o.ctypes.data, o.size - 1, int(k), int(n_threads), out.ctypes.data)
+    if rc:
+        raise ValueError(f"orc_build_mt failed ({rc})")
+    return {"n_nodes": int(out[0]), "n_edges": int(out[1]), "n_kmer_instances": int(out[2]),
+            "n_edge_instances": int(out[3]), "digest": int(out[4])}

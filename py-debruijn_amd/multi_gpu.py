@@ -41,19 +41,42 @@ def exchange_counts(dist, counts, device):
     return [int(x) for x in recv.tolist()]
 
 
-# per (source, destination) pair and call; larger transfers go in rounds.  1 GiB: over nccl a self-copy of 2 GiB - 4 KiB
-# still arrived damaged (one-rank sharded build of 4 M reads at k = 63: 1.77e8 nodes instead of 1.83e8), 1 GiB is exact
+# Largest (source, destination) message of one all_to_all_single call; larger transfers go in rounds.
+# Evidence (tools/nccl_large_msg.py, one rank over nccl = RCCL 2.26.6, profiles/r02_nccl_large_msg.log): a message a
+# rank sends to ITSELF arrives exactly up to 1 GiB; from 1.5 GiB on only its first half is written (1.5 -> 0.75,
+# 2 -> 1, 2.5 -> 1.25, 3 -> 1.5, 4 -> 2 GiB; the rest of the destination keeps its old contents), identically for
+# 1-byte and 8-byte elements and with or without explicit split sizes -- so the loss is a byte-count matter inside
+# RCCL's send-to-self path, not torch's split-size arithmetic.  Consequences here: (1) the self part of every
+# all-to-all is a plain device copy and never goes through the collective; (2) messages to other ranks stay at or below
+# 1 GiB, the largest size seen exact (whether the xGMI path shares the defect cannot be tested on one GPU);
+# (3) every message is checked against a digest of its sender (ExchangeCheck), so a damaged one raises.
 MAX_MESSAGE_BYTES = 1 << 30
 
 
 def _alltoallv_once(dist, tensor, send_counts, recv_counts):
     n_out = sum(recv_counts)
+    send_counts, recv_counts = list(send_counts), list(recv_counts)
     if _is_gloo(dist):
         out = torch.empty(n_out, dtype=tensor.dtype)
-        dist.all_to_all_single(out, tensor.cpu().contiguous(), list(recv_counts), list(send_counts))
+        dist.all_to_all_single(out, tensor.cpu().contiguous(), recv_counts, send_counts)
         return out.to(tensor.device)
     out = torch.empty(n_out, dtype=tensor.dtype, device=tensor.device)
-    dist.all_to_all_single(out, tensor.contiguous(), list(recv_counts), list(send_counts))
+    if dist.get_backend() != "nccl":  # in-process stand-in of the tests
+        dist.all_to_all_single(out, tensor.contiguous(), recv_counts, send_counts)
+        return out
+    # nccl: the message to this rank itself is a device copy, not part of the collective (see MAX_MESSAGE_BYTES);
+    # the others go as views of the two buffers (grouped send / recv, no staging copies)
+    me, w = dist.get_rank(), len(send_counts)
+    tensor = tensor.contiguous()
+    s_off = [sum(send_counts[:d]) for d in range(w)]
+    r_off = [sum(recv_counts[:d]) for d in range(w)]
+    assert send_counts[me] == recv_counts[me]
+    if send_counts[me]:
+        out[r_off[me]:r_off[me] + recv_counts[me]] = tensor[s_off[me]:s_off[me] + send_counts[me]]
+    if w > 1:
+        ins = [tensor[s_off[d]:s_off[d] + (0 if d == me else send_counts[d])] for d in range(w)]
+        outs = [out[r_off[d]:r_off[d] + (0 if d == me else recv_counts[d])] for d in range(w)]
+        dist.all_to_all(outs, ins)
     return out
 
 
