@@ -144,6 +144,26 @@ int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_bytes, const vo
  * zeros for keys and the k-mer of node i is the k bytes at offset stamps[i] >> 1 of the reads). */
 int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint);
 
+/* ---- the same graph in several passes (BASELINE.json configs[3]: more nodes than one 32-bit id space, or than one pass
+ *      should hold in flight).  The reads are cut into records once and split by the 512 top-9-bit groups of the
+ *      bucket hash; pass p builds the groups [p * 512 / n_passes, (p + 1) * 512 / n_passes) into PART p, whose arrays
+ *      stay parked in HBM.  A node id is (part, local id < 2^32 - 16): up to 64 x (2^32 - 16) nodes.  n_passes: a power of two
+ *      up to 64; k <= 31; ACGT reads.  Afterwards dbg_get_sizes reports the totals; the graph is read part by part
+ *      (below); the traversal entry points refuse it (their node ids are 32-bit). */
+int dbg_build_multipass(dbg_t *h, int k, int n_passes);
+int dbg_part_count(dbg_t *h, int *n_parts);
+/* first_node_id: global id of the part's node 0 when the parts are concatenated in order */
+int dbg_part_sizes(dbg_t *h, int part, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *first_node_id);
+/* keys[n], stamps[n], flags[n] (DBG_F_INDEG | bit (1 + code): base `code` is a successor), CSR row_ptr[n + 1] and per
+ * column: col[e] = local id of the successor in part col_part[e], cnt[e] = count of the (k+1)-mer.  The columns of a
+ * row follow the base codes set in flags, ascending.  NULL pointers are skipped. */
+int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *stamps, uint8_t *flags, uint64_t *row_ptr, uint32_t *col,
+                    uint8_t *col_part, uint32_t *cnt);
+/* the same arrays on the device (valid until the next build): stamps are uint32 or uint64 (*stamp_bytes), row_ptr uint32 */
+int dbg_part_device_views(dbg_t *h, int part, const void **d_keys, const void **d_stamps, int *stamp_bytes,
+                          const void **d_flags, const void **d_row_ptr32, const void **d_col, const void **d_col_part,
+                          const void **d_cnt);
+
 /* ---- exact successor order (Counter semantics of debruijn.py:159-165 and :215-216): finds the first
  *      occurrence of every out-edge of the nodes with >= 2 distinct successors (one more pass over the
  *      reads) and rewrites the per-node rank bytes.  Without it equal-count successors are ranked

@@ -31,6 +31,7 @@ SYMBOLS = (
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
+    "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
 )
 
 
@@ -76,6 +77,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not found: build it with py-debruijn_amd/csrc/build.sh "
                       f"(there is no CPU fallback for the device path)")
+    # torch (used for device tensors and torch.distributed, never for compute) bundles its own HIP runtime under the same
+    # SONAME as the system one this library links to.  Whichever is loaded first serves both; torch fails to find a GPU
+    # when it is the second ("No HIP GPUs are available"), so it goes first when it is installed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     u64p, u32p, u8p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
@@ -118,6 +126,11 @@ def load_library():
         "dbg_shard_bucket_counts": (C.c_int, [H, u64p]),
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
+        "dbg_build_multipass": (C.c_int, [H, C.c_int, C.c_int]),
+        "dbg_part_count": (C.c_int, [H, C.POINTER(C.c_int)]),
+        "dbg_part_sizes": (C.c_int, [H, C.c_int, u64p, u64p, u64p]),
+        "dbg_export_part": (C.c_int, [H, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+        "dbg_part_device_views": (C.c_int, [H, C.c_int] + [C.POINTER(vp)] * 2 + [C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5),
         "dbg_shard_apply": (C.c_int, [H, vp]),
         "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp, vp]),
         "dbg_device_keys_hi": (C.c_int, [H, C.POINTER(vp)]),
@@ -349,6 +362,46 @@ class Graph:
         self._chk(self._lib.dbg_export_contigs(self._h, _ptr(off), _ptr(chars), _ptr(score), _ptr(stamp), _ptr(seq)))
         return off, chars, score, stamp, seq
 
+
+    # ---- multi-pass build: graphs beyond one 32-bit id space (BASELINE.json configs[3])
+    def build_multipass(self, k, n_passes):
+        self._chk(self._lib.dbg_build_multipass(self._h, int(k), int(n_passes)))
+
+    def part_count(self):
+        n = C.c_int()
+        self._chk(self._lib.dbg_part_count(self._h, C.byref(n)))
+        return n.value
+
+    def part_sizes(self, part):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._chk(self._lib.dbg_part_sizes(self._h, int(part), C.byref(a), C.byref(b), C.byref(c)))
+        return {"n_nodes": a.value, "n_edges": b.value, "first_node_id": c.value}
+
+    def export_part(self, part):
+        """-> dict(keys, stamps, flags, row_ptr, col, col_part, cnt) of one part (numpy)."""
+        sz = self.part_sizes(part)
+        n, ne = sz["n_nodes"], sz["n_edges"]
+        out = {"keys": np.empty(n, np.uint64), "stamps": np.empty(n, np.uint64), "flags": np.empty(n, np.uint8),
+               "row_ptr": np.empty(n + 1, np.uint64), "col": np.empty(ne, np.uint32), "col_part": np.empty(ne, np.uint8),
+               "cnt": np.empty(ne, np.uint32)}
+        self._chk(self._lib.dbg_export_part(self._h, int(part), *[_ptr(out[x]) for x in
+                                                                   ("keys", "stamps", "flags", "row_ptr", "col", "col_part", "cnt")]))
+        return out
+
+    def part_tensors(self, part):
+        """Zero-copy torch views of one part: keys int64, stamps int32/int64, flags uint8, row_ptr int32 [n + 1],
+        col int32, col_part uint8, cnt int32."""
+        p = [C.c_void_p() for _ in range(7)]
+        sb = C.c_int()
+        self._chk(self._lib.dbg_part_device_views(self._h, int(part), C.byref(p[0]), C.byref(p[1]), C.byref(sb), C.byref(p[2]),
+                                                  C.byref(p[3]), C.byref(p[4]), C.byref(p[5]), C.byref(p[6])))
+        sz, dev = self.part_sizes(part), self.sizes_device()
+        n, ne = sz["n_nodes"], sz["n_edges"]
+        return {"keys": device_tensor(p[0].value, n, "int64", dev),
+                "stamps": device_tensor(p[1].value, n, "int32" if sb.value == 4 else "int64", dev),
+                "flags": device_tensor(p[2].value, n, "uint8", dev), "row_ptr": device_tensor(p[3].value, n + 1, "int32", dev),
+                "col": device_tensor(p[4].value, ne, "int32", dev), "col_part": device_tensor(p[5].value, ne, "uint8", dev),
+                "cnt": device_tensor(p[6].value, ne, "int32", dev)}
 
     # ---- multi-GPU sharding (buffers are torch tensors on this handle's device; see multi_gpu.py)
     def shard_extract(self, k, n_shards):

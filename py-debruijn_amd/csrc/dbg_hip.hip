@@ -126,13 +126,17 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_l2, ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
     uint64_t sk_n_ranges = 0, sk_n_buckets = 0;
     SkGeom sk_geom{};            // hash -> bucket mapping of the last partitioned build (k_succ_resolve)
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
+    void *multipass = nullptr;    // MultiPass (dbg_build_multipass): the parts of the graph, parked in HBM
+    bool wide_owner = false;      // a part of a multi-pass build: successor ids are (owner byte, 32-bit local id), not tagged
+    bool borrowed_stream = false; // sub-handle of a multi-pass build: the stream belongs to the parent
+    uint64_t shard_node_limit = 0;  // option (tests): lowers the 2^29 - 16 node ids a shard may hand out
     bool partial_graph = false;   // the node table is one shard of several: successor ids point into other handles
     // branch k-mer lookup (pull-out reads)
     uint64_t *d_btab = nullptr;
@@ -150,6 +154,7 @@ struct ShardState {
     std::vector<uint64_t> l1_counts;         // records per level-1 bucket (512) of the last dbg_shard_extract
 };
 static ShardState &shard_of(dbg *h);
+static void multipass_free(dbg *h);
 
 static int buf_ensure(dbg *h, dbg::Buf &b, uint64_t bytes) {
     if (bytes == 0) bytes = 16;
@@ -1435,6 +1440,7 @@ __global__ __launch_bounds__(256) void k_text_fill(uint64_t n_chars, G g, const 
 static const char *const kPartialGraph =
     "this handle holds one shard of a multi-GPU build: gather the shards first (multi_gpu.gather_graph / dbg_import_graph)";
 static void free_build(dbg *h) {
+    multipass_free(h);
     dev_free(h->d_tab); dev_free(h->d_occ);
     if (h->nodes_in_arena) {
         h->d_keys = nullptr; h->d_stamps = nullptr; h->d_cnt = nullptr; h->d_flags = nullptr;
@@ -1511,6 +1517,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_misc) buf_free(b);
     for (auto &b : h->ar_csr) buf_free(b);
     buf_free(h->ar_dir);
+    buf_free(h->ar_l2);
     for (auto &b : h->ar_shard) buf_free(b);
     for (auto &b : h->ar_walk) buf_free(b);
     for (auto &b : h->ar_wide) buf_free(b);
@@ -1519,7 +1526,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     buf_free(h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
-    (void)hipStreamDestroy(h->stream);
+    if (!h->borrowed_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -1710,7 +1717,10 @@ static int finish_graph(dbg *h) {
 
 // Engine 0 builds keys + stamps + CSR only (SkCountOut); the dense per-base views the traversal kernels and the
 // exports read are derived here, once, the first time something asks for them.
+static const char *const kMultipassGraph =
+    "this handle holds a multi-pass graph (more nodes than one id space): read it part by part (dbg_part_sizes / dbg_export_part)";
 static int ensure_dense(dbg *h) {
+    if (h->multipass) { h->err = kMultipassGraph; return DBG_E_ARG; }
     if (!h->dense_pending) return DBG_OK;
     const uint64_t n = h->n_nodes, cap = n ? n : 1;
     CHK(buf_ensure(h, h->ar_node[2], cap * 16));
@@ -1742,10 +1752,12 @@ static int ensure_dense(dbg *h) {
 }
 
 // starts = nodes with indegree 0 (debruijn.py:334-336)
+static int multipass_starts(dbg *h, uint64_t *total);
 static int ensure_starts(dbg *h) {
     if (h->starts_known || !h->k) return DBG_OK;
     uint64_t total = 0;
-    CHK(reduce_sum(h, h->n_nodes, FlagSet{h->d_flags, DBG_F_INDEG, 0}, &total));
+    if (h->multipass) CHK(multipass_starts(h, &total));
+    else CHK(reduce_sum(h, h->n_nodes, FlagSet{h->d_flags, DBG_F_INDEG, 0}, &total));
     h->n_starts = total;
     h->starts_known = true;
     return DBG_OK;
@@ -1952,13 +1964,14 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (!h || !name) return DBG_E_ARG;
     const std::string n(name);
     if (n == "engine" && (value == 0 || value == 1)) { h->engine = (int)value; return DBG_OK; }
-    if (n == "bucket_bits" && value >= 0 && value <= 20) { h->bucket_bits = (int)value; return DBG_OK; }
+    if (n == "bucket_bits" && value >= 0 && value <= SK_BUCKET_BITS) { h->bucket_bits = (int)value; return DBG_OK; }
     if (n == "lds_slots" && (value == 2048 || value == 4096)) { h->lds_slots = (int)value; return DBG_OK; }
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     if (n == "estimate_scale_pct" && value >= 1 && value <= 1000) { h->est_scale_pct = (int)value; return DBG_OK; }
     if (n == "target_distinct" && value >= 0 && value <= 4096) { h->target_distinct = (int)value; return DBG_OK; }
     if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
+    if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
 }
@@ -3054,14 +3067,14 @@ struct Presplit {
     const uint64_t *counts = nullptr;     // host, [n_senders][512 / n_shards]: records of (sender, owned level-1 bucket)
     const uint64_t *recv_off = nullptr;   // host, [n_senders]: first record of every sender in the received arrays
     const uint64_t *stamp_add = nullptr;  // host, [n_senders]: 2 x byte offset of the sender's reads in the concatenation
-    const uint32_t *in_st32 = nullptr;    // device: rank-local stamps of the received records
+    const void *in_st = nullptr;          // device: stamps of the received records (STI: rank-local 32-bit in a sharded build)
 };
 
 // ---- stages 2..: records given as segments of (in_w0, in_w1, in_st) -> node arrays + successors.
 // The ping-pong sets w0/w1/st (arena) must hold n_rec records; n_inst bounds the distinct k-mers.
 // shard_bits > 0: only buckets whose top shard_bits equal my_shard hold records (the caller made
 // sure); successors owned by other shards are left as remote queries in ar_shard[0..1].
-template <class ST, int CAP>
+template <class ST, int CAP, class STI = ST>
 static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
                                   uint64_t n_rec, uint64_t n_inst, uint64_t n_edge_inst, const uint64_t *in_w0,
                                   const uint64_t *in_w1, const ST *in_st, uint64_t *w0[2], uint64_t *w1[2], ST *st[2],
@@ -3075,7 +3088,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     // ---- bucket geometry.  Level 1 takes up to 9 bits of the bucket hash; the remaining bits are
     //      chosen after level 1 from a distinct-k-mer estimate on one level-1 bucket (auto mode).
     constexpr double TARGET_DISTINCT = CAP * 0.36;  // mean distinct k-mers per final bucket (table ~1/3 full: measured optimum)
-    constexpr int T_MAX = 20;                       // up to 10 + 10 bits over the two multisplit levels
+    constexpr int T_MAX = 20;                       // provisional geometry: up to 10 + 10 bits; the estimate may add a third level
     const double own = shard_bits ? (double)(1 << shard_bits) : 1.0;  // buckets are spread over `own` shards
     int T = h->bucket_bits;
     const bool auto_T = (T == 0);
@@ -3084,9 +3097,12 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         while (T < T_MAX && (double)(1ull << T) < want) ++T;
     }
     if (T < shard_bits) T = shard_bits;
-    if (pre) T = std::min(19, std::max(9, T));  // the senders split by 9 bits; the second level has at most 1024 children
-    int l1 = T < 9 ? T : (T >= 20 && !pre ? 10 : 9), l2 = T - l1;  // level 1 is fixed before the estimate refines T
+    if (pre) T = std::max(9, T);  // the senders split by 9 bits
+    // level 1 is fixed before the estimate refines the rest; forced geometries take plain bit fields: up to 10 bits at
+    // level 2, what is left (the bucket hash has 22 bits) at level 3
+    int l1 = T < 9 ? T : (T >= 20 && !pre ? 10 : 9), l2 = std::min(10, T - l1);
     int nb2 = 0;                                            // children of the second level (0: not decided yet)
+    int nb3 = (T - l1 - l2) > 0 ? 1 << (T - l1 - l2) : 1;   // children of the third level
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
@@ -3153,28 +3169,46 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             // the second level takes any number of children up to 1024 (all hash bits below level 1, scaled): the
             // bucket count follows the estimate instead of jumping by powers of two
             const double want = distinct / ((double)h->target_distinct > 0 ? (double)h->target_distinct : TARGET_DISTINCT);
-            nb2 = (int)std::min<double>(1024.0, std::max<double>(1.0, std::ceil(want / nb1)));
+            const double want2 = std::max<double>(1.0, std::ceil(want / nb1));
+            if (want2 <= 1024.0) {
+                nb2 = (int)want2;
+                nb3 = 1;
+            } else {  // more than 1024 children per level-1 group: a plain 10-bit second level and a third one below it
+                nb2 = 1024;
+                nb3 = (int)std::min<double>((double)(1 << (SK_BUCKET_BITS - l1 - 10)), std::ceil(want2 / 1024.0));
+            }
             l2 = nb2 > 1 ? 1 : 0;  // "there is a second level"
         }
     }
     if (nb2 == 0 && l2 > 0) nb2 = 1 << l2;  // forced or small geometries: a power of two, plain bit fields
     if (pre && l2 == 0) { l2 = 1; nb2 = 1; }  // the received records still have to be gathered bucket by bucket
-    const int fb2 = (nb2 > 0 && (nb2 & (nb2 - 1)) != 0) || (auto_T && l1 >= 9 && nb2 > 1) ? SK_BUCKET_BITS - l1 : 0;
-    const uint64_t n_buckets = l2 > 0 ? (uint64_t)nb1 * (uint64_t)nb2 : (uint64_t)nb1;
+    if (l2 == 0) nb3 = 1;
+    // the second level is a scaled field over ALL hash bits below level 1 unless a third level needs the low ones
+    const int fb2 = (nb3 == 1 && ((nb2 > 0 && (nb2 & (nb2 - 1)) != 0) || (auto_T && l1 >= 9 && nb2 > 1))) ? SK_BUCKET_BITS - l1 : 0;
+    const uint64_t n_l2 = l2 > 0 ? (uint64_t)nb1 * (uint64_t)nb2 : (uint64_t)nb1;  // buckets after level 2
+    const uint64_t n_buckets = n_l2 * (uint64_t)nb3;
     T = 0;
     while ((1ull << T) < n_buckets) ++T;  // only for reporting
     const int l2_pow = (fb2 || l2 == 0) ? 0 : (int)std::lround(std::log2((double)nb2));  // second level as plain bits
+    const int fb3 = nb3 > 1 ? SK_BUCKET_BITS - l1 - l2_pow : 0;  // level 3: the hash bits below levels 1 and 2, scaled into [0, nb3)
     CHK(buf_ensure(h, h->ar_misc[5], n_buckets * 16));
     uint64_t *b_start = (uint64_t *)h->ar_misc[5].p, *b_cnt = b_start + n_buckets;
+    uint64_t *l2_start = b_start, *l2_cnt = b_cnt;  // children of level 2: the final buckets unless a third level follows
+    if (nb3 > 1) {
+        CHK(buf_ensure(h, h->ar_l2, n_l2 * 16));
+        l2_start = (uint64_t *)h->ar_l2.p;
+        l2_cnt = l2_start + n_l2;
+    }
     if (l2 > 0) {
         const int sh2 = fb2 ? top - SK_BUCKET_BITS : top - l1 - l2_pow;
         if (pre) {
             // only the level-1 buckets this shard owns have records: their children sit at [b_lo * nb2, ...)
             HIPCHK(h, hipMemsetAsync(b_start, 0, n_buckets * 16, h->stream));
+            if (nb3 > 1) HIPCHK(h, hipMemsetAsync(l2_start, 0, n_l2 * 16, h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_scalars + 56, 0, 16, h->stream));
-            CHK((multisplit_level<ST, true, uint32_t>(h, ps_start, ps_cnt, ps_n, (uint32_t)pre->n_senders, n_rec, in_w0, in_w1,
-                                                      pre->in_st32, w0[0], w1[0], st[0], sh2, nb2, b_start + b_lo * nb2,
-                                                      b_cnt + b_lo * nb2, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2,
+            CHK((multisplit_level<ST, true, STI>(h, ps_start, ps_cnt, ps_n, (uint32_t)pre->n_senders, n_rec, in_w0, in_w1,
+                                                      (const STI *)pre->in_st, w0[0], w1[0], st[0], sh2, nb2, l2_start + b_lo * nb2,
+                                                      l2_cnt + b_lo * nb2, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2,
                                                       ps_add, (unsigned long long *)(h->d_scalars + 56))));
             uint64_t sums[2] = {0, 0};
             HIPCHK(h, hipMemcpyAsync(sums, h->d_scalars + 56, 16, hipMemcpyDeviceToHost, h->stream));
@@ -3185,9 +3219,22 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             h->n_edge_inst = n_edge_inst;
         } else {
             CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, 1, n_rec, w0[1], w1[1], st[1], w0[0], w1[0],
-                                            st[0], sh2, nb2, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
+                                            st[0], sh2, nb2, l2_start, l2_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
         }
         where = 0;
+        if (nb3 > 1) {  // third level: every level-2 child (of the groups this build owns) is split once more
+            if (!w0[1]) {  // callers that start at level 2 bring one record set only
+                CHK(buf_ensure(h, h->ar_rec[1][0], (n_rec + 16) * 8));
+                CHK(buf_ensure(h, h->ar_rec[1][1], (n_rec + 16) * 8));
+                CHK(buf_ensure(h, h->ar_rec[1][2], (n_rec + 16) * sizeof(ST)));
+                w0[1] = (uint64_t *)h->ar_rec[1][0].p; w1[1] = (uint64_t *)h->ar_rec[1][1].p; st[1] = (ST *)h->ar_rec[1][2].p;
+            }
+            const uint64_t p_lo = pre ? b_lo * nb2 : 0, p_n = pre ? (uint64_t)bps * nb2 : n_l2;
+            CHK((multisplit_level<ST, true>(h, l2_start + p_lo, l2_cnt + p_lo, (uint32_t)p_n, 1, n_rec, w0[0], w1[0], st[0], w0[1],
+                                            w1[1], st[1], top - SK_BUCKET_BITS, nb3, b_start + p_lo * nb3, b_cnt + p_lo * nb3,
+                                            h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb3)));
+            where = 1;
+        }
     } else {
         HIPCHK(h, hipMemcpyAsync(b_start, c1_start, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(b_cnt, c1_cnt, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
@@ -3198,7 +3245,10 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     // ---- K5: per-bucket counting.  Node and edge arrays are sized from the distinct-k-mer estimate (58 B per node:
     //      the worst case "every instance distinct" would not fit the HBM beyond ~3e9 instances); if the estimate
     //      was low the kernel reports it and the second attempt takes the worst case.
-    const uint64_t id_limit = shard_bits ? ((1ull << 29) - 16) : 0xFFFFFFF0ull;  // sharded ids carry the owner in bits 31:29
+    // sharded ids carry the owner in bits 31:29; the parts of a multi-pass build keep it in a byte of its own
+    const uint64_t id_limit = (shard_bits && !h->wide_owner) ? (h->shard_node_limit ? h->shard_node_limit : (1ull << 29) - 16)
+                                                             : 0xFFFFFFF0ull;
+    const uint32_t id_tag = (shard_bits && !h->wide_owner) ? ((uint32_t)my_shard << 29) : 0u;
     const uint64_t node_cap_max = std::min<uint64_t>(n_inst, id_limit);
     const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
     uint64_t node_cap = node_capacity_hint ? std::min<uint64_t>(node_capacity_hint, id_limit) : node_cap_max;
@@ -3230,7 +3280,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     const uint64_t range_cap = n_buckets + 4096 + n_inst / (CAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
-    CHK(buf_ensure(h, h->ar_dir, range_cap * (CAP / 64) * sizeof(SkDirEnt)));
+    // buckets this build owns (a shard or a pass owns 1 / 2^shard_bits of the level-1 groups): only they get a directory
+    const uint64_t own_cnt = n_buckets >> shard_bits, own_lo = (uint64_t)my_shard * own_cnt;
+    CHK(buf_ensure(h, h->ar_dir, (own_cnt + (range_cap - n_buckets)) * (CAP / 64) * sizeof(SkDirEnt)));
     SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
     for (int attempt = 0; attempt < 3; ++attempt) {
         CHK(ensure_node_arrays());
@@ -3247,8 +3299,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
         SkCountOut out{h->d_keys, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
-                       qk[0], qc[0], q_cap, ranges, n_buckets, range_cap, dirs,
-                       shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev};
+                       qk[0], qc[0], q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, id_tag, sc_dev};
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3262,8 +3313,12 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             static_assert(sizeof(SkCountOut) <= 64 * 8, "descriptor slot");
             SkCountOut *d_out = (SkCountOut *)(h->d_scalars + 64);
             HIPCHK(h, hipMemcpyAsync(d_out, &out, sizeof(out), hipMemcpyHostToDevice, h->stream));
+            // records beyond which a bucket starts in hash sub-ranges: ~2800 distinct k-mers (two thirds of the table)
+            uint32_t split_recs = 0;
+            if (est_distinct > 0.0 && n_rec)
+                split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(64.0, (CAP * 0.68) / (est_distinct / (double)n_rec)));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
-                               st[where], k, m, n_buckets, (const SkCountOut *)d_out, h->phase_limit);
+                               st[where], k, m, n_buckets, (const SkCountOut *)d_out, split_recs, h->phase_limit);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;
@@ -3296,7 +3351,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     uint64_t n_q = sc[5];
     const uint64_t n_ranges = n_buckets + sc[6];
     h->stats.n_queries = n_q;
-    SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, shard_bits, my_shard};
+    SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, nb3, fb3, shard_bits, my_shard, own_lo, own_cnt};
 
     // ---- K6: successors that live in another bucket.  Of this shard: the asker looks them up through the target
     //      range's directory (k_succ_resolve).  Of another shard: grouped by owner and parked for the exchange.
@@ -3307,7 +3362,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (shard_bits && n_q) {  // group by owner shard = top shard_bits of the bucket hash
             hipLaunchKernelGGL(k_q_bucket, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, qk[0], qm[0], n_q, k, m);
             HIPCHK(h, hipGetLastError());
-            CHK(buf_ensure(h, h->ar_misc[7], 64 * 16 + 16));
+            CHK(buf_ensure(h, h->ar_misc[7], 512 * 16 + 16));
             uint64_t *q_seg = (uint64_t *)h->ar_misc[7].p;  // [0..1]: one input segment; [2..]: per-owner children
             const int nsh = 1 << shard_bits;
             HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
@@ -3336,7 +3391,7 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (n_q) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_succ_resolve<CAP>), dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream,
                                qk[qset] + root[0], qc[qset] + root[0], n_q, geom, ranges, n_buckets, n_ranges, dirs, h->d_keys,
-                               h->n_nodes, h->d_col, shard_bits ? ((uint32_t)my_shard << 29) : 0u, sc_dev);
+                               h->n_nodes, h->d_col, id_tag, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -3667,11 +3722,11 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
         pre.counts = sender_bucket_counts;
         pre.recv_off = seg.data();
         pre.stamp_add = add.data();
-        pre.in_st32 = (const uint32_t *)d_st32;
+        pre.in_st = d_st32;
         const int w = k - sk_m_for_k(k) + 1;  // a record holds at most w k-mers
-        rc = sk_count_from_segments<uint64_t, 4096>(h, k, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w, n_rec * (uint64_t)w,
-                                                    (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)nullptr, w0,
-                                                    w1, st, 0, shard_bits, my_shard, &pre);
+        rc = sk_count_from_segments<uint64_t, 4096, uint32_t>(h, k, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w,
+                                                              n_rec * (uint64_t)w, (const uint64_t *)d_w0, (const uint64_t *)d_w1,
+                                                              (const uint64_t *)nullptr, w0, w1, st, 0, shard_bits, my_shard, &pre);
         n_inst = h->n_kmer_inst;
         n_edge = h->n_edge_inst;
     } else {
@@ -3885,4 +3940,321 @@ extern "C" int dbg_shard_apply(dbg_t *h, const void *d_answers) {
     if (sc0 & 256) { h->err = "a remote successor came back unresolved"; return DBG_E_HIP; }
     h->stats.ms_succ += t.stop();
     return finish_graph(h);
+}
+
+// ==========================================================================================
+// Multi-pass build (BASELINE.json configs[3]: "multi-pass radix buckets spilled to HBM"): graphs with more nodes
+// than one 32-bit id space, or than the working set of one pass should hold.
+// The reads are cut into super-k-mer records ONCE and split by the 512 level-1 buckets; the records stay parked
+// in HBM.  Pass p then builds the node table of the level-1 buckets [p * 512 / P, (p + 1) * 512 / P) exactly like
+// the owner of a shard does (second multisplit level -> per-bucket LDS count -> CSR), into arrays of its own that
+// stay parked as well: part p of the graph.  A node id is (part, local id); a CSR column holds the local id and a
+// byte beside it the part, so the graph may hold up to 256 x (2^32 - 16) nodes.  Successors that live in another
+// part are resolved after the last pass through that part's directories (k_succ_resolve).
+// ==========================================================================================
+struct MultiPass {
+    int n_passes = 0;
+    std::vector<dbg *> part;
+    std::vector<uint8_t *> col_owner;  // per part: [n_edges of the part] owner part of every CSR column
+    std::vector<uint64_t> base;        // global id of the part's first node (prefix sums of the part sizes)
+};
+
+// A finished part keeps only what later reads need -- node arrays, CSR, ranges and directory -- cut to their real
+// sizes (they were sized from an estimate, x 1.2): the parts are parked in HBM side by side.
+static int buf_shrink(dbg *h, dbg::Buf &b, uint64_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (!b.p || b.bytes <= bytes + (16ull << 20)) return DBG_OK;
+    void *p = nullptr;
+    HIPCHK(h, hipMalloc(&p, bytes));
+    hipError_t e = hipMemcpyAsync(p, b.p, bytes, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { (void)hipFree(p); h->err = std::string("buf_shrink: ") + hipGetErrorString(e); return DBG_E_HIP; }
+    (void)hipFree(b.p);
+    b.p = p;
+    b.bytes = bytes;
+    return DBG_OK;
+}
+
+static int part_compact(dbg *sub, uint64_t n_dir_entries) {
+    const uint64_t n = sub->n_nodes, ne = sub->n_edges;
+    const int st_slot = sub->stamps_st_bytes == 8 ? 1 : 7;
+    CHK(buf_shrink(sub, sub->ar_node[0], n * 8));
+    CHK(buf_shrink(sub, sub->ar_node[st_slot], n * (uint64_t)sub->stamps_st_bytes));
+    CHK(buf_shrink(sub, sub->ar_node[3], n));
+    CHK(buf_shrink(sub, sub->ar_csr[3], (n + 1) * 4));
+    CHK(buf_shrink(sub, sub->ar_csr[1], ne * 4));
+    CHK(buf_shrink(sub, sub->ar_csr[2], ne * 4));
+    CHK(buf_shrink(sub, sub->ar_dir, n_dir_entries * sizeof(SkDirEnt)));
+    CHK(buf_shrink(sub, sub->ar_misc[6], sub->sk_n_ranges * sizeof(SkRange)));
+    sub->d_keys = (uint64_t *)sub->ar_node[0].p;
+    sub->d_stamps_st = sub->ar_node[st_slot].p;
+    if (sub->stamps_st_bytes == 8) sub->d_stamps = (uint64_t *)sub->d_stamps_st;
+    sub->d_flags = (uint8_t *)sub->ar_node[3].p;
+    sub->d_rowptr32 = (uint32_t *)sub->ar_csr[3].p;
+    sub->d_col = (uint32_t *)sub->ar_csr[1].p;
+    sub->d_ecnt = (uint32_t *)sub->ar_csr[2].p;
+    for (auto &lvl : sub->ar_rec) for (auto &b : lvl) buf_free(b);
+    for (auto &lvl : sub->ar_q) for (auto &b : lvl) buf_free(b);
+    for (int i : {0, 1, 2, 3, 4, 5, 7, 8}) buf_free(sub->ar_misc[i]);
+    buf_free(sub->ar_scan);
+    sub->sk_src.valid = false;
+    return DBG_OK;
+}
+
+static void multipass_free(dbg *h) {
+    MultiPass *mp = (MultiPass *)h->multipass;
+    if (!mp) return;
+    for (auto *o : mp->col_owner) if (o) (void)hipFree(o);
+    for (dbg *sub : mp->part) if (sub) dbg_destroy(sub);
+    delete mp;
+    h->multipass = nullptr;
+}
+
+static int multipass_starts(dbg *h, uint64_t *total) {
+    MultiPass *mp = (MultiPass *)h->multipass;
+    *total = 0;
+    for (dbg *sub : mp->part) {
+        uint64_t t = 0;
+        if (sub->n_nodes) CHK(reduce_sum(h, sub->n_nodes, FlagSet{sub->d_flags, DBG_F_INDEG, 0}, &t));
+        *total += t;
+    }
+    return DBG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_apply_part(const uint32_t *__restrict__ qcol, const uint32_t *__restrict__ ans,
+                                                    uint64_t n, uint8_t owner, uint32_t *col, uint8_t *col_owner,
+                                                    unsigned long long *scalars) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = ans[i];
+    if (a == NO_NODE) { atomicOr(&scalars[0], 256ull); return; }
+    col[qcol[i]] = a;
+    col_owner[qcol[i]] = owner;
+}
+
+template <class ST>
+static int build_multipass_t(dbg *h, int k, int n_passes) {
+    uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
+    ST *st[2];
+    uint32_t n_seg = 0;
+    CHK(sk_extract<ST>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    const int nb1 = 512;
+    CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+    uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
+    std::vector<uint64_t> cnt(nb1), start(nb1);
+    {
+        Timer t(h->stream);
+        CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+                                        6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3],
+                                        h->ar_misc[4])));
+        HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(start.data(), c1_start, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
+        h->stats.ms_partition = t.stop();
+        for (auto &b : h->ar_rec[0]) buf_free(b);  // the unsplit records; the split ones (set 1) stay parked for the passes
+    }
+    int shard_bits = 0;
+    while ((1 << shard_bits) < n_passes) ++shard_bits;
+    const int bps = nb1 / n_passes;
+    MultiPass *mp = new MultiPass();
+    h->multipass = mp;
+    mp->n_passes = n_passes;
+    mp->part.assign(n_passes, nullptr);
+    mp->col_owner.assign(n_passes, nullptr);
+    mp->base.assign(n_passes + 1, 0);
+    const int w = k - sk_m_for_k(k) + 1;
+    double ms_count = 0, ms_part = h->stats.ms_partition, ms_succ = 0;
+    uint64_t n_buckets = 0, n_queries = 0;
+    for (int p = 0; p < n_passes; ++p) {
+        dbg *sub = new (std::nothrow) dbg();
+        if (!sub) return DBG_E_NOMEM;
+        mp->part[p] = sub;
+        sub->device = h->device;
+        sub->stream = h->stream;
+        sub->borrowed_stream = true;
+        sub->wide_owner = true;
+        sub->bucket_bits = h->bucket_bits;
+        sub->target_distinct = h->target_distinct;
+        sub->est_scale_pct = h->est_scale_pct;
+        HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));
+        sub->k = k;
+        uint64_t n_rec_p = 0;
+        for (int b = 0; b < bps; ++b) n_rec_p += cnt[(size_t)p * bps + b];
+        // level-2 output of this pass (one set: the presplit path writes set 0 only); freed again below
+        uint64_t *pw0[2] = {nullptr, nullptr}, *pw1[2] = {nullptr, nullptr};
+        ST *pst[2] = {nullptr, nullptr};
+        CHK(buf_ensure(sub, sub->ar_rec[0][0], (n_rec_p + 16) * 8));
+        CHK(buf_ensure(sub, sub->ar_rec[0][1], (n_rec_p + 16) * 8));
+        CHK(buf_ensure(sub, sub->ar_rec[0][2], (n_rec_p + 16) * sizeof(ST)));
+        pw0[0] = (uint64_t *)sub->ar_rec[0][0].p; pw1[0] = (uint64_t *)sub->ar_rec[0][1].p; pst[0] = (ST *)sub->ar_rec[0][2].p;
+        ShardState &sh = shard_of(sub);
+        sh.n_shards = n_passes; sh.my_shard = p; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
+        sh.q_start.assign(n_passes, 0);
+        sh.q_cnt.assign(n_passes, 0);
+        const uint64_t off0 = start[(size_t)p * bps], add0 = 0;
+        Presplit pre;
+        pre.n_senders = 1;
+        pre.counts = &cnt[(size_t)p * bps];
+        pre.recv_off = &off0;
+        pre.stamp_add = &add0;
+        pre.in_st = st[1];
+        int rc = DBG_OK;
+        if (n_rec_p)
+            rc = sk_count_from_segments<ST, 4096, ST>(sub, k, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w,
+                                                      w0[1], w1[1], (const ST *)nullptr, pw0, pw1, pst, 0, shard_bits, p, &pre);
+        if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
+        if (n_rec_p) {
+            const uint64_t own_cnt = sub->sk_n_buckets >> shard_bits;
+            rc = part_compact(sub, (own_cnt + (sub->sk_n_ranges - sub->sk_n_buckets)) * (4096 / 64));
+            if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
+        }
+        mp->base[p + 1] = mp->base[p] + sub->n_nodes;
+        if (sub->n_edges) {
+            HIPCHK(h, hipMalloc((void **)&mp->col_owner[p], sub->n_edges));
+            HIPCHK(h, hipMemsetAsync(mp->col_owner[p], p, sub->n_edges, h->stream));
+        }
+        ms_count += sub->stats.ms_count; ms_part += sub->stats.ms_partition; ms_succ += sub->stats.ms_succ;
+        n_buckets += sub->stats.n_buckets >> shard_bits; n_queries += sub->stats.n_queries;
+        h->stats.count_launches += sub->stats.count_launches;
+    }
+    // ---- successors owned by another part: the asker's queries are grouped by owner (ShardState), the owner's
+    //      directory answers them
+    {
+        Timer t(h->stream);
+        uint64_t max_q = 0;
+        for (int p = 0; p < n_passes; ++p) {
+            ShardState &sh = shard_of(mp->part[p]);
+            for (int q = 0; q < n_passes; ++q) if (q != p) max_q = std::max(max_q, sh.q_cnt[q]);
+        }
+        CHK(buf_ensure(h, h->ar_shard[2], (max_q + 16) * 4));
+        uint32_t *ans = (uint32_t *)h->ar_shard[2].p;
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+        for (int p = 0; p < n_passes; ++p) {
+            dbg *sub = mp->part[p];
+            ShardState &sh = shard_of(sub);
+            const uint64_t *keys = (const uint64_t *)sub->ar_shard[0].p;
+            const uint32_t *qcol = (const uint32_t *)sub->ar_shard[3].p;
+            for (int q = 0; q < n_passes; ++q) {
+                if (q == p || !sh.q_cnt[q]) continue;
+                int rc = dbg_shard_answer(mp->part[q], keys + sh.q_start[q], sh.q_cnt[q], ans);
+                if (rc != DBG_OK) { h->err = "part " + std::to_string(q) + ": " + mp->part[q]->err; return rc; }
+                hipLaunchKernelGGL(k_apply_part, dim3(grid_for(sh.q_cnt[q], 256)), dim3(256), 0, h->stream, qcol + sh.q_start[q],
+                                   ans, sh.q_cnt[q], (uint8_t)q, sub->d_col, mp->col_owner[p], (unsigned long long *)h->d_scalars);
+            }
+            buf_free(sub->ar_shard[0]);
+            buf_free(sub->ar_shard[3]);
+        }
+        HIPCHK(h, hipGetLastError());
+        uint64_t sc0 = 0;
+        HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (sc0 & 256) { h->err = "a successor in another part came back unresolved"; return DBG_E_HIP; }
+        ms_succ += t.stop();
+    }
+    for (auto &b : h->ar_rec[1]) buf_free(b);  // every pass has read its slice of the parked records
+    h->n_nodes = mp->base[n_passes];
+    h->n_edges = 0;
+    for (dbg *sub : mp->part) h->n_edges += sub->n_edges;
+    h->stats.ms_count = ms_count; h->stats.ms_partition = ms_part; h->stats.ms_succ = ms_succ;
+    h->stats.n_buckets = n_buckets; h->stats.n_queries = n_queries;
+    h->starts_known = false;
+    return DBG_OK;
+}
+
+extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
+    if (!h) return DBG_E_ARG;
+    if (k < 1 || k > 31) { h->err = "multi-pass builds take k in 1..31 (one-word k-mers)"; return DBG_E_ARG; }
+    if (n_passes < 1 || n_passes > 64 || (n_passes & (n_passes - 1))) { h->err = "n_passes must be a power of two up to 64"; return DBG_E_ARG; }
+    if (!h->d_offsets) { h->err = "no reads set"; return DBG_E_ARG; }
+    if (h->engine != 0) { h->err = "multi-pass builds use the super-k-mer engine"; return DBG_E_ARG; }
+    if (h->bucket_bits && h->bucket_bits < 9) { h->err = "multi-pass builds split by 9 bits first: bucket_bits must be 0 or >= 9"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    free_build(h);
+    h->stats = dbg_stats_t{};
+    CHK(compute_alphabet(h));
+    if (!h->is_dna) { h->err = "multi-pass builds take ACGT reads"; return DBG_E_ALPHABET; }
+    h->k = k;
+    Timer t_total(h->stream);
+    int rc = (h->n_bytes < (1ull << 31)) ? build_multipass_t<uint32_t>(h, k, n_passes) : build_multipass_t<uint64_t>(h, k, n_passes);
+    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+    h->stats.ms_build_total = t_total.stop();
+    return DBG_OK;
+}
+
+extern "C" int dbg_part_count(dbg_t *h, int *n_parts) {
+    if (!h || !n_parts) return DBG_E_ARG;
+    *n_parts = h->multipass ? ((MultiPass *)h->multipass)->n_passes : 0;
+    return DBG_OK;
+}
+
+extern "C" int dbg_part_sizes(dbg_t *h, int part, uint64_t *n_nodes, uint64_t *n_edges, uint64_t *first_node_id) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp || part < 0 || part >= mp->n_passes) { if (h) h->err = "no such part (dbg_build_multipass must run first)"; return DBG_E_ARG; }
+    if (n_nodes) *n_nodes = mp->part[part]->n_nodes;
+    if (n_edges) *n_edges = mp->part[part]->n_edges;
+    if (first_node_id) *first_node_id = mp->base[part];
+    return DBG_OK;
+}
+
+template <class ST>
+__global__ __launch_bounds__(256) void k_widen(const ST *__restrict__ in, uint64_t n, uint64_t *out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint64_t)in[i];
+}
+
+extern "C" int dbg_part_device_views(dbg_t *h, int part, const void **d_keys, const void **d_stamps, int *stamp_bytes,
+                                     const void **d_flags, const void **d_row_ptr32, const void **d_col, const void **d_col_part,
+                                     const void **d_cnt) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp || part < 0 || part >= mp->n_passes) { if (h) h->err = "no such part (dbg_build_multipass must run first)"; return DBG_E_ARG; }
+    dbg *sub = mp->part[part];
+    if (d_keys) *d_keys = sub->d_keys;
+    if (d_stamps) *d_stamps = sub->d_stamps_st;
+    if (stamp_bytes) *stamp_bytes = sub->stamps_st_bytes;
+    if (d_flags) *d_flags = sub->d_flags;
+    if (d_row_ptr32) *d_row_ptr32 = sub->d_rowptr32;
+    if (d_col) *d_col = sub->d_col;
+    if (d_col_part) *d_col_part = mp->col_owner[part];
+    if (d_cnt) *d_cnt = sub->d_ecnt;
+    return DBG_OK;
+}
+
+extern "C" int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *stamps, uint8_t *flags, uint64_t *row_ptr,
+                               uint32_t *col, uint8_t *col_part, uint32_t *cnt) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp || part < 0 || part >= mp->n_passes) { if (h) h->err = "no such part (dbg_build_multipass must run first)"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    dbg *sub = mp->part[part];
+    const uint64_t n = sub->n_nodes, ne = sub->n_edges;
+    D2H(h, keys, sub->d_keys, n * 8);
+    D2H(h, flags, sub->d_flags, n);
+    D2H(h, col, sub->d_col, ne * 4);
+    D2H(h, col_part, mp->col_owner[part], ne);
+    D2H(h, cnt, sub->d_ecnt, ne * 4);
+    uint64_t *tmp = nullptr;
+    if ((stamps && n) || row_ptr) {
+        CHK(dev_alloc(h, &tmp, n + 1));
+        if (stamps && n) {
+            if (sub->stamps_st_bytes == 4)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_widen<uint32_t>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream,
+                                   (const uint32_t *)sub->d_stamps_st, n, tmp);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_widen<uint64_t>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream,
+                                   (const uint64_t *)sub->d_stamps_st, n, tmp);
+            hipError_t e = hipMemcpyAsync(stamps, tmp, n * 8, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); h->err = hipGetErrorString(e); return DBG_E_HIP; }
+        }
+        if (row_ptr) {
+            if (n || true)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_widen<uint32_t>), dim3(grid_for(n + 1, 256)), dim3(256), 0, h->stream,
+                                   (const uint32_t *)sub->d_rowptr32, n + 1, tmp);
+            hipError_t e = hipMemcpyAsync(row_ptr, tmp, (n + 1) * 8, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); h->err = hipGetErrorString(e); return DBG_E_HIP; }
+        }
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return DBG_E_HIP; }
+    return DBG_OK;
 }

@@ -644,11 +644,13 @@ __global__ __launch_bounds__(256) void k_estimate_distinct(const uint64_t *__res
 // ------------------------------------------------------------------------------------------------
 // K5: per-bucket counting in LDS.
 // ------------------------------------------------------------------------------------------------
-struct SkRange {            // one successfully counted (bucket, hash sub-range): consumed by k_q_answer
+struct SkRange {            // one successfully counted (bucket, hash sub-range)
     uint32_t bucket;
     uint32_t mask, val;     // k-mers with (sub_hash & mask) == val
     uint32_t node_cnt;
     uint64_t node_base;
+    uint32_t next;          // buckets counted in sub-ranges: chain of their ranges, headed by ranges[bucket].next (0 = end)
+    uint32_t pad;
 };
 
 __device__ inline uint32_t fold32(uint64_t kmer) { return (uint32_t)kmer * 0x9E3779B1u ^ (uint32_t)(kmer >> 32) * 0x85EBCA77u; }
@@ -745,7 +747,8 @@ struct SkCountOut {
     SkRange *ranges;        // [0, n_buckets): the unsplit range of each bucket; beyond: ranges of split buckets
     uint64_t n_buckets;
     uint64_t range_cap;
-    SkDirEnt *dirs;            // [range_cap][CAP / 64]
+    SkDirEnt *dirs;            // [own_cnt + extra ranges][CAP / 64]: only the buckets this build owns have a directory
+    uint64_t own_lo, own_cnt;  // buckets [own_lo, own_lo + own_cnt) (everything for a single-GPU build)
     uint32_t id_tag;           // OR-ed into every successor id written (sharded builds: owner << 29)
     unsigned long long *scalars;  // [0] err [4] packed cursor: nodes (low 32) | edges (high 32) [5] queries [6] extra ranges
 };
@@ -810,7 +813,11 @@ template <class ST, int CAP>
 __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
                                                      const ST *__restrict__ rec_st, int k, int m, uint64_t n_buckets,
-                                                     const SkCountOut *__restrict__ outp, int phase_limit /* ablation only: 0 = run everything */) {
+                                                     const SkCountOut *__restrict__ outp, uint32_t split_recs,
+                                                     int phase_limit /* ablation only: 0 = run everything */) {
+    // split_recs: a bucket with more records than this is counted in 2^j hash sub-ranges from the start (the host
+    // knows the distinct k-mers per record): finding out by overflowing the table first costs a full insert pass
+    // with probe runs through a full table -- per level of the split
     // Persistent: one workgroup per CU walks buckets blockIdx.x, blockIdx.x + gridDim.x, ...  The table
     // stays in LDS across buckets: the node write clears exactly the slots it reads (a third of the
     // table), and the next bucket's records are prefetched into registers while this bucket is in
@@ -869,6 +876,14 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
         // common case (the whole bucket fits the table) never touches LDS for it.
         uint32_t stk_n = 1;
         bool root = true, failed = false;
+        if (split_recs && r_n > split_recs) {  // uniform
+            uint32_t parts = 2;
+            while (parts < 16 && (uint64_t)parts * split_recs < r_n) parts <<= 1;
+            if (threadIdx.x < parts) { s.stk_mask[threadIdx.x] = parts - 1; s.stk_val[threadIdx.x] = threadIdx.x; }
+            stk_n = parts;
+            root = false;
+            __syncthreads();
+        }
         while (stk_n) {
             uint32_t cur_mask = 0, cur_val = 0;
             --stk_n;
@@ -1106,12 +1121,17 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 uint64_t ri = bucket;
                 if (cur_mask) {
                     ri = orr.n_buckets + atomicAdd(&orr.scalars[6], 1ull);
-                    if (ri >= orr.range_cap) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
+                    if (ri >= orr.range_cap || ri >= 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
                 }
                 s.ri = ri;
                 if (!s.fail) {
                     SkRange rg;
                     rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
+                    rg.next = 0; rg.pad = 0;
+                    if (cur_mask) {  // link it into the bucket's chain (this workgroup is the only writer of the bucket's ranges)
+                        rg.next = orr.ranges[bucket].next;
+                        orr.ranges[bucket].next = (uint32_t)ri;
+                    }
                     orr.ranges[ri] = rg;
                 }
             }
@@ -1135,7 +1155,8 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 de.mask = s.dir_mask[threadIdx.x];
                 de.base = (uint32_t)(gbase + s.dir_base[threadIdx.x]);
                 de.pad = 0;
-                ow.dirs[s.ri * (CAP / 64) + threadIdx.x] = de;
+                const uint64_t di = s.ri < ow.n_buckets ? s.ri - ow.own_lo : ow.own_cnt + (s.ri - ow.n_buckets);
+                ow.dirs[di * (CAP / 64) + threadIdx.x] = de;
             }
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
@@ -1227,16 +1248,23 @@ struct SkGeom {
     int nb2;      // children of level 2 (1: no second level)
     int fb2;      // != 0: level 2 scales the fb2 low bits of the hash into [0, nb2); 0: plain bit field of l2_pow bits
     int l2_pow;
+    int nb3, fb3; // level 3 (nb3 > 1: level 2 is a plain l2_pow-bit field): the fb3 hash bits below it scaled into [0, nb3)
     int shard_bits, my_shard;  // sharded builds: owner = top shard_bits of the hash
+    uint64_t own_lo, own_cnt;  // the buckets this build owns: [own_lo, own_lo + own_cnt) -- the directory holds only those
 };
 
 __host__ __device__ inline uint64_t sk_bucket_of(uint32_t bh, const SkGeom &g) {
     const uint32_t b1 = g.l1 ? bh >> (SK_BUCKET_BITS - g.l1) : 0u;
-    if (g.nb2 <= 1) return b1;
-    uint32_t b2;
+    if (g.nb2 <= 1 && g.nb3 <= 1) return b1;
+    uint32_t b2 = 0;
+    if (g.nb2 > 1) {
     if (g.fb2) b2 = (uint32_t)(((uint64_t)(bh & ((1u << g.fb2) - 1u)) * (uint32_t)g.nb2) >> g.fb2);
     else b2 = (bh >> (SK_BUCKET_BITS - g.l1 - g.l2_pow)) & (uint32_t)(g.nb2 - 1);
-    return (uint64_t)b1 * (uint32_t)g.nb2 + b2;
+    }
+    const uint64_t b12 = (uint64_t)b1 * (uint32_t)g.nb2 + b2;
+    if (g.nb3 <= 1) return b12;
+    const uint32_t b3 = (uint32_t)(((uint64_t)(bh & ((1u << g.fb3) - 1u)) * (uint32_t)g.nb3) >> g.fb3);
+    return b12 * (uint32_t)g.nb3 + b3;
 }
 
 // sort key of the owner split of a sharded build: bucket hash of every query in bits 40.. of q_meta
@@ -1283,17 +1311,19 @@ __global__ __launch_bounds__(256) void k_succ_resolve(const uint64_t *__restrict
     const uint64_t key = q_key[i];
     const uint64_t bucket = sk_bucket_of(kmer_bucket22(key, g.k, g.m), g);
     uint32_t id = NO_NODE;
-    if (bucket < n_buckets) {
+    if (bucket >= g.own_lo && bucket < g.own_lo + g.own_cnt) {
         uint64_t ri = bucket;
         bool have = ranges[bucket].node_cnt != 0;
-        if (!have) {  // the bucket overflowed its table and was counted in hash sub-ranges (rare): find the one of this key
+        if (!have) {  // the bucket was counted in hash sub-ranges: walk its chain of ranges to the one of this key
             const uint32_t sh = sub_hash(key);
-            for (uint64_t r = n_buckets; r < n_ranges && !have; ++r) {
+            uint32_t r = ranges[bucket].next;
+            for (int guard = 0; r && r < n_ranges && !have && guard < (1 << 20); ++guard) {
                 const SkRange rg = ranges[r];
-                if (rg.bucket == (uint32_t)bucket && rg.node_cnt && (sh & rg.mask) == rg.val) { ri = r; have = true; }
+                if (rg.node_cnt && (sh & rg.mask) == rg.val) { ri = r; have = true; }
+                r = rg.next;
             }
         }
-        if (have) id = dir_find<CAP>(dirs, ri, keys, n_nodes, key);
+        if (have) id = dir_find<CAP>(dirs, ri < n_buckets ? ri - g.own_lo : g.own_cnt + (ri - n_buckets), keys, n_nodes, key);
     }
     if (id == NO_NODE) { atomicOr(&scalars[0], 128ull); return; }  // every successor k-mer exists as a node
     out[q_col ? q_col[i] : i] = id | id_tag;

@@ -1,0 +1,157 @@
+"""Multi-pass build (BASELINE.json configs[3]: hash-prefix passes, finished parts parked in HBM, node ids beyond 2^32).
+
+Small sizes: every part export, gathered, equals the C oracle and every successor (part, local id) points at the
+shifted k-mer.  Full size: one GPU, more than 2^32 nodes across the parts, checked through properties that hold
+whatever the size."""
+import numpy as np
+import pytest
+
+import _dbg
+import synth
+from oracle import orc_c
+
+pytestmark = pytest.mark.gpu
+
+
+def gather_parts(g):
+    parts = [g.export_part(p) for p in range(g.part_count())]
+    for p, d in enumerate(parts):
+        assert g.part_sizes(p)["n_nodes"] == d["keys"].size and int(d["row_ptr"][-1]) == d["col"].size
+    return parts
+
+
+def dense_counts(d):
+    """[n, 4] counts by base code from a part's CSR: the columns of a row follow the base codes set in flags."""
+    n = d["keys"].size
+    counts = np.zeros((n, 4), dtype=np.uint32)
+    e = d["row_ptr"][:-1].astype(np.int64).copy()
+    for code in range(4):
+        has = ((d["flags"] >> (1 + code)) & 1).astype(bool)
+        counts[has, code] = d["cnt"][e[has]]
+        e[has] += 1
+    assert np.array_equal(e, d["row_ptr"][1:].astype(np.int64))
+    return counts
+
+
+def check_against_oracle(g, reads, read_len, k):
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
+    parts = gather_parts(g)
+    keys = np.concatenate([d["keys"] for d in parts])
+    stamps = np.concatenate([d["stamps"] for d in parts])
+    counts = np.concatenate([dense_counts(d) for d in parts])
+    flags = np.concatenate([d["flags"] for d in parts])
+    sz = g.sizes()
+    assert keys.size == want["n_nodes"] == sz["n_nodes"] and sz["n_edges"] == int((want["counts"] != 0).sum())
+    assert sz["n_kmer_instances"] == want["n_kmer_instances"] and sz["n_edge_instances"] == want["n_edge_instances"]
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(counts[o], want["counts"])
+    assert np.array_equal(flags & 1, (stamps & np.uint64(1)).astype(np.uint8))
+    assert sz["n_starts"] == int(((want["stamps"] & np.uint64(1)) == 0).sum())
+    # successors: (part, local id) -> the shifted k-mer
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for d in parts:
+        e = d["row_ptr"][:-1].astype(np.int64).copy()
+        for code in range(4):
+            has = ((d["flags"] >> (1 + code)) & 1).astype(bool)
+            cols, owners = d["col"][e[has]], d["col_part"][e[has]]
+            got = np.empty(cols.size, dtype=np.uint64)
+            for q, dq in enumerate(parts):
+                sel = owners == q
+                assert np.all(cols[sel] < dq["keys"].size)
+                got[sel] = dq["keys"][cols[sel]]
+            assert owners.size == 0 or int(owners.max()) < len(parts)
+            assert np.array_equal(got, ((d["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+            e[has] += 1
+
+
+@pytest.mark.parametrize("n_passes", [1, 2, 4, 8, 64])
+@pytest.mark.parametrize("k,n_reads,read_len", [(31, 6000, 150), (21, 6000, 100)])
+def test_multipass_equals_the_oracle(n_passes, k, n_reads, read_len):
+    reads = synth.reads_ascii(11, n_reads * read_len // 20, n_reads, read_len, 0.01)
+    g = _dbg.Graph()
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
+    g.build_multipass(k, n_passes)
+    assert g.part_count() == n_passes
+    check_against_oracle(g, reads, read_len, k)
+    with pytest.raises(_dbg.DbgError, match="multi-pass"):
+        g.prune(2)  # 32-bit node ids: the traversal refuses a graph in parts
+    with pytest.raises(_dbg.DbgError, match="multi-pass"):
+        g.export_nodes()
+    g.build(k)  # the same handle builds a single-pass graph again
+    assert g.part_count() == 0 and g.sizes()["n_nodes"] > 0
+
+
+def test_multipass_with_forced_geometry_and_overflowing_buckets():
+    """bucket_bits = 9: one final bucket per level-1 group, so tables overflow and are counted in hash sub-ranges
+    (the directory then has extra ranges): successors across parts and across sub-ranges still resolve."""
+    reads = synth.reads_ascii(12, 400_000, 60_000, 100, 0.01)
+    g = _dbg.Graph()
+    g.set_option("bucket_bits", 9)
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64))
+    g.build_multipass(31, 4)
+    check_against_oracle(g, reads, 100, 31)
+
+
+def test_more_than_two_to_the_32_nodes_on_one_gpu():
+    """45 M x 150 bp reads with 5 % substitutions: about 4.5e9 distinct 31-mers -- more than a 32-bit node id can
+    name -- built in 8 passes on one GPU (6.75 GB of reads, 64-bit stamps).  No host export at this size: the
+    invariants are computed on the device (torch) over the parts' arrays."""
+    import torch
+    torch.zeros(1, device="cuda")  # bring torch's context up before the build fills most of the HBM
+    n, L, k, G = 45_000_000, 150, 31, 225_000_000
+    g = _dbg.Graph()
+    g.synth_reads(1, G, n, L, 0.05)
+    g.build_multipass(k, 8)
+    sz = g.sizes()
+    assert sz["n_nodes"] > (1 << 32)
+    assert sz["n_kmer_instances"] == n * (L - k + 1) and sz["n_edge_instances"] == n * (L - k)
+    parts = [g.part_tensors(p) for p in range(8)]
+    psz = [g.part_sizes(p) for p in range(8)]
+    assert sum(s["n_nodes"] for s in psz) == sz["n_nodes"] and sum(s["n_edges"] for s in psz) == sz["n_edges"]
+    assert all(s["n_nodes"] < (1 << 32) - 16 for s in psz)
+    assert [s["first_node_id"] for s in psz] == [sum(x["n_nodes"] for x in psz[:p]) for p in range(8)]
+    bases, _ = g.reads_tensors()
+    mask = (1 << (2 * k)) - 1
+    total_cnt = total_starts = 0
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    for p, d in enumerate(parts):
+        nn, ne = psz[p]["n_nodes"], psz[p]["n_edges"]
+        rp = d["row_ptr"].to(torch.int64) & 0xFFFFFFFF
+        assert int(rp[-1]) == ne and int(rp[0]) == 0
+        deg = rp[1:] - rp[:-1]
+        present = (d["flags"] >> 1) & 15
+        popc = ((present & 1) + ((present >> 1) & 1) + ((present >> 2) & 1) + ((present >> 3) & 1)).to(torch.int64)
+        assert bool((deg == popc).all())                                    # a row holds one column per base that occurs
+        total_cnt += int((d["cnt"].to(torch.int64) & 0xFFFFFFFF).sum())
+        assert bool((d["cnt"] != 0).all())
+        stamps = d["stamps"].to(torch.int64)
+        assert bool(((d["flags"] & 1).to(torch.int64) == (stamps & 1)).all())
+        pos = stamps >> 1
+        assert bool((((stamps & 1) == 0) == (pos % L == 0)).all())          # indegree 0 <=> position 0 of a read
+        total_starts += int(((stamps & 1) == 0).sum())
+        for q in range(8):                                                   # every successor id names a node of its part
+            sel = d["col_part"] == q
+            if bool(sel.any()):
+                assert int((d["col"][sel].to(torch.int64) & 0xFFFFFFFF).max()) < psz[q]["n_nodes"]
+        assert int(d["col_part"].max()) < 8
+        # a sample of nodes: the first occurrence holds the k-mer, and every successor is the shifted k-mer
+        idx = torch.randint(0, nn, (200_000,), device="cuda", generator=gen)
+        window = bases[(pos[idx][:, None] + torch.arange(k, device="cuda")[None, :])].to(torch.int64)
+        code = (window >> 1) & 3
+        shifts = 2 * (k - 1 - torch.arange(k, device="cuda"))
+        assert bool(((code << shifts[None, :]).sum(dim=1) == d["keys"][idx]).all())
+        e = rp[idx].clone()
+        for c in range(4):
+            has = ((present[idx] >> c) & 1).bool()
+            ee = e[has]
+            tgt_part, tgt = d["col_part"][ee], d["col"][ee].to(torch.int64) & 0xFFFFFFFF
+            got = torch.empty_like(tgt)
+            for q in range(8):
+                sel = tgt_part == q
+                got[sel] = parts[q]["keys"][tgt[sel]]
+            assert bool((got == (((d["keys"][idx][has] << 2) | c) & mask)).all())
+            e[has] += 1
+        del rp, deg, present, popc, stamps, pos
+    assert total_cnt == sz["n_edge_instances"]                               # every (k+1)-mer instance counted once
+    assert total_starts == sz["n_starts"]
