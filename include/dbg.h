@@ -274,6 +274,17 @@ int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *shard_nodes,
 /* device pointer of the upper key words (NULL for k <= 31) */
 int dbg_device_keys_hi(dbg_t *h, const void **d_keys_hi);
 
+/* ---- f4: read-support scores of contigs (findSupportReadScore, IV_sortOutputs.py:10-15): out_scores[c] = sum of
+ *      read_scores[r] over the reads r (distinct strings: the reference's dict keys) that occur in contig c as a
+ *      substring, added in ascending r from 0.0 -- the reference's order, so double sums equal the reference's bit for
+ *      bit; an empty read occurs in every contig.  read_is_float (may be NULL = all): 1 where the reference's score
+ *      is a Python float; out_float_hits[c] (may be NULL) counts the float-typed reads found in c (0: the reference's
+ *      result is an int).  All pointers are host pointers; reads / contigs are concatenated characters + offsets[n + 1].
+ *      Uses the handle's device only; its reads and graph are untouched. */
+int dbg_support_read_scores(dbg_t *h, const char *read_chars, const uint64_t *read_off, uint64_t n_reads,
+                            const double *read_scores, const uint8_t *read_is_float, const char *contig_chars,
+                            const uint64_t *contig_off, uint64_t n_contigs, double *out_scores, uint32_t *out_float_hits);
+
 #ifdef __cplusplus
 }
 #endif

@@ -356,3 +356,14 @@ def get_graph_from_kmers(kmers, k):
                 vertices[other].outdegree += 1
                 vertices[km].indegree += 1
     return vertices, edges
+
+
+def find_support_read_score(contig, score_table):
+    """IV_sortOutputs.py:10-15: the scores of the reads (dict keys, in dict order) that occur in ``contig`` as a
+    substring, added up from 0 in that order (the order matters for floating-point scores; an empty read occurs in
+    every contig)."""
+    score = 0
+    for read, value in score_table.items():
+        if contig.find(read) >= 0:
+            score += value
+    return score

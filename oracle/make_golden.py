@@ -443,8 +443,50 @@ def main():
     print("synth checksum", out["checksum_e0"], out["checksum_e1"])
 
 
+def main_support():
+    """Read-support scores (IV_sortOutputs.py:10-15): findSupportReadScore of the reference, imported by path, on
+    random peptide and DNA score tables.  Scores travel as float.hex() so that the sums compare bit for bit."""
+    import random
+    iv = _load("ref_IV_sortOutputs", os.path.join(REF, "IV_sortOutputs.py"))
+    assert os.path.realpath(iv.__file__).startswith(os.path.realpath(REF))
+    rng = random.Random(4242)
+    cases = []
+    for t in range(60):
+        alpha = "ACDEFGHIKLMNPQRSTVWY" if t % 3 else "ACGT"
+        n_reads = rng.randint(1, 60)
+        reads = {}
+        while len(reads) < n_reads:
+            L = rng.choice([0] * (1 if t % 10 == 0 else 0) + [1, 2, 3, 4, 5, 6, 8, 12, 20, 33])
+            r = "".join(rng.choice(alpha) for _ in range(L))
+            if r not in reads:
+                # the reference's TSV scores are floats; integers and repeated values on purpose, too
+                reads[r] = rng.choice([rng.uniform(0, 100), float(rng.randint(1, 99)), rng.randint(1, 50), 0.1, 1e-3, 97.25])
+        keys = list(reads)
+        contigs = []
+        for _ in range(rng.randint(1, 12)):
+            parts = []
+            for _ in range(rng.randint(0, 6)):
+                if keys and rng.random() < 0.7:
+                    r = rng.choice(keys)
+                    if r and rng.random() < 0.3:   # a truncated copy: must NOT count unless another read matches
+                        r = r[:-1] if rng.random() < 0.5 else r[1:]
+                    parts.append(r)
+                else:
+                    parts.append("".join(rng.choice(alpha) for _ in range(rng.randint(0, 9))))
+            contigs.append("".join(parts))
+        want = [iv.findSupportReadScore(c, reads) for c in contigs]
+        cases.append({"reads": keys, "scores": [reads[r].hex() if isinstance(reads[r], float) else reads[r] for r in keys],
+                      "contigs": contigs, "want": [w.hex() if isinstance(w, float) else w for w in want]})
+    with open(os.path.join(GOLDEN, "support_scores.json"), "w") as fh:
+        json.dump(cases, fh, separators=(",", ":"))
+    print("support_scores:", len(cases), "cases;", sum(len(c["contigs"]) for c in cases), "contigs;",
+          sum(1 for c in cases for w in c["want"] if w not in (0, "0x0.0p+0")), "non-zero scores")
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["wide"]:
+    if sys.argv[1:] == ["support"]:
+        main_support()
+    elif sys.argv[1:] == ["wide"]:
         main_wide()
     elif sys.argv[1:] == ["pepwide"]:
         main_pepwide()
@@ -455,3 +497,4 @@ if __name__ == "__main__":
         main_wide()
         main_pepwide()
         main_aux()
+        main_support()

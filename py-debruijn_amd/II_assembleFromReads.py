@@ -19,14 +19,6 @@ import debruijn as db
 from debruijn import read_reads, read_reads_device
 
 
-def getScore(edge_count_table, contig, k):
-    """II_assembleFromReads.py:14-18 (host form; the driver below uses the device scores)."""
-    score = 0
-    for i in range(len(contig) - k):
-        score += edge_count_table[contig[i:i + k + 1]]
-    return score
-
-
 def get_args():
     parser = argparse.ArgumentParser()
     parser.add_argument('-froot', type=str)

@@ -31,7 +31,7 @@ SYMBOLS = (
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
-    "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
+    "dbg_support_read_scores", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
 )
 
 
@@ -127,6 +127,7 @@ def load_library():
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_build_multipass": (C.c_int, [H, C.c_int, C.c_int]),
+        "dbg_support_read_scores": (C.c_int, [H, vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "dbg_part_count": (C.c_int, [H, C.POINTER(C.c_int)]),
         "dbg_part_sizes": (C.c_int, [H, C.c_int, u64p, u64p, u64p]),
         "dbg_export_part": (C.c_int, [H, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
@@ -169,6 +170,7 @@ class Graph:
             self._h = None
             raise DbgError(rc, "dbg_create failed: no usable MI355X visible (the device path has no CPU fallback)")
         self._keep = []  # buffers the device borrows
+        self.generation = 0  # bumped whenever the handle's graph is replaced (debruijn.output_contigs checks it)
         for var, opt in (("DBG_ENGINE", "engine"), ("DBG_BUCKET_BITS", "bucket_bits"), ("DBG_LDS_SLOTS", "lds_slots"),
                          ("DBG_WALK_JUMP_MIN", "walk_jump_min_nodes")):
             if os.environ.get(var, "") != "":
@@ -235,6 +237,7 @@ class Graph:
 
     # ---- pipeline
     def build(self, k, table_capacity_hint=0):
+        self.generation += 1
         self._chk(self._lib.dbg_build(self._h, int(k), int(table_capacity_hint)))
 
     def refine_edge_order(self):
@@ -363,8 +366,21 @@ class Graph:
         return off, chars, score, stamp, seq
 
 
+    # ---- read-support scores (IV_sortOutputs.py:10-15)
+    def support_read_scores(self, read_chars, read_off, scores, is_float, contig_chars, contig_off):
+        """-> (float64 scores [n_contigs], uint32 float-typed hits [n_contigs]); numpy arrays in, see include/dbg.h."""
+        n_reads, n_contigs = read_off.size - 1, contig_off.size - 1
+        out = np.zeros(n_contigs, dtype=np.float64)
+        fh = np.zeros(n_contigs, dtype=np.uint32)
+        self._chk(self._lib.dbg_support_read_scores(
+            self._h, _ptr(read_chars) if read_chars.size else None, _ptr(read_off), n_reads, _ptr(scores) if n_reads else None,
+            _ptr(is_float) if n_reads else None, _ptr(contig_chars) if contig_chars.size else None, _ptr(contig_off), n_contigs,
+            _ptr(out) if n_contigs else None, _ptr(fh) if n_contigs else None))
+        return out, fh
+
     # ---- multi-pass build: graphs beyond one 32-bit id space (BASELINE.json configs[3])
     def build_multipass(self, k, n_passes):
+        self.generation += 1
         self._chk(self._lib.dbg_build_multipass(self._h, int(k), int(n_passes)))
 
     def part_count(self):
@@ -488,6 +504,7 @@ class Graph:
         """Install the concatenated shard arrays (torch tensors on this device) as this handle's graph."""
         sn = (C.c_uint64 * len(shard_nodes))(*[int(x) for x in shard_nodes])
         ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
+        self.generation += 1
         self._graph_keep = (keys, keys_hi, stamps, counts, succ)  # borrowed by the library, not copied
         self._chk(self._lib.dbg_import_graph(self._h, int(k), len(shard_nodes), sn, ptr(keys), ptr(keys_hi), ptr(stamps),
                                              ptr(counts), ptr(succ)))

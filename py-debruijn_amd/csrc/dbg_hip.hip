@@ -25,6 +25,7 @@
 #include "dbg_generic.h"
 #include "dbg_genref.h"
 #include "dbg_wide.h"
+#include "dbg_support.h"
 
 using namespace dbgk;
 
@@ -2306,6 +2307,8 @@ __global__ __launch_bounds__(256) void k_iota32(uint64_t n, uint32_t *out) {
 // radix sort of the stamps instead of a host argsort of 10^7..10^8 elements.
 extern "C" int dbg_export_dict_order(dbg_t *h, uint32_t *order) {
     if (!h || !h->k || !order) { if (h) h->err = "dbg_build must run first"; return DBG_E_ARG; }
+    // a shard's stamps are global positions: the order of one shard alone is not the dict order of anything
+    if (h->partial_graph) { h->err = kPartialGraph; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     CHK(ensure_dense(h));
     const uint64_t n = h->n_nodes;
@@ -4257,4 +4260,104 @@ extern "C" int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *sta
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return DBG_E_HIP; }
     return DBG_OK;
+}
+
+
+// ==========================================================================================
+// Read-support scores (IV_sortOutputs.py:10-15), see dbg_support.h.  Uses the handle's device and stream only:
+// the graph and the reads of the handle are not touched.
+// ==========================================================================================
+extern "C" int dbg_support_read_scores(dbg_t *h, const char *read_chars, const uint64_t *read_off, uint64_t n_reads,
+                                       const double *read_scores, const uint8_t *read_is_float, const char *contig_chars,
+                                       const uint64_t *contig_off, uint64_t n_contigs, double *out_scores,
+                                       uint32_t *out_float_hits) {
+    if (!h || !read_off || !contig_off || (n_reads && !read_scores) || (n_contigs && !out_scores)) return DBG_E_ARG;
+    if (n_reads >= SUP_NONE || n_contigs >= SUP_NONE) { h->err = "at most 2^32 - 2 reads and contigs"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!n_contigs) return DBG_OK;
+    const uint64_t rbytes = read_off[n_reads], cbytes = contig_off[n_contigs];
+    if ((rbytes && !read_chars) || (cbytes && !contig_chars)) return DBG_E_ARG;
+    int a = 7;
+    std::vector<uint32_t> empties;
+    for (uint64_t r = 0; r < n_reads; ++r) {
+        if (read_off[r + 1] < read_off[r]) { h->err = "offsets must be non-decreasing"; return DBG_E_ARG; }
+        const uint64_t len = read_off[r + 1] - read_off[r];
+        if (len == 0) empties.push_back((uint32_t)r);
+        else a = (int)std::min<uint64_t>((uint64_t)a, len);
+    }
+    uint64_t cap = 1024;
+    while (cap < 2 * (n_reads + 1)) cap <<= 1;
+    char *d_r = nullptr, *d_c = nullptr;
+    uint64_t *d_roff = nullptr, *d_coff = nullptr;
+    double *d_sc = nullptr, *d_out = nullptr;
+    uint8_t *d_isf = nullptr;
+    unsigned long long *d_keys = nullptr, *d_hits = nullptr, *d_hits2 = nullptr, *d_cnt = nullptr;
+    uint32_t *d_head = nullptr, *d_next = nullptr, *d_empty = nullptr, *d_fh = nullptr;
+    void *d_tmp = nullptr;
+    int rc = DBG_OK;
+    auto fail = [&](hipError_t e, const char *what) { h->err = std::string(what) + ": " + hipGetErrorString(e); rc = DBG_E_HIP; };
+    do {
+        if ((rc = dev_alloc(h, &d_r, rbytes + 8)) || (rc = dev_alloc(h, &d_c, cbytes + 8)) || (rc = dev_alloc(h, &d_roff, n_reads + 1)) ||
+            (rc = dev_alloc(h, &d_coff, n_contigs + 1)) || (rc = dev_alloc(h, &d_sc, n_reads)) || (rc = dev_alloc(h, &d_out, n_contigs)) ||
+            (rc = dev_alloc(h, &d_isf, n_reads)) || (rc = dev_alloc(h, &d_keys, cap)) || (rc = dev_alloc(h, &d_head, cap)) ||
+            (rc = dev_alloc(h, &d_next, n_reads)) || (rc = dev_alloc(h, &d_empty, empties.size())) ||
+            (rc = dev_alloc(h, &d_fh, n_contigs)) || (rc = dev_alloc(h, &d_cnt, 1)))
+            break;
+        hipError_t e = hipSuccess;
+        if (rbytes) e = hipMemcpyAsync(d_r, read_chars, rbytes, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && cbytes) e = hipMemcpyAsync(d_c, contig_chars, cbytes, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_roff, read_off, (n_reads + 1) * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_coff, contig_off, (n_contigs + 1) * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && n_reads) e = hipMemcpyAsync(d_sc, read_scores, n_reads * 8, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && n_reads && read_is_float) e = hipMemcpyAsync(d_isf, read_is_float, n_reads, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && !empties.empty())
+            e = hipMemcpyAsync(d_empty, empties.data(), empties.size() * 4, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_keys, 0xFF, cap * 8, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_head, 0xFF, cap * 4, h->stream);
+        if (e != hipSuccess) { fail(e, "support scores: upload"); break; }
+        if (n_reads)
+            hipLaunchKernelGGL(k_sup_insert, dim3(grid_for(n_reads, 256)), dim3(256), 0, h->stream, d_r, d_roff, n_reads, a, d_keys,
+                               d_head, d_next, cap - 1);
+        uint64_t hit_cap = std::max<uint64_t>(1024, cbytes + empties.size() * n_contigs + 1024), n_hits = 0;
+        for (int attempt = 0; attempt < 2 && rc == DBG_OK; ++attempt) {
+            if (d_hits) { (void)hipFree(d_hits); d_hits = nullptr; }
+            if ((rc = dev_alloc(h, &d_hits, hit_cap)) != DBG_OK) break;
+            (void)hipMemsetAsync(d_cnt, 0, 8, h->stream);
+            if (cbytes && n_reads > empties.size())
+                hipLaunchKernelGGL(k_sup_scan, dim3(grid_for(cbytes, 256)), dim3(256), 0, h->stream, d_c, d_coff, n_contigs, cbytes, a,
+                                   d_keys, d_head, d_next, cap - 1, d_r, d_roff, d_hits, hit_cap, d_cnt);
+            if (!empties.empty())
+                hipLaunchKernelGGL(k_sup_empty, dim3(grid_for(empties.size() * n_contigs, 256)), dim3(256), 0, h->stream, d_empty,
+                                   (uint64_t)empties.size(), n_contigs, d_hits, hit_cap, d_cnt);
+            e = hipMemcpyAsync(&n_hits, d_cnt, 8, hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) { fail(e, "support scores: scan"); break; }
+            if (n_hits <= hit_cap) break;
+            if (attempt == 1) { h->err = "support scores: hit list overflow"; rc = DBG_E_CAPACITY; break; }
+            hit_cap = n_hits + 1024;  // one a-mer shared by many reads: take the exact size
+        }
+        if (rc != DBG_OK) break;
+        const unsigned long long *sorted = d_hits;
+        if (n_hits > 1) {
+            if ((rc = dev_alloc(h, &d_hits2, n_hits)) != DBG_OK) break;
+            size_t tmp_bytes = 0;
+            e = rocprim::radix_sort_keys(nullptr, tmp_bytes, d_hits, d_hits2, (size_t)n_hits, 0u, 64u, h->stream);
+            if (e == hipSuccess) e = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1);
+            if (e == hipSuccess) e = rocprim::radix_sort_keys(d_tmp, tmp_bytes, d_hits, d_hits2, (size_t)n_hits, 0u, 64u, h->stream);
+            if (e != hipSuccess) { fail(e, "support scores: sort"); break; }
+            sorted = d_hits2;
+        }
+        hipLaunchKernelGGL(k_sup_sum, dim3(grid_for(n_contigs, 256)), dim3(256), 0, h->stream, sorted, n_hits, n_contigs, d_sc,
+                           read_is_float ? d_isf : (const uint8_t *)nullptr, d_out, d_fh);
+        e = hipMemcpyAsync(out_scores, d_out, n_contigs * 8, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && out_float_hits) e = hipMemcpyAsync(out_float_hits, d_fh, n_contigs * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { fail(e, "support scores"); break; }
+    } while (0);
+    dev_free(d_r); dev_free(d_c); dev_free(d_roff); dev_free(d_coff); dev_free(d_sc); dev_free(d_out); dev_free(d_isf);
+    dev_free(d_keys); dev_free(d_hits); dev_free(d_hits2); dev_free(d_cnt); dev_free(d_head); dev_free(d_next);
+    dev_free(d_empty); dev_free(d_fh);
+    if (d_tmp) (void)hipFree(d_tmp);
+    return rc;
 }

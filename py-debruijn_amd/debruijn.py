@@ -60,7 +60,7 @@ class DeviceReads:
     builds from the resident reads, so no Python string is created per read.  Items are
     materialised lazily (one device-to-host copy of the packed buffer on first access).
     The object owns one device handle: a later ``construct_graph`` on the same object replaces the
-    graph of an earlier one.
+    graph of an earlier one (``output_contigs`` on the earlier result then raises instead of walking the new graph).
     """
 
     def __init__(self, fname):
@@ -72,7 +72,7 @@ class DeviceReads:
     def _pull(self):
         if self._host is None:
             bases, offsets = self._graph.copy_reads()
-            self._host = (bases.tobytes().decode("ascii", "replace"), offsets)
+            self._host = (bases.tobytes().decode("latin-1"), offsets)  # one byte, one character, as everywhere else
         return self._host
 
     def __len__(self):
@@ -323,17 +323,26 @@ MAX_CONTIG_CHARS = 0  # dbg_walk's max_chars; 0 = the library default (1 GiB of 
 
 class LazyContigs(Sequence):
     """Contigs of a walk whose text was larger than MAX_CONTIG_CHARS: same order, ``.scores`` and ``.lengths`` as
-    ContigList, every text fetched from the device when it is indexed (dbg_export_contig_text)."""
+    ContigList, every text fetched from the device when it is indexed (dbg_export_contig_text).
+
+    ``sort`` and ``extend`` exist so that the reference's own driver (II_assembleFromReads.py:64,74:
+    ``sequences.sort(key=lambda x: getScore(edge_count_table, x, k), reverse=True)`` and
+    ``sequences.extend(pull_out_read)``) runs unchanged on this object.  Both only permute / append: no text moves.
+    ``sort`` orders by the device-computed getScore of every contig -- the one key the pipeline sorts by; evaluating an
+    arbitrary ``key`` would mean fetching every text (10^12 characters at the BASELINE size).  A ``key`` that is not
+    that score is detected on a sample of the shortest contigs and refused."""
 
     def __init__(self, graph, order, off, score):
         self._graph = graph
-        self._order = order
+        self._order = np.asarray(order)
         self._off = off
-        self.scores = score[order].tolist()
-        self.lengths = (off[1:] - off[:-1])[order].tolist()
+        self._score = np.asarray(score)
+        self._tail = []   # plain strings appended by extend()
+        self.scores = self._score[self._order].tolist()
+        self.lengths = (off[1:] - off[:-1])[self._order].tolist()
 
     def __len__(self):
-        return len(self._order)
+        return len(self._order) + len(self._tail)
 
     def __getitem__(self, i):
         if isinstance(i, slice):
@@ -342,8 +351,31 @@ class LazyContigs(Sequence):
             i += len(self)
         if not 0 <= i < len(self):
             raise IndexError(i)
+        if i >= len(self._order):
+            return self._tail[i - len(self._order)]
         c = int(self._order[i])
         return self._graph.export_contig_text(c, int(self._off[c + 1] - self._off[c])).decode("latin-1")
+
+    def sort(self, key=None, reverse=False):
+        """In-place, stable (``list.sort`` semantics) by the device getScore; see the class docstring."""
+        if self._tail:
+            raise NotImplementedError("sort after extend: the appended strings carry no device score")
+        n = len(self._order)
+        if key is not None and n:
+            lens = (self._off[1:] - self._off[:-1])[self._order]
+            for i in np.argsort(lens, kind="stable")[:4].tolist():  # the shortest ones are cheap to fetch
+                if key(self[i]) != self.scores[i]:
+                    raise NotImplementedError("LazyContigs.sort orders by the contig score (getScore); this key is a "
+                                              "different function and would need every contig's text")
+        sc = self._score[self._order].astype(np.int64)
+        # stable in both directions: equal scores keep their current relative order, as list.sort(reverse=True) does
+        perm = np.argsort(-sc if reverse else sc, kind="stable")
+        self._order = self._order[perm]
+        self.scores = [self.scores[i] for i in perm.tolist()]
+        self.lengths = [self.lengths[i] for i in perm.tolist()]
+
+    def extend(self, more):
+        self._tail.extend(more)
 
 
 def _pack_reads(reads):
@@ -468,7 +500,7 @@ def construct_graph(reads, k, threshold=3, final=False):
 
     token = object()
     vertices._graph = g
-    vertices._state = {"token": token, "final": bool(final), "k": k, "n_branch": int(n_branch)}
+    vertices._state = {"token": token, "final": bool(final), "k": k, "n_branch": int(n_branch), "generation": g.generation}
     branch_kmer._token = token
     already_pull_out._token = token
     return (vertices, edges), pull_out_read, branch_kmer, already_pull_out, ect
@@ -486,6 +518,9 @@ def output_contigs(g, branch_kmer, already_pull_out):
     state = getattr(V, "_state", None)
     if graph is None or state is None:
         raise TypeError("output_contigs needs the (vertices, edges) returned by this module's construct_graph")
+    if state.get("generation") != graph.generation:
+        raise ValueError("the device graph of this construct_graph result was replaced by a later build on the same handle "
+                         "(construct_graph on the same DeviceReads): call output_contigs before building again")
     tok = state["token"]
     if getattr(already_pull_out, "_token", None) is not tok or (
             getattr(branch_kmer, "_token", None) is not tok and len(branch_kmer) != 0):

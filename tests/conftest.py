@@ -24,11 +24,11 @@ def load_golden(name):
 
 
 def golden_case_names():
-    """construct_graph/output_contigs cases (one JSON each), excluding driver/fuzz/synth files."""
+    """construct_graph/output_contigs cases (one JSON each), excluding driver/fuzz/synth/support-score files."""
     names = []
     for p in sorted(glob.glob(os.path.join(GOLDEN, "*.json"))):
         n = os.path.basename(p)[:-5]
-        if n.startswith(("driver_", "fuzz_", "synth_", "aux_")):
+        if n.startswith(("driver_", "fuzz_", "synth_", "aux_", "support_")):
             continue
         names.append(n)
     return names
@@ -44,9 +44,3 @@ def case_reads(case):
     arr = synth.reads_ascii(g["seed"], g["genome_len"], g["n_reads"], g["read_len"], g["err_rate"])
     assert synth.checksum(arr) == inp["reads_checksum"], "synthetic generator drifted from the fixture"
     return [row.tobytes().decode("ascii") for row in arr]
-
-
-@pytest.fixture(scope="session")
-def have_gpu():
-    import torch
-    return torch.cuda.is_available()

@@ -114,3 +114,36 @@ def test_construct_graph_from_device_reads(tmp_path):
     assert list(a[0][0]) == list(b[0][0]) and a[0][1] == b[0][1]
     assert a[1] == b[1] and list(a[2]) == list(b[2]) and list(a[3]) == list(b[3]) and a[4] == b[4]
     assert list(ca) == list(cb)
+
+
+def test_device_reads_hold_one_character_per_byte(tmp_path):
+    """Bytes >= 0x80 in a FASTA file: the device reads decode as latin-1 (one byte, one character) like _pack_reads, the
+    node labels and the contig text, so reads[i], pull_out_read and a graph built from list(reads) stay consistent."""
+    import debruijn as prod
+    p = tmp_path / "hi.fasta"
+    p.write_bytes(b">h\nAC\xe9GTAC\xe9GA\n>i\nC\xe9GTT\n")
+    dev = prod.read_reads_device(str(p))
+    assert list(dev) == ["AC\xe9GTAC\xe9GA", "C\xe9GTT"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = prod.construct_graph(dev, 3, threshold=1)
+        ca = list(prod.output_contigs(a[0], a[2], a[3]))
+        b = prod.construct_graph(list(dev), 3, threshold=1)
+        cb = list(prod.output_contigs(b[0], b[2], b[3]))
+    assert list(a[0][0]) == list(b[0][0]) and "C\xe9G" in a[0][0] and a[1] == b[1] and ca == cb
+
+
+def test_output_contigs_refuses_a_graph_that_was_replaced(tmp_path):
+    """construct_graph(DeviceReads) builds into the reads' own handle: a second call replaces the first graph on the
+    device, and output_contigs on the first result must raise instead of walking the new graph."""
+    import debruijn as prod
+    import synth
+    reads = synth.reads_list(52, 3000, 300, 80, 0.01)
+    p = tmp_path / "input_reads.fasta"
+    synth.write_fasta(str(p), reads)
+    dev = prod.read_reads_device(str(p))
+    with contextlib.redirect_stdout(io.StringIO()):
+        first = prod.construct_graph(dev, 15, threshold=2)
+        second = prod.construct_graph(dev, 17, threshold=2)
+        with pytest.raises(ValueError, match="replaced"):
+            prod.output_contigs(first[0], first[2], first[3])
+        assert len(prod.output_contigs(second[0], second[2], second[3])) > 0

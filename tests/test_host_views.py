@@ -94,6 +94,38 @@ def test_lazy_contigs_sequence_protocol():
         lazy[3]
 
 
+def test_lazy_contigs_survive_the_reference_driver_lines():
+    """II_assembleFromReads.py:64 and :74 on a LazyContigs: ``sequences.sort(key=lambda x: getScore(...), reverse=True)``
+    permutes by the device scores exactly as list.sort would (stable), ``sequences.extend(pull_out_read)`` appends."""
+    rng = np.random.default_rng(3)
+    n = 40
+    texts = {i: bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(12, 24)))) for i in range(n)}
+    lens = np.array([len(texts[i]) for i in range(n)], dtype=np.uint64)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    score = rng.integers(0, 6, size=n).astype(np.uint64)  # many ties: stability matters
+
+    class Handle:
+        def export_contig_text(self, index, length):
+            return texts[index]
+
+    order = rng.permutation(n)
+    table = {texts[i].decode(): int(score[i]) for i in range(n)}  # stand-in for getScore(edge_count_table, x, k)
+    if len(table) < n:  # duplicate texts would make the stand-in ambiguous
+        pytest.skip("random texts collided")
+    lazy = prod.LazyContigs(Handle(), order, off, score)
+    want = list(lazy)
+    want.sort(key=lambda x: table[x], reverse=True)
+    lazy.sort(key=lambda x: table[x], reverse=True)
+    assert list(lazy) == want and lazy.scores == [table[x] for x in want] and lazy.lengths == [len(x) for x in want]
+    lazy.sort(key=lambda x: table[x])
+    want.sort(key=lambda x: table[x])
+    assert list(lazy) == want
+    with pytest.raises(NotImplementedError):
+        lazy.sort(key=len)  # not the contig score: would need every text
+    lazy.extend(["TTT", "GGGG"])
+    assert len(lazy) == n + 2 and lazy[-1] == "GGGG" and lazy[n] == "TTT" and list(lazy)[:n] == want
+
+
 @pytest.mark.parametrize("name", ["peptide_k3_nonfinal", "peptide_k4_nonfinal"])
 def test_views_for_a_generic_alphabet(name):
     """The same for the generic engine's layout: 5 bits per character, [n][32] count and rank arrays, 0xFF beyond the
