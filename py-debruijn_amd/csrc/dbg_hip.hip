@@ -137,6 +137,9 @@ struct dbg {
     void *multipass = nullptr;    // MultiPass (dbg_build_multipass): the parts of the graph, parked in HBM
     bool wide_owner = false;      // a part of a multi-pass build: successor ids are (owner byte, 32-bit local id), not tagged
     bool borrowed_stream = false; // sub-handle of a multi-pass build: the stream belongs to the parent
+    bool arena_freed = false;     // an arena buffer went back to the memory pool since the last trim
+    std::vector<uint64_t> host_seg_cnt;  // sk_extract: records per extraction segment (host copy)
+    std::vector<uint64_t> host_scpre;    // multisplit_level: staging that must outlive an asynchronous upload
     uint64_t shard_node_limit = 0;  // option (tests): lowers the 2^29 - 16 node ids a shard may hand out
     bool partial_graph = false;   // the node table is one shard of several: successor ids point into other handles
     // branch k-mer lookup (pull-out reads)
@@ -157,25 +160,49 @@ struct ShardState {
 static ShardState &shard_of(dbg *h);
 static void multipass_free(dbg *h);
 
+// Arena buffers come from the device's stream-ordered memory pool (hipMallocAsync on the handle's stream) with the
+// pool told to keep what is freed: a hipMalloc / hipFree of several GB costs ~0.1 s each, and a multi-pass build
+// allocates, trims and frees a few hundred GB in pieces of similar sizes -- 14 s of allocator calls around 0.4 s of
+// kernels before this.  Everything a handle does is on its one stream, so stream order is program order.
 static int buf_ensure(dbg *h, dbg::Buf &b, uint64_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.bytes >= bytes) return DBG_OK;
-    if (b.p) (void)hipFree(b.p);
+    if (b.p) { (void)hipFreeAsync(b.p, h->stream); h->arena_freed = true; }
     b.p = nullptr;
     b.bytes = 0;
-    hipError_t e = hipMalloc(&b.p, bytes);
+    hipError_t e = hipMallocAsync(&b.p, bytes, h->stream);
     if (e != hipSuccess) {
-        h->err = std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
+        // the pool may be holding freed blocks of the wrong sizes: give them back to the device and try once more
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(h->stream);
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, h->device) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+        e = hipMallocAsync(&b.p, bytes, h->stream);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        h->err = std::string("hipMallocAsync(") + std::to_string(bytes) + "): " + hipGetErrorString(e);
         b.p = nullptr;
         return DBG_E_NOMEM;
     }
     b.bytes = bytes;
     return DBG_OK;
 }
-static void buf_free(dbg::Buf &b) {
-    if (b.p) (void)hipFree(b.p);
+static void buf_free(dbg *h, dbg::Buf &b) {
+    if (b.p) { (void)hipFreeAsync(b.p, h->stream); h->arena_freed = true; }
     b.p = nullptr;
     b.bytes = 0;
+}
+// Blocks the pool kept for reuse go back to the device: called when a build is complete, so that what the library
+// holds is what it uses (other allocators of the process -- torch -- see the rest) and a later build does not find the
+// pool full of blocks of the wrong sizes.
+static void pool_trim(dbg *h) {
+    if (!h->arena_freed) return;
+    (void)hipStreamSynchronize(h->stream);
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, h->device) == hipSuccess) (void)hipMemPoolTrimTo(pool, 0);
+    (void)hipGetLastError();
+    h->arena_freed = false;
 }
 
 #define HIPCHK(h, call)                                                                      \
@@ -292,6 +319,7 @@ static int exclusive_scan(dbg *h, uint64_t n, F f, OutT *out, uint64_t *h_total)
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(256), 0, h->stream, partial, nblk, d_total);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_write<F, OutT>), dim3((unsigned)nblk), dim3(256), 0, h->stream, n, f,
                        partial, out);
+    if (!h_total) return DBG_OK;  // the caller does not need the total on the host: no synchronisation
     hipError_t e = hipMemcpyAsync(h_total, d_total, 8, hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
@@ -1502,6 +1530,14 @@ extern "C" int dbg_create(int device, dbg_t **out) {
         delete h;
         return DBG_E_HIP;
     }
+    {  // keep freed arena memory in the pool instead of returning it to the device at every synchronisation
+        hipMemPool_t pool;
+        if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        (void)hipGetLastError();
+    }
     *out = h;
     return DBG_OK;
 }
@@ -1512,21 +1548,22 @@ extern "C" void dbg_destroy(dbg_t *h) {
     (void)hipStreamSynchronize(h->stream);
     free_build(h);
     free_reads(h);
-    for (auto &lvl : h->ar_rec) for (auto &b : lvl) buf_free(b);
-    for (auto &lvl : h->ar_q) for (auto &b : lvl) buf_free(b);
-    for (auto &b : h->ar_node) buf_free(b);
-    for (auto &b : h->ar_misc) buf_free(b);
-    for (auto &b : h->ar_csr) buf_free(b);
-    buf_free(h->ar_dir);
-    buf_free(h->ar_l2);
-    for (auto &b : h->ar_shard) buf_free(b);
-    for (auto &b : h->ar_walk) buf_free(b);
-    for (auto &b : h->ar_wide) buf_free(b);
-    for (auto &b : h->ar_refine) buf_free(b);
-    for (auto &b : h->ar_tips) buf_free(b);
-    buf_free(h->ar_scan);
+    for (auto &lvl : h->ar_rec) for (auto &b : lvl) buf_free(h, b);
+    for (auto &lvl : h->ar_q) for (auto &b : lvl) buf_free(h, b);
+    for (auto &b : h->ar_node) buf_free(h, b);
+    for (auto &b : h->ar_misc) buf_free(h, b);
+    for (auto &b : h->ar_csr) buf_free(h, b);
+    buf_free(h, h->ar_dir);
+    buf_free(h, h->ar_l2);
+    for (auto &b : h->ar_shard) buf_free(h, b);
+    for (auto &b : h->ar_walk) buf_free(h, b);
+    for (auto &b : h->ar_wide) buf_free(h, b);
+    for (auto &b : h->ar_refine) buf_free(h, b);
+    for (auto &b : h->ar_tips) buf_free(h, b);
+    buf_free(h, h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
+    (void)hipStreamSynchronize(h->stream);  // the arena buffers were freed in stream order
     if (!h->borrowed_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2113,6 +2150,7 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
         if (rc == DBG_OK) rc = finish_graph(h);
         if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
         h->stats.ms_build_total = t_total.stop();
+        pool_trim(h);  // no-op in the steady state: the arenas only grow
         return DBG_OK;
     }
     Timer t_total(h->stream);
@@ -2951,13 +2989,23 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
                             uint64_t total, const uint64_t *in_w0, const uint64_t *in_w1, const STI *in_st,
                             uint64_t *out_w0, uint64_t *out_w1, ST *out_st, int shift, int nb, uint64_t *c_start,
                             uint64_t *c_cnt, dbg::Buf &b_scpre, dbg::Buf &b_cmat, dbg::Buf &b_offs, int fbits = 0,
-                            const uint64_t *seg_add = nullptr, unsigned long long *d_sums = nullptr) {
+                            const uint64_t *seg_add = nullptr, unsigned long long *d_sums = nullptr,
+                            const uint64_t *host_cnt = nullptr) {
     // spg: segments per group (n_seg: all segments form one group; 1: every segment is its own group)
+    // host_cnt: the segment counts on the host, when the caller has them: the super-chunk prefix then needs no device scan
     CHK(buf_ensure(h, b_scpre, (uint64_t)(n_seg + 1) * 8));
     uint64_t *sc_pre = (uint64_t *)b_scpre.p;
     uint64_t nsc = 0;
-    CHK(exclusive_scan(h, n_seg, CeilDiv{p_cnt, (uint64_t)MS_SC}, sc_pre, &nsc));
-    HIPCHK(h, hipMemcpyAsync(sc_pre + n_seg, &nsc, 8, hipMemcpyHostToDevice, h->stream));
+    if (host_cnt) {
+        std::vector<uint64_t> &pre = h->host_scpre;  // lives in the handle: the upload is asynchronous
+        pre.resize((size_t)n_seg + 1);
+        for (uint32_t i = 0; i < n_seg; ++i) { pre[i] = nsc; nsc += (host_cnt[i] + MS_SC - 1) / MS_SC; }
+        pre[n_seg] = nsc;
+        HIPCHK(h, hipMemcpyAsync(sc_pre, pre.data(), pre.size() * 8, hipMemcpyHostToDevice, h->stream));
+    } else {
+        CHK(exclusive_scan(h, n_seg, CeilDiv{p_cnt, (uint64_t)MS_SC}, sc_pre, &nsc));
+        HIPCHK(h, hipMemcpyAsync(sc_pre + n_seg, &nsc, 8, hipMemcpyHostToDevice, h->stream));
+    }
     MsParents P{p_start, p_cnt, sc_pre, n_seg, spg};
     const uint64_t n_log = nsc * (uint64_t)nb;
     CHK(buf_ensure(h, b_cmat, n_log * 4));
@@ -2972,9 +3020,9 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ms_hist<false>), dim3((unsigned)nsc), dim3(256), 0, h->stream, P, in_w1, shift, nb,
                                fbits, cmat, (unsigned long long *)nullptr);
         HIPCHK(h, hipGetLastError());
-        uint64_t tot = 0;
-        CHK(exclusive_scan(h, n_log, MsLogical{P, cmat, nb}, offs, &tot));
-        if (tot != total) { h->err = "multisplit: histogram total mismatch"; return DBG_E_HIP; }
+        // (the total of the histograms equals `total` by construction; reading it back here would cost a host
+        //  synchronisation per level -- k_ms_children takes the ends from `total` itself)
+        CHK(exclusive_scan(h, n_log, MsLogical{P, cmat, nb}, offs, (uint64_t *)nullptr));
     }
     const uint64_t n_child = (uint64_t)(n_seg / spg) * nb;
     hipLaunchKernelGGL(k_ms_children, dim3(grid_for(n_child, 256)), dim3(256), 0, h->stream, P, offs, nb, total, c_start,
@@ -3055,6 +3103,7 @@ static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2]
     }
     h->stats.ms_extract = t.stop();
     h->stats.n_records = n_rec;
+    h->host_seg_cnt.assign(hseg.begin() + n_wg, hseg.begin() + 2 * (size_t)n_wg);
     *seg_start_out = seg_start;
     *seg_cnt_out = seg_cnt;
     *n_seg_out = n_wg;
@@ -3136,8 +3185,11 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         HIPCHK(h, hipMemcpyAsync(ps_start, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));  // hs goes out of scope
     } else {
+        const uint64_t *host_cnt = (h->host_seg_cnt.size() == n_seg && seg_cnt == (const uint64_t *)h->ar_misc[0].p + n_seg)
+                                       ? h->host_seg_cnt.data() : nullptr;  // the segments sk_extract just wrote
         CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, in_w0, in_w1, in_st, w0[1], w1[1], st[1],
-                                        top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4])));
+                                        top - l1, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], 0, nullptr,
+                                        nullptr, host_cnt)));
         where = 1;
     }
     if (auto_T && l1 >= 9 && n_rec) {  // refine T from a sample: the first level-1 bucket this shard owns
@@ -3316,10 +3368,11 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             static_assert(sizeof(SkCountOut) <= 64 * 8, "descriptor slot");
             SkCountOut *d_out = (SkCountOut *)(h->d_scalars + 64);
             HIPCHK(h, hipMemcpyAsync(d_out, &out, sizeof(out), hipMemcpyHostToDevice, h->stream));
-            // records beyond which a bucket starts in hash sub-ranges: ~2800 distinct k-mers (two thirds of the table)
+            // records beyond which a bucket starts in hash sub-ranges: ~3300 distinct k-mers (80 % of the table: the
+            // mean is 36 %, so this is the far tail -- a bucket counted in sub-ranges turns in-bucket successors into queries)
             uint32_t split_recs = 0;
             if (est_distinct > 0.0 && n_rec)
-                split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(64.0, (CAP * 0.68) / (est_distinct / (double)n_rec)));
+                split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(64.0, (CAP * 0.80) / (est_distinct / (double)n_rec)));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
                                st[where], k, m, n_buckets, (const SkCountOut *)d_out, split_recs, h->phase_limit);
             HIPCHK(h, hipGetLastError());
@@ -3968,11 +4021,11 @@ static int buf_shrink(dbg *h, dbg::Buf &b, uint64_t bytes) {
     if (bytes == 0) bytes = 16;
     if (!b.p || b.bytes <= bytes + (16ull << 20)) return DBG_OK;
     void *p = nullptr;
-    HIPCHK(h, hipMalloc(&p, bytes));
+    HIPCHK(h, hipMallocAsync(&p, bytes, h->stream));
     hipError_t e = hipMemcpyAsync(p, b.p, bytes, hipMemcpyDeviceToDevice, h->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { (void)hipFree(p); h->err = std::string("buf_shrink: ") + hipGetErrorString(e); return DBG_E_HIP; }
-    (void)hipFree(b.p);
+    if (e != hipSuccess) { (void)hipFreeAsync(p, h->stream); h->err = std::string("buf_shrink: ") + hipGetErrorString(e); return DBG_E_HIP; }
+    (void)hipFreeAsync(b.p, h->stream);  // stream order: after the copy
+    h->arena_freed = true;
     b.p = p;
     b.bytes = bytes;
     return DBG_OK;
@@ -3996,10 +4049,10 @@ static int part_compact(dbg *sub, uint64_t n_dir_entries) {
     sub->d_rowptr32 = (uint32_t *)sub->ar_csr[3].p;
     sub->d_col = (uint32_t *)sub->ar_csr[1].p;
     sub->d_ecnt = (uint32_t *)sub->ar_csr[2].p;
-    for (auto &lvl : sub->ar_rec) for (auto &b : lvl) buf_free(b);
-    for (auto &lvl : sub->ar_q) for (auto &b : lvl) buf_free(b);
-    for (int i : {0, 1, 2, 3, 4, 5, 7, 8}) buf_free(sub->ar_misc[i]);
-    buf_free(sub->ar_scan);
+    for (auto &lvl : sub->ar_rec) for (auto &b : lvl) buf_free(sub, b);
+    for (auto &lvl : sub->ar_q) for (auto &b : lvl) buf_free(sub, b);
+    for (int i : {0, 1, 2, 3, 4, 5, 7, 8}) buf_free(sub, sub->ar_misc[i]);
+    buf_free(sub, sub->ar_scan);
     sub->sk_src.valid = false;
     return DBG_OK;
 }
@@ -4053,7 +4106,7 @@ static int build_multipass_t(dbg *h, int k, int n_passes) {
         HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(start.data(), c1_start, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_partition = t.stop();
-        for (auto &b : h->ar_rec[0]) buf_free(b);  // the unsplit records; the split ones (set 1) stay parked for the passes
+        for (auto &b : h->ar_rec[0]) buf_free(h, b);  // the unsplit records; the split ones (set 1) stay parked for the passes
     }
     int shard_bits = 0;
     while ((1 << shard_bits) < n_passes) ++shard_bits;
@@ -4143,8 +4196,8 @@ static int build_multipass_t(dbg *h, int k, int n_passes) {
                 hipLaunchKernelGGL(k_apply_part, dim3(grid_for(sh.q_cnt[q], 256)), dim3(256), 0, h->stream, qcol + sh.q_start[q],
                                    ans, sh.q_cnt[q], (uint8_t)q, sub->d_col, mp->col_owner[p], (unsigned long long *)h->d_scalars);
             }
-            buf_free(sub->ar_shard[0]);
-            buf_free(sub->ar_shard[3]);
+            buf_free(sub, sub->ar_shard[0]);
+            buf_free(sub, sub->ar_shard[3]);
         }
         HIPCHK(h, hipGetLastError());
         uint64_t sc0 = 0;
@@ -4153,7 +4206,7 @@ static int build_multipass_t(dbg *h, int k, int n_passes) {
         if (sc0 & 256) { h->err = "a successor in another part came back unresolved"; return DBG_E_HIP; }
         ms_succ += t.stop();
     }
-    for (auto &b : h->ar_rec[1]) buf_free(b);  // every pass has read its slice of the parked records
+    for (auto &b : h->ar_rec[1]) buf_free(h, b);  // every pass has read its slice of the parked records
     h->n_nodes = mp->base[n_passes];
     h->n_edges = 0;
     for (dbg *sub : mp->part) h->n_edges += sub->n_edges;
@@ -4172,14 +4225,18 @@ extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     if (h->bucket_bits && h->bucket_bits < 9) { h->err = "multi-pass builds split by 9 bits first: bucket_bits must be 0 or >= 9"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     free_build(h);
+    h->arena_freed = true;
+    pool_trim(h);  // the parts of an earlier multi-pass build
     h->stats = dbg_stats_t{};
     CHK(compute_alphabet(h));
     if (!h->is_dna) { h->err = "multi-pass builds take ACGT reads"; return DBG_E_ALPHABET; }
     h->k = k;
     Timer t_total(h->stream);
     int rc = (h->n_bytes < (1ull << 31)) ? build_multipass_t<uint32_t>(h, k, n_passes) : build_multipass_t<uint64_t>(h, k, n_passes);
-    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->arena_freed = true; pool_trim(h); h->err = keep; return rc; }
     h->stats.ms_build_total = t_total.stop();
+    h->arena_freed = true;
+    pool_trim(h);
     return DBG_OK;
 }
 
