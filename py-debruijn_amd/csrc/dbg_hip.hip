@@ -3353,6 +3353,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         Timer t(h->stream);
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
+        // directory of the owned buckets: entries of a bucket that stays empty or is counted in sub-ranges must not
+        // read as "whole bucket" (pad == 1) from an earlier build
+        HIPCHK(h, hipMemsetAsync(dirs, 0, own_cnt * (CAP / 64) * sizeof(SkDirEnt), h->stream));
         SkCountOut out{h->d_keys, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
                        qk[0], qc[0], q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, id_tag, sc_dev};
         auto kern = k_sk_count<ST, CAP>;

@@ -195,3 +195,29 @@ def test_one_rank_over_rccl_equals_the_single_build_with_multi_round_exchange():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("4000000 ")]
     assert lines and lines[-1].endswith(" OK"), out.stdout[-2000:]
+
+
+@pytest.mark.gpu
+def test_a_shard_that_outgrows_its_id_space_fails_loudly():
+    """Sharded successor ids are (owner << 29) | local id: a shard that would hold more nodes than its id space must
+    end in DBG_E_CAPACITY with a message, never in ids that alias another shard (the ceiling is lowered with the
+    "shard_node_limit" option so that a few thousand reads reach it)."""
+    import _dbg
+    import multi_gpu
+
+    def one(dist, rank):
+        reads = rank_reads(2, rank, 8000, 100)
+        g = _dbg.Graph(device=0)
+        g.set_option("shard_node_limit", 5000)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64))
+        try:
+            multi_gpu.sharded_build(g, 21, dist)
+        except _dbg.DbgError as e:
+            return (e.code, str(e))
+        finally:
+            g.close()
+        return None
+
+    # both ranks fail at the same step (each owns half of ~60 000 nodes), so neither waits for the other
+    got = inproc_dist.run_ranks(2, one)
+    assert all(x is not None and x[0] == _dbg.DBG_E_CAPACITY and "capacity" in x[1] for x in got), got

@@ -3,7 +3,7 @@
 #   kernel-trace stats of the default bench command, then separate --pmc passes for HBM traffic and LDS counters.
 # Output: gpurun_out/prof_<tag>/...; tools/pmc_summary.py turns the counter csv files into per-kernel json.
 set -uo pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT"
@@ -16,3 +16,6 @@ for pass in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INS
   python3 tools/pmc_summary.py "$OUT/pmc_$name" > "$OUT/pmc_$name.json"
 done
 cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
+python3 tools/hbm_traffic.py "$OUT/pmc_FETCH_SIZE.json" "$OUT/pmc_WRITE_SIZE.json" > "$OUT/hbm_traffic_pmc.json"
+timeout -k 10 500 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_line.log" 2>&1
+echo "bench rc=$?"
