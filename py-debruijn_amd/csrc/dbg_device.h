@@ -95,19 +95,28 @@ constexpr int HALO = 64;
 constexpr int PK_WORDS = (TILE + HALO) / 16 + 2;  // +2: window reads touch word+2
 constexpr int SB_WORDS = (TILE + HALO) / 32 + 2;
 
-struct TileLds {
-    uint32_t pk[PK_WORDS];
-    uint32_t sb[SB_WORDS];
+// HALO_: positions readable beyond the tile (a window of 32 bases / 64 start bits at tile position j reaches j + 63;
+// the wide super-k-mer extraction looks k - 13 minimizer windows further: dbg_wsk.h uses 128)
+template <int HALO_>
+struct TileLdsT {
+    static constexpr int SPAN = TILE + HALO_;
+    static constexpr int PK = SPAN / 16 + 2;  // +2: window reads touch word+2
+    static constexpr int SB = SPAN / 32 + 2;
+    uint32_t pk[PK];
+    uint32_t sb[SB];
 };
+using TileLds = TileLdsT<HALO>;
+static_assert(TileLds::PK == PK_WORDS && TileLds::SB == SB_WORDS, "tile layout");
 
 // returns nonzero if a byte outside ACGT was seen among the bytes < n_bytes
-__device__ inline uint32_t load_tile(TileLds &t, const char *bases, uint64_t n_bytes, const uint32_t *startbits,
+template <class T>
+__device__ inline uint32_t load_tile(T &t, const char *bases, uint64_t n_bytes, const uint32_t *startbits,
                                      uint64_t tile0) {
     uint32_t bad = 0;
-    for (int v = threadIdx.x; v < PK_WORDS; v += blockDim.x) {
+    for (int v = threadIdx.x; v < T::PK; v += blockDim.x) {
         const uint64_t off = tile0 + (uint64_t)v * 16;
         uint4 q = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);  // 'A' padding
-        if (v < (TILE + HALO) / 16 && off < n_bytes) {
+        if (v < T::SPAN / 16 && off < n_bytes) {
             if (off + 16 <= n_bytes) {
                 q = *reinterpret_cast<const uint4 *>(bases + off);
             } else {
@@ -124,12 +133,13 @@ __device__ inline uint32_t load_tile(TileLds &t, const char *bases, uint64_t n_b
         t.pk[v] = (pack4(q.x) << 24) | (pack4(q.y) << 16) | (pack4(q.z) << 8) | pack4(q.w);
     }
     const uint64_t w0 = tile0 >> 5;
-    for (int v = threadIdx.x; v < SB_WORDS; v += blockDim.x) t.sb[v] = startbits[w0 + v];
+    for (int v = threadIdx.x; v < T::SB; v += blockDim.x) t.sb[v] = startbits[w0 + v];
     return bad;
 }
 
 // 32 bases starting at tile-relative position j, first base in bits 63:62
-__device__ inline uint64_t window32(const TileLds &t, int j) {
+template <class T>
+__device__ inline uint64_t window32(const T &t, int j) {
     const int w = j >> 4, sh = (j & 15) * 2;
     const uint64_t hi = ((uint64_t)t.pk[w] << 32) | t.pk[w + 1];
     const uint64_t lo = (uint64_t)t.pk[w + 2] << 32;
@@ -137,7 +147,8 @@ __device__ inline uint64_t window32(const TileLds &t, int j) {
 }
 
 // read-start bits of positions j .. j+31 (bit 0 = position j)
-__device__ inline uint32_t startwin32(const TileLds &t, int j) {
+template <class T>
+__device__ inline uint32_t startwin32(const T &t, int j) {
     const int w = j >> 5, sh = j & 31;
     const uint64_t both = ((uint64_t)t.sb[w + 1] << 32) | t.sb[w];
     return (uint32_t)(both >> sh);

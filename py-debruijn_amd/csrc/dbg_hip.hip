@@ -26,6 +26,7 @@
 #include "dbg_genref.h"
 #include "dbg_wide.h"
 #include "dbg_support.h"
+#include "dbg_wsk.h"
 
 using namespace dbgk;
 
@@ -120,6 +121,7 @@ struct dbg {
     int lds_slots = 4096;    // LDS table slots per bucket workgroup (2048 or 4096)
     int phase_limit = 0;     // ablation of k_sk_count (timing only; the build then fails on purpose)
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
+    int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
 
     // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
     // so buffers survive across dbg_build calls on the same handle
@@ -1724,6 +1726,7 @@ extern "C" int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets) {
 
 // ------------------------------------------------------------------------------------------
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint);
+static int build_wsk(dbg *h, int k);
 // CSR over distinct edges + start count; shared by both engines
 static int finish_graph(dbg *h) {
     if (!h->csr_built) {
@@ -2009,6 +2012,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "target_distinct" && value >= 0 && value <= 4096) { h->target_distinct = (int)value; return DBG_OK; }
     if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
+    if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
     if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -2136,9 +2140,9 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
         h->stats.ms_build_total = t_total.stop();
         return DBG_OK;
     }
-    if (k > 31) {  // two-word k-mers: reference-keyed global table (dbg_wide.h)
+    if (k > 31) {  // two-word k-mers: the super-k-mer / LDS engine (dbg_wsk.h), or the global reference-keyed table (dbg_wide.h)
         Timer t_total(h->stream);
-        int rc = build_wide(h, k, table_capacity_hint);
+        int rc = (h->wide_engine == 1 && h->engine == 0) ? build_wsk(h, k) : build_wide(h, k, table_capacity_hint);
         if (rc == DBG_OK) rc = finish_graph(h);
         if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
         h->stats.ms_build_total = t_total.stop();
@@ -3467,6 +3471,243 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         h->sk_src.valid = n_rec != 0;
     }
     return DBG_OK;
+}
+
+// ---- two-word k-mers on the super-k-mer engine (dbg_wsk.h): extraction -> two or three multisplit levels -> k_wsk_count
+//      -> k_wsucc_resolve.  Single GPU; the geometry logic is that of sk_count_from_segments with 2048-slot tables.
+template <class ST>
+static int build_wsk_t(dbg *h, int k) {
+    const int m = SK_MAX_M, w = k - m + 1;
+    unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
+    uint64_t sc[8] = {0};
+    // ---- 2-bit packed reads (the records point into them)
+    const uint64_t pk_words = (h->n_bytes + 31) / 32;
+    CHK(buf_ensure(h, h->ar_wide[0], (pk_words + 8) * 8));
+    uint64_t *pk = (uint64_t *)h->ar_wide[0].p;
+    HIPCHK(h, hipMemsetAsync(pk + pk_words, 0, 8 * 8, h->stream));
+    if (pk_words)
+        hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, pk_words, pk);
+    // ---- extraction into one private segment per persistent workgroup
+    const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 2048);
+    CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
+    uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg, *seg_ne = seg_nk + n_wg;
+    std::vector<uint64_t> hseg((size_t)n_wg * 4);
+    uint64_t *w0[2], *w1[2];
+    ST *st[2];
+    uint64_t n_rec = 0;
+    {
+        Timer t(h->stream);
+        const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
+        const double density = std::min(1.0, 2.6 / (double)(w + 1) + 1.3 * (double)(h->n_reads + 1) / (double)(h->n_bytes + 1) + 0.01);
+        uint64_t seg_cap = (uint64_t)((double)(tiles_per_wg * TILE) * density) + 256;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const uint64_t rec_cap = seg_cap * n_wg;
+            for (int set = 0; set < 2; ++set) {
+                CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
+                CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
+                CHK(buf_ensure(h, h->ar_rec[set][2], rec_cap * sizeof(ST)));
+                w0[set] = (uint64_t *)h->ar_rec[set][0].p;
+                w1[set] = (uint64_t *)h->ar_rec[set][1].p;
+                st[set] = (ST *)h->ar_rec[set][2].p;
+            }
+            for (uint32_t g = 0; g < n_wg; ++g) hseg[g] = (uint64_t)g * seg_cap;
+            HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+            if (tiles)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wsk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                                   h->d_startbits, k, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
+            if (!(sc[0] & 4)) break;
+            if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
+            seg_cap = tiles_per_wg * TILE;
+        }
+        h->n_kmer_inst = h->n_edge_inst = 0;
+        for (uint32_t g = 0; g < n_wg; ++g) {
+            n_rec += hseg[n_wg + g];
+            h->n_kmer_inst += hseg[2 * n_wg + g];
+            h->n_edge_inst += hseg[3 * n_wg + g];
+        }
+        h->host_seg_cnt.assign(hseg.begin() + n_wg, hseg.begin() + 2 * (size_t)n_wg);
+        h->stats.ms_extract = t.stop();
+        h->stats.n_records = n_rec;
+    }
+    const uint64_t n_inst = h->n_kmer_inst, n_edge_inst = h->n_edge_inst;
+    // ---- bucket geometry
+    constexpr double TARGET_DISTINCT = WCAP * 0.36;
+    int T = h->bucket_bits;
+    const bool auto_T = (T == 0);
+    if (auto_T) {
+        const double want = (double)n_inst * 0.4 / TARGET_DISTINCT;
+        while (T < 20 && (double)(1ull << T) < want) ++T;
+    }
+    int l1 = T < 9 ? T : (T >= 20 ? 10 : 9), l2 = std::min(10, T - l1);
+    int nb2 = 0, nb3 = (T - l1 - l2) > 0 ? 1 << (T - l1 - l2) : 1;
+    const int nb1 = 1 << l1;
+    CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+    uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
+    int where = 1;
+    double est_distinct = 0.0;
+    const int top = 6 + SK_BUCKET_BITS;
+    Timer t_part(h->stream);
+    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_wg, n_wg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1], top - l1, nb1,
+                                    c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], 0, nullptr, nullptr,
+                                    h->host_seg_cnt.data())));
+    if (auto_T && l1 >= 9 && n_rec) {
+        const uint64_t inst_bucket = (uint64_t)((double)n_inst / nb1) * 2 + 1024;
+        uint64_t set_cap = 1024;
+        while (set_cap < inst_bucket * 2) set_cap <<= 1;
+        CHK(buf_ensure(h, h->ar_misc[8], set_cap * 8));
+        HIPCHK(h, hipMemsetAsync(h->ar_misc[8].p, 0xFF, set_cap * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_scalars + 40, 0, 16, h->stream));
+        hipLaunchKernelGGL(k_wsk_estimate, dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt, 0u, w0[1], w1[1], k, pk,
+                           (unsigned long long *)h->ar_misc[8].p, set_cap - 1, (unsigned long long *)(h->d_scalars + 40));
+        uint64_t est[2] = {0, 0};
+        HIPCHK(h, hipMemcpyAsync(est, h->d_scalars + 40, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (est[0]) {
+            est_distinct = (double)n_inst * (double)est[1] / (double)est[0];
+            const double want = est_distinct / ((double)h->target_distinct > 0 ? (double)h->target_distinct : TARGET_DISTINCT);
+            const double want2 = std::max<double>(1.0, std::ceil(want / nb1));
+            if (want2 <= 1024.0) { nb2 = (int)want2; nb3 = 1; }
+            else { nb2 = 1024; nb3 = (int)std::min<double>((double)(1 << (SK_BUCKET_BITS - l1 - 10)), std::ceil(want2 / 1024.0)); }
+            l2 = nb2 > 1 ? 1 : 0;
+        }
+    }
+    if (nb2 == 0 && l2 > 0) nb2 = 1 << l2;
+    if (l2 == 0) nb3 = 1;
+    const int fb2 = (nb3 == 1 && ((nb2 > 0 && (nb2 & (nb2 - 1)) != 0) || (auto_T && l1 >= 9 && nb2 > 1))) ? SK_BUCKET_BITS - l1 : 0;
+    const uint64_t n_l2 = l2 > 0 ? (uint64_t)nb1 * (uint64_t)nb2 : (uint64_t)nb1;
+    const uint64_t n_buckets = n_l2 * (uint64_t)nb3;
+    const int l2_pow = (fb2 || l2 == 0) ? 0 : (int)std::lround(std::log2((double)nb2));
+    const int fb3 = nb3 > 1 ? SK_BUCKET_BITS - l1 - l2_pow : 0;
+    CHK(buf_ensure(h, h->ar_misc[5], n_buckets * 16));
+    uint64_t *b_start = (uint64_t *)h->ar_misc[5].p, *b_cnt = b_start + n_buckets;
+    uint64_t *l2_start = b_start, *l2_cnt = b_cnt;
+    if (nb3 > 1) {
+        CHK(buf_ensure(h, h->ar_l2, n_l2 * 16));
+        l2_start = (uint64_t *)h->ar_l2.p;
+        l2_cnt = l2_start + n_l2;
+    }
+    if (l2 > 0) {
+        const int sh2 = fb2 ? top - SK_BUCKET_BITS : top - l1 - l2_pow;
+        CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, 1, n_rec, w0[1], w1[1], st[1], w0[0], w1[0], st[0], sh2,
+                                        nb2, l2_start, l2_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
+        where = 0;
+        if (nb3 > 1) {
+            CHK((multisplit_level<ST, true>(h, l2_start, l2_cnt, (uint32_t)n_l2, 1, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+                                            top - SK_BUCKET_BITS, nb3, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb3)));
+            where = 1;
+        }
+    } else {
+        HIPCHK(h, hipMemcpyAsync(b_start, c1_start, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(b_cnt, c1_cnt, (size_t)nb1 * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+    h->stats.ms_partition = t_part.stop();
+    h->stats.n_buckets = n_buckets;
+    // ---- per-bucket counting
+    const uint64_t node_cap_max = std::min<uint64_t>(n_inst, 0xFFFFFFF0ull);
+    const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
+    uint64_t node_cap = node_cap_max;
+    if (est_distinct > 0.0)
+        node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2 * h->est_scale_pct / 100.0) +
+                                                        (h->est_scale_pct == 100 ? (1u << 20) : 1024u));
+    uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
+    uint64_t q_cap = n_rec + 1024;
+    const uint64_t range_cap = n_buckets + 4096 + n_inst / (WCAP / 4);
+    CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
+    SkRange *ranges = (SkRange *)h->ar_misc[6].p;
+    CHK(buf_ensure(h, h->ar_dir, range_cap * (WCAP / 64) * sizeof(SkDirEnt)));
+    SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
+    uint64_t *q_lo = nullptr, *q_hi = nullptr;
+    uint32_t *q_col = nullptr;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
+        CHK(buf_ensure(h, h->ar_wide[5], node_cap * 8));
+        CHK(buf_ensure(h, h->ar_node[sizeof(ST) == 8 ? 1 : 7], node_cap * sizeof(ST)));
+        CHK(buf_ensure(h, h->ar_node[3], node_cap));
+        CHK(buf_ensure(h, h->ar_csr[3], (node_cap + 1) * 4));
+        CHK(buf_ensure(h, h->ar_csr[1], edge_cap * 4));
+        CHK(buf_ensure(h, h->ar_csr[2], edge_cap * 4));
+        CHK(buf_ensure(h, h->ar_q[0][0], q_cap * 8));
+        CHK(buf_ensure(h, h->ar_q[0][1], q_cap * 8));
+        CHK(buf_ensure(h, h->ar_q[0][2], q_cap * 4));
+        h->d_keys = (uint64_t *)h->ar_node[0].p;
+        h->d_keys_hi = (uint64_t *)h->ar_wide[5].p;
+        h->d_stamps_st = h->ar_node[sizeof(ST) == 8 ? 1 : 7].p;
+        h->stamps_st_bytes = (int)sizeof(ST);
+        h->d_stamps = sizeof(ST) == 8 ? (uint64_t *)h->d_stamps_st : nullptr;
+        h->d_flags = (uint8_t *)h->ar_node[3].p;
+        h->nodes_in_arena = true;
+        h->d_rowptr32 = (uint32_t *)h->ar_csr[3].p;
+        h->d_col = (uint32_t *)h->ar_csr[1].p;
+        h->d_ecnt = (uint32_t *)h->ar_csr[2].p;
+        q_lo = (uint64_t *)h->ar_q[0][0].p; q_hi = (uint64_t *)h->ar_q[0][1].p; q_col = (uint32_t *)h->ar_q[0][2].p;
+        Timer t(h->stream);
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
+        HIPCHK(h, hipMemsetAsync(dirs, 0, n_buckets * (WCAP / 64) * sizeof(SkDirEnt), h->stream));
+        WSkCountOut out{h->d_keys, h->d_keys_hi, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
+                        q_lo, q_hi, q_col, q_cap, ranges, n_buckets, range_cap, dirs, 0, n_buckets, sc_dev};
+        auto kern = k_wsk_count<ST>;
+        const size_t lds = sizeof(WCntLds<ST>);
+        HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (n_rec) {
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);
+            uint32_t split_recs = 0;
+            if (est_distinct > 0.0) split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(16.0, (WCAP * 0.80) / (est_distinct / (double)n_rec)));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(WCNT_NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where], st[where], pk, k,
+                               n_buckets, out, split_recs);
+            HIPCHK(h, hipGetLastError());
+        }
+        h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;
+        HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
+        h->stats.ms_count = t.stop();
+        if (sc[0] & (8 | 32)) break;
+        bool again = false;
+        if ((sc[0] & 16) && (node_cap < node_cap_max || edge_cap < edge_cap_max)) { node_cap = node_cap_max; edge_cap = edge_cap_max; again = true; }
+        if ((sc[0] & 64) && q_cap < n_edge_inst + 1024) { q_cap = n_edge_inst + 1024; again = true; }
+        if (!again || attempt == 2) break;
+    }
+    if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
+    if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }
+    if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
+    h->n_nodes = sc[4] & 0xFFFFFFFFull;
+    h->n_edges = sc[4] >> 32;
+    {
+        const uint32_t ne32 = (uint32_t)h->n_edges;
+        HIPCHK(h, hipMemcpyAsync(h->d_rowptr32 + h->n_nodes, &ne32, 4, hipMemcpyHostToDevice, h->stream));
+    }
+    h->csr_built = true;
+    h->dense_pending = true;
+    const uint64_t n_q = sc[5], n_ranges = n_buckets + sc[6];
+    h->stats.n_queries = n_q;
+    SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, nb3, fb3, 0, 0, 0, n_buckets};
+    {
+        Timer t(h->stream);
+        if (n_q) {
+            hipLaunchKernelGGL(k_wsucc_resolve, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, q_lo, q_hi, q_col, n_q, geom, ranges,
+                               n_buckets, n_ranges, dirs, h->d_keys, h->d_keys_hi, h->n_nodes, h->d_col, sc_dev);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            if (sc[0] & 128) { h->err = "internal: a successor k-mer was not found in its bucket"; return DBG_E_HIP; }
+        }
+        h->stats.ms_succ = t.stop();
+    }
+    h->sk_src.valid = false;  // the per-range kernels of dbg_refine_edge_order / dbg_mark_pull_reads read one-word records
+    return DBG_OK;
+}
+
+static int build_wsk(dbg *h, int k) {
+    return h->n_bytes < (1ull << 31) ? build_wsk_t<uint32_t>(h, k) : build_wsk_t<uint64_t>(h, k);
 }
 
 template <class ST, int CAP>

@@ -67,7 +67,8 @@ __device__ inline K128 packed_kmer(const uint64_t *__restrict__ pk, uint64_t p, 
 }
 
 // read-start bits of positions j .. j+63 (bit 0 = position j)
-__device__ inline uint64_t startwin64(const TileLds &t, int j) {
+template <class T>
+__device__ inline uint64_t startwin64(const T &t, int j) {
     const int w = j >> 5, sh = j & 31;
     const uint64_t lo = ((uint64_t)t.sb[w + 1] << 32) | t.sb[w];
     const uint64_t hi = t.sb[w + 2];

@@ -1,0 +1,700 @@
+// Super-k-mer engine for two-word k-mers: 32 <= k <= 63 over ACGT (BASELINE.json configs[4] key width).
+//
+// The one-word engine (dbg_sk.h) with three differences that follow from the key width:
+//   * a super-k-mer holds up to k - 12 k-mers of k bases each -- up to 115 bases, four words -- so a record does not
+//     carry bases: w0 = position of its first k-mer in the 2-bit packed reads (k_wpack), w1 = bucket hash | length |
+//     flags, st = stamp.  Same three arrays as the one-word records: the multisplit kernels move them unchanged,
+//     and there are only N_k / 26 of them at k = 63.  The count kernel reads each record's bases once from the packed
+//     reads (40 contiguous bytes) into LDS, aligned.
+//   * the LDS table holds 128-bit keys.  There is no 128-bit LDS atomic: a slot is claimed by a 64-bit
+//     compare-and-swap on the HIGH word (at most 62 significant bits, so all-ones marks "empty" and bit 63 "low word
+//     not written yet"), the winner stores the low word and then the high word without the pending bit; a probe
+//     that meets a pending slot looks again.  After the insert phase nothing is pending and every later phase reads
+//     plain keys.
+//   * 2048 slots per bucket (16-byte keys), ~740 nodes per bucket.
+// Everything else -- dedupe of identical records, quads of 4 k-mers on 4 lanes, dense node list + CSR edge offsets
+// from ballots, in-bucket successor lookup, one packed global reservation per bucket, directory for the resolver,
+// hash sub-ranges for oversized buckets -- is the design of k_sk_count; see there for the reasons.
+//
+//   k_wsk_extract   reads -> records                                           [debruijn.py:123-128 windows]
+//   k_wsk_estimate  distinct / instances of one level-1 bucket (sizes the partition)
+//   k_wsk_count     per-bucket counting in LDS -> keys (lo, hi), stamps, flags, CSR  [debruijn.py:129-143, :213-222]
+//   k_wsucc_resolve successors that live in another bucket, through the directory
+#pragma once
+#include "dbg_sk.h"
+#include "dbg_wide.h"
+
+namespace dbgk {
+
+constexpr int WSK_HALO = 128;
+using TileLdsW = TileLdsT<WSK_HALO>;
+
+// record meta word: bits 27..6 bucket hash (where the one-word records keep it: ms_child is shared), bits 33..28
+// length - 1 (a super-k-mer holds at most k - 12 <= 51 k-mers), bit 0: the last k-mer has a successor
+__host__ __device__ inline int wrec_len(uint64_t w1) { return (int)((w1 >> SK_META_BITS) & 63) + 1; }
+__host__ __device__ inline uint32_t wrec_has_succ(uint64_t w1) { return (uint32_t)(w1 & 1); }
+
+// 2m bits of a 2k-bit K128 value starting `off` bits above its least significant bit (off + 2m <= 2k)
+__device__ inline uint32_t k128_bits(K128 v, int off, uint32_t mask) {
+    if (off >= 64) return (uint32_t)(v.hi >> (off - 64)) & mask;
+    const uint64_t lo = v.lo >> off;
+    return (uint32_t)(off ? lo | (v.hi << (64 - off)) : lo) & mask;
+}
+
+// minimizer-hash bucket of a two-word k-mer: the same choice as the extraction (smallest 16-bit hash, leftmost on ties)
+__device__ inline uint32_t wkmer_bucket22(K128 kmer, int k, int m) {
+    const int w = k - m + 1;
+    const uint32_t mmask = (uint32_t)((1ull << (2 * m)) - 1);
+    uint32_t best = 0xFFFFFFFFu, best_mm = 0;
+    for (int i = 0; i < w; ++i) {
+        const uint32_t mm = k128_bits(kmer, 2 * (k - m - i), mmask);
+        const uint32_t hv = mmer_hash16(mm);
+        if (hv < best) { best = hv; best_mm = mm; }
+    }
+    return bucket_hash22(best_mm);
+}
+
+constexpr int WCAP = 2048;                                              // LDS table slots per bucket
+__device__ inline uint32_t wslot_of(K128 key) { return (uint32_t)(k128_hash(key) >> 53); }           // 11 bits
+__device__ inline uint32_t wsub_hash(K128 key) { return fmix32((uint32_t)(k128_hash(key) >> 11) ^ 0x27D4EB2Fu); }
+
+// ------------------------------------------------------------------------------------------------
+// extraction: the generic kernel of dbg_sk.h (window minimum by a loop over the w m-mer hashes of the tile) with
+// 64-bit read-start windows and positions instead of bases in the records
+// ------------------------------------------------------------------------------------------------
+struct WSkLds {
+    TileLdsW t;
+    uint16_t hm[TILE + WSK_HALO];   // 16-bit m-mer hash per position
+    uint8_t minp[TILE];             // minimizer offset (0..w-1) from the k-mer position, 0xFF = no k-mer
+    unsigned long long sbits[TILE / 64 + 1];
+    unsigned long long vbits[TILE / 64 + 1];
+    uint32_t wpre[TILE / 64 + 1];
+    uint16_t list[TILE];
+    uint32_t nrec;
+};
+
+template <class ST>
+__global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ bases, uint64_t n_bytes,
+                                                     const uint32_t *__restrict__ startbits, int k, uint64_t n_tiles,
+                                                     uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
+                                                     uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
+                                                     unsigned long long *scalars /* [0] err */) {
+    __shared__ WSkLds s;
+    __shared__ uint64_t red[8];
+    constexpr int m = SK_MAX_M;
+    const int w = k - m + 1;
+    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
+    uint64_t cursor = 0;
+    const uint64_t mid_mask = (1ull << (k - 1)) - 1ull;
+    uint64_t n_k = 0, n_e = 0;
+    bool overflow = false;
+    for (uint64_t tile = t_beg; tile < t_end; ++tile) {
+        const uint64_t tile0 = tile * TILE;
+        __syncthreads();
+        const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
+        if (bad) atomicOr(&scalars[0], 1ull);
+        __syncthreads();
+        for (int j = threadIdx.x; j < TILE + WSK_HALO - 32; j += 256)
+            s.hm[j] = (uint16_t)mmer_hash16((uint32_t)(window32(s.t, j) >> (64 - 2 * m)));
+        __syncthreads();
+        for (int j0 = 0; j0 < TILE; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            const uint64_t p = tile0 + j;
+            bool v = false;
+            uint32_t mp = 0xFFu;
+            if (p < n_bytes) {
+                const uint64_t sw = startwin64(s.t, j);
+                const uint32_t s0 = (uint32_t)(sw & 1ull), sk = (uint32_t)(sw >> k) & 1u;
+                v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0) && (p + (uint64_t)k <= n_bytes);
+                if (v) {
+                    n_k += 1;
+                    n_e += sk ^ 1u;
+                    uint32_t best = s.hm[j];
+                    mp = 0;
+                    for (int i = 1; i < w; ++i) {
+                        const uint32_t hv = s.hm[j + i];
+                        if (hv < best) { best = hv; mp = i; }
+                    }
+                }
+            }
+            s.minp[j] = (uint8_t)mp;
+            const unsigned long long vb = __ballot(v);
+            if ((threadIdx.x & 63) == 0) s.vbits[j >> 6] = vb;
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < TILE; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            const uint32_t mp = s.minp[j];
+            const bool st = (mp != 0xFFu) && (j == 0 || (uint32_t)s.minp[j - 1] != mp + 1);
+            const unsigned long long sb = __ballot(st);
+            if ((threadIdx.x & 63) == 0) s.sbits[j >> 6] = sb;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            uint32_t a = __popcll(s.sbits[threadIdx.x]), b = __popcll(s.sbits[threadIdx.x + 64]);
+            uint32_t ia = a, ib = b;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+                if ((int)threadIdx.x >= d) { ia += oa; ib += ob; }
+            }
+            const uint32_t tot_a = __shfl(ia, 63, 64);
+            s.wpre[threadIdx.x] = ia - a;
+            s.wpre[threadIdx.x + 64] = tot_a + ib - b;
+            if (threadIdx.x == 63) s.nrec = tot_a + ib;
+            if (threadIdx.x == 0) { s.sbits[TILE / 64] = 0; s.vbits[TILE / 64] = 0; }
+        }
+        __syncthreads();
+        const uint32_t nrec = s.nrec;
+        if (cursor + nrec > seg_cap) { overflow = true; break; }
+        const uint64_t gbase = seg0 + cursor;
+        cursor += nrec;
+        for (int j0 = 0; j0 < TILE; j0 += 256) {
+            const int j = j0 + threadIdx.x;
+            const unsigned long long sb = s.sbits[j >> 6];
+            if ((sb >> (j & 63)) & 1ull) s.list[s.wpre[j >> 6] + __popcll(sb & ((1ull << (j & 63)) - 1))] = (uint16_t)j;
+        }
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < nrec; r += 256) {
+            const int j = s.list[r];
+            const int wd = j >> 6, bt = j & 63;
+            const unsigned long long sb = s.sbits[wd];
+            const unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
+            const unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
+            const int room = 63 - bt;
+            const unsigned long long stop = nxt_s | nxt_i;
+            int len;
+            if (stop) {
+                len = 1 + (__ffsll((unsigned long long)stop) - 1);
+            } else {
+                const unsigned long long stop2 = s.sbits[wd + 1] | ~s.vbits[wd + 1];
+                len = 1 + room + (__ffsll((unsigned long long)stop2) - 1);
+            }
+            if (j + len > TILE) len = TILE - j;
+            const uint64_t p = tile0 + j;
+            const uint32_t s0 = (uint32_t)(startwin64(s.t, j) & 1ull);
+            const uint32_t sk_last = (uint32_t)(startwin64(s.t, j + len - 1) >> k) & 1u;
+            const uint32_t has_succ = sk_last ^ 1u;
+            const uint32_t mp = j + s.minp[j];
+            const uint32_t bh = bucket_hash22((uint32_t)(window32(s.t, mp) >> (64 - 2 * m)));
+            const uint64_t o = gbase + r;
+            rec_w0[o] = p;
+            rec_w1[o] = ((uint64_t)(len - 1) << SK_META_BITS) | ((uint64_t)bh << 6) | has_succ;
+            rec_st[o] = (ST)((p << 1) | (s0 ^ 1u));
+        }
+    }
+    if (overflow && threadIdx.x == 0) atomicOr(&scalars[0], 4ull);
+    n_k = wave_sum_u64(n_k);
+    n_e = wave_sum_u64(n_e);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = n_k; red[4 + (threadIdx.x >> 6)] = n_e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        seg_cnt[blockIdx.x] = cursor;
+        seg_nk[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        seg_ne[blockIdx.x] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
+// distinct / instances of the records of one segment (a level-1 bucket): 64-bit hashes of the k-mers in a global set
+__global__ __launch_bounds__(256) void k_wsk_estimate(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
+                                                      uint32_t bucket, const uint64_t *__restrict__ rec_w0,
+                                                      const uint64_t *__restrict__ rec_w1, int k,
+                                                      const uint64_t *__restrict__ pk, unsigned long long *set, uint64_t set_mask,
+                                                      unsigned long long *out /* [0] instances [1] distinct */) {
+    const uint64_t beg = b_start[bucket], n = b_cnt[bucket];
+    uint64_t inst = 0, fresh = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t p = rec_w0[beg + r];
+        const int len = wrec_len(rec_w1[beg + r]);
+        for (int i = 0; i < len; ++i) {
+            unsigned long long hv = k128_hash(packed_kmer(pk, p + i, k));
+            if (hv == EMPTY_KEY) hv = 0;
+            ++inst;
+            uint64_t slot = hv & set_mask;
+            for (uint64_t probe = 0; probe <= set_mask; ++probe) {
+                unsigned long long cur = set[slot];
+                if (cur == EMPTY_KEY) {
+                    cur = atomicCAS(&set[slot], EMPTY_KEY, hv);
+                    if (cur == EMPTY_KEY) { ++fresh; break; }
+                }
+                if (cur == hv) break;
+                slot = (slot + 1) & set_mask;
+            }
+        }
+    }
+    inst = wave_sum_u64(inst);
+    fresh = wave_sum_u64(fresh);
+    if ((threadIdx.x & 63) == 0) {
+        if (inst) atomicAdd(&out[0], (unsigned long long)inst);
+        if (fresh) atomicAdd(&out[1], (unsigned long long)fresh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-bucket counting in LDS
+// ------------------------------------------------------------------------------------------------
+constexpr int WCNT_NT = 1024;
+constexpr int WCNT_STAGE = 192;      // records staged per round (a bucket holds ~55 at the default geometry)
+constexpr int WCNT_QMAX = 13;        // quads of 4 k-mers per record: ceil(51 / 4)
+constexpr int WCNT_QBUF = 320;       // cross-bucket successor queries staged per bucket
+constexpr int WCNT_DD = 512;         // dedupe set slots (>= 2 * WCNT_STAGE)
+constexpr unsigned long long W_PEND = 1ull << 63;
+
+template <class ST>
+struct WCntLds {
+    unsigned long long khi[WCAP];   // EMPTY_KEY / hi | W_PEND / hi   (hi < 2^62)
+    unsigned long long klo[WCAP];
+    uint32_t cnt[WCAP * 4];
+    ST stamp[WCAP];
+    uint16_t list[WCAP];            // local node index -> slot
+    uint16_t eoff[WCAP];            // local node index -> first CSR edge of the node, relative to the bucket
+    unsigned long long rb[WCNT_STAGE][4];  // staged records: bases, aligned (first base in bits 63:62 of word 0), zero beyond
+    unsigned long long rmeta[WCNT_STAGE];
+    ST rst[WCNT_STAGE];
+    uint32_t dd_tab[WCNT_DD];
+    uint32_t dd_mult[WCNT_STAGE];
+    uint16_t flat[WCNT_STAGE * WCNT_QMAX];
+    unsigned long long q_lo[WCNT_QBUF], q_hi[WCNT_QBUF];
+    uint32_t q_off[WCNT_QBUF];
+    uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
+    uint32_t overflow, n_local, n_q, fail, n_flat;
+    unsigned long long gbase, qbase, ebase, ri;
+    unsigned long long dir_mask[WCAP / 64];
+    uint16_t dir_base[WCAP / 64];
+};
+
+struct WSkCountOut {
+    uint64_t *keys, *keys_hi;
+    void *stamps;              // ST[node_cap]
+    uint8_t *flags;            // (stamp & 1) | present-base mask << 1
+    uint64_t node_cap;
+    uint32_t *rowptr, *col, *ecnt;
+    uint64_t edge_cap;
+    uint64_t *q_lo, *q_hi;     // cross-bucket successors: the successor k-mer ...
+    uint32_t *q_col;           // ... and the CSR position to patch
+    uint64_t q_cap;
+    SkRange *ranges;
+    uint64_t n_buckets, range_cap;
+    SkDirEnt *dirs;
+    uint64_t own_lo, own_cnt;
+    unsigned long long *scalars;  // [0] err [4] nodes | edges << 32 [5] queries [6] extra ranges
+};
+
+__device__ inline int wlds_find(const unsigned long long *khi, const unsigned long long *klo, K128 key) {
+    uint32_t slot = wslot_of(key);
+    for (int probe = 0; probe < WCAP; ++probe) {
+        const unsigned long long cur = khi[slot];
+        if (cur == EMPTY_KEY) return -1;
+        if (cur == key.hi && klo[slot] == key.lo) return (int)slot;
+        slot = (slot + 1) & (WCAP - 1);
+    }
+    return -1;
+}
+
+template <class ST>
+__global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
+                                                      const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
+                                                      const ST *__restrict__ rec_st, const uint64_t *__restrict__ pk, int k,
+                                                      uint64_t n_buckets, WSkCountOut out, uint32_t split_recs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wcnt_raw[];
+    WCntLds<ST> &s = *reinterpret_cast<WCntLds<ST> *>(wcnt_raw);
+    constexpr int NPT = WCAP / WCNT_NT;
+    static_assert(WCNT_DD >= 2 * WCNT_STAGE && WCNT_STAGE <= WCNT_NT, "staging");
+    bool clean = false;
+    if (threadIdx.x == 0) s.fail = 0;
+    for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
+        const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
+        if (r_n == 0) continue;
+        uint32_t stk_n = 1;
+        bool root = true, failed = false;
+        if (split_recs && r_n > split_recs) {
+            uint32_t parts = 2;
+            while (parts < 16 && (uint64_t)parts * split_recs < r_n) parts <<= 1;
+            __syncthreads();
+            if (threadIdx.x < parts) { s.stk_mask[threadIdx.x] = parts - 1; s.stk_val[threadIdx.x] = threadIdx.x; }
+            stk_n = parts;
+            root = false;
+            __syncthreads();
+        }
+        while (stk_n) {
+            uint32_t cur_mask = 0, cur_val = 0;
+            --stk_n;
+            if (!root) { cur_mask = s.stk_mask[stk_n]; cur_val = s.stk_val[stk_n]; }
+            root = false;
+            __syncthreads();
+            if (!clean) {
+                for (int i = threadIdx.x; i < WCAP; i += WCNT_NT) {
+                    s.khi[i] = EMPTY_KEY;
+                    s.stamp[i] = (ST)~(ST)0;
+                    reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+                }
+            }
+            clean = false;
+            if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; }
+            // ---- insert
+            for (uint64_t c0 = 0; c0 < r_n; c0 += WCNT_STAGE) {
+                const uint32_t n_st = (uint32_t)min((uint64_t)WCNT_STAGE, r_n - c0);
+                if (c0) __syncthreads();
+                if (threadIdx.x == 0) s.n_flat = 0;
+                if (threadIdx.x < n_st) {  // one record per thread: its bases from the packed reads, aligned
+                    const uint64_t p = rec_w0[r_beg + c0 + threadIdx.x], w1 = rec_w1[r_beg + c0 + threadIdx.x];
+                    const int nb = k + wrec_len(w1) - 1 + (int)wrec_has_succ(w1);  // bases the record covers (<= 115)
+                    const uint64_t wi = p >> 5;
+                    const int sh = (int)(p & 31) * 2;
+                    uint64_t W[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) W[j] = pk[wi + j];  // (the packed array is padded)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint64_t v = sh ? (W[j] << sh) | (W[j + 1] >> (64 - sh)) : W[j];
+                        const int have = nb - 32 * j;  // bases of this word that belong to the record
+                        if (have <= 0) v = 0;
+                        else if (have < 32) v &= ~0ull << (64 - 2 * have);
+                        s.rb[threadIdx.x][j] = v;
+                    }
+                    s.rmeta[threadIdx.x] = w1;
+                    s.rst[threadIdx.x] = rec_st[r_beg + c0 + threadIdx.x];
+                    s.dd_mult[threadIdx.x] = 0;
+                }
+                for (uint32_t i = threadIdx.x; i < WCNT_DD; i += WCNT_NT) s.dd_tab[i] = 0xFFFFFFFFu;
+                __syncthreads();
+                if (s.overflow) break;
+                // ---- identical records collapse to one representative with a multiplicity and the smallest stamp
+                if (threadIdx.x < n_st) {
+                    const uint32_t r = threadIdx.x;
+                    const unsigned long long b0 = s.rb[r][0], b1 = s.rb[r][1], b2 = s.rb[r][2], b3 = s.rb[r][3];
+                    const unsigned long long mt = s.rmeta[r] & ~(((1ull << SK_BUCKET_BITS) - 1) << 6);  // length + flag
+                    uint32_t hslot = (uint32_t)(mix64(b0 ^ mix64(b1 + 0x9E3779B97F4A7C15ull) ^ mix64(b2 ^ (b3 * 0xD6E8FEB86659FD93ull)) ^ mt) >> 40) &
+                                     (WCNT_DD - 1);
+                    uint32_t rep = r;
+                    for (uint32_t probe = 0; probe < WCNT_DD; ++probe) {
+                        uint32_t cur = s.dd_tab[hslot];
+                        if (cur == 0xFFFFFFFFu) {
+                            cur = atomicCAS(&s.dd_tab[hslot], 0xFFFFFFFFu, r);
+                            if (cur == 0xFFFFFFFFu) break;
+                        }
+                        if (s.rb[cur][0] == b0 && s.rb[cur][1] == b1 && s.rb[cur][2] == b2 && s.rb[cur][3] == b3 &&
+                            (s.rmeta[cur] & ~(((1ull << SK_BUCKET_BITS) - 1) << 6)) == mt) { rep = cur; break; }
+                        hslot = (hslot + 1) & (WCNT_DD - 1);
+                    }
+                    atomicAdd(&s.dd_mult[rep], 1u);
+                    if (rep != r) atomicMin(&s.rst[rep], s.rst[r]);
+                }
+                __syncthreads();
+                {
+                    const uint32_t r = threadIdx.x;
+                    uint32_t nquad = 0;
+                    if (r < n_st && s.dd_mult[r]) nquad = ((uint32_t)wrec_len(s.rmeta[r]) + 3) >> 2;
+                    const uint32_t base = wave_alloc_n<WCNT_QMAX>(&s.n_flat, nquad);
+                    for (uint32_t q = 0; q < nquad; ++q) s.flat[base + q] = (uint16_t)((r << 4) | q);
+                }
+                __syncthreads();
+                const uint32_t n_flat = s.n_flat;
+                for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += WCNT_NT / 4) {
+                    const uint32_t e = s.flat[f];
+                    const uint32_t r = e >> 4;
+                    const int i = (int)((e & 15) * 4 + (threadIdx.x & 3));
+                    const unsigned long long w1 = s.rmeta[r];
+                    const int len = wrec_len(w1);
+                    if (i >= len) continue;
+                    const int wi = i >> 5, sh = (i & 31) * 2;
+                    const unsigned long long a0 = s.rb[r][wi], a1 = s.rb[r][wi + 1], a2 = s.rb[r][wi + 2];
+                    const uint64_t A = sh ? (a0 << sh) | (a1 >> (64 - sh)) : a0;
+                    const uint64_t B = sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1;
+                    const K128 key = k128_from_windows(A, B, k);
+                    if (cur_mask && (wsub_hash(key) & cur_mask) != cur_val) continue;
+                    const bool has_succ = (i < len - 1) || wrec_has_succ(w1);
+                    const uint32_t b = base_after_kmer(B, k);
+                    const ST st0 = s.rst[r];
+                    const ST stamp = i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0;
+                    const uint32_t mult = s.dd_mult[r];
+                    uint32_t slot = wslot_of(key);
+                    bool ok = false;
+                    for (int probe = 0, spins = 0; probe < CNT_PROBE_LIMIT && spins < (1 << 20); ) {
+                        unsigned long long cur = __hip_atomic_load(&s.khi[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (cur == EMPTY_KEY) {
+                            cur = atomicCAS(&s.khi[slot], EMPTY_KEY, key.hi | W_PEND);
+                            if (cur == EMPTY_KEY) {  // claimed: publish the low word, then the high word without the pending bit
+                                __hip_atomic_store(&s.klo[slot], key.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(&s.khi[slot], key.hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                ok = true;
+                                break;
+                            }
+                        }
+                        if (cur & W_PEND) { ++spins; continue; }  // its low word is on the way: look again
+                        if (cur == key.hi &&
+                            __hip_atomic_load(&s.klo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.lo) { ok = true; break; }
+                        slot = (slot + 1) & (WCAP - 1);
+                        ++probe;
+                    }
+                    if (!ok) { s.overflow = 1; continue; }
+                    if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], mult);
+                    atomicMin(&s.stamp[slot], stamp);
+                }
+            }
+            __syncthreads();
+            if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
+                const uint32_t bit = cur_mask + 1;
+                if (stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
+                    if (threadIdx.x == 0) atomicOr(&out.scalars[0], 8ull);
+                    failed = true;
+                    break;
+                }
+                if (threadIdx.x == 0) {
+                    s.stk_mask[stk_n] = cur_mask | bit; s.stk_val[stk_n] = cur_val;
+                    s.stk_mask[stk_n + 1] = cur_mask | bit; s.stk_val[stk_n + 1] = cur_val | bit;
+                }
+                stk_n += 2;
+                __syncthreads();
+                continue;
+            }
+            // ---- dense list of occupied slots + CSR edge offsets
+            for (int i = threadIdx.x; i < WCAP; i += WCNT_NT) {
+                const bool occ = s.khi[i] != EMPTY_KEY;
+                uint32_t deg = 0;
+                if (occ) {
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
+                    deg = (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
+                }
+                const unsigned long long mask = __ballot(occ);
+                if ((threadIdx.x & 63) == 0) s.dir_mask[i >> 6] = mask;
+                if (mask) {
+                    uint32_t eexc = 0, etot = 0;
+#pragma unroll
+                    for (int j = 1; j <= 4; ++j) {
+                        const unsigned long long mj = __ballot(deg >= (uint32_t)j);
+                        eexc += lanes_below(mj);
+                        etot += (uint32_t)__popcll(mj);
+                    }
+                    uint32_t base = 0;
+                    if ((threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if ((threadIdx.x & 63) == 0) s.dir_base[i >> 6] = (uint16_t)base;
+                    if (occ) {
+                        const uint32_t li = (base & 0xFFFFu) + lanes_below(mask);
+                        s.list[li] = (uint16_t)i;
+                        s.eoff[li] = (uint16_t)((base >> 16) + eexc);
+                    }
+                }
+            }
+            __syncthreads();
+            const uint32_t n_local = s.n_local & 0xFFFFu, n_edges_local = s.n_local >> 16;
+            unsigned long long got = 0;
+            if (threadIdx.x == 0)
+                got = atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
+            // ---- successor lookups into registers; misses are staged as queries
+            unsigned long long nsucc[NPT];
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                nsucc[u] = ~0ull;
+                if ((uint32_t)(u * WCNT_NT) >= n_local) continue;
+                const uint32_t li = threadIdx.x + u * WCNT_NT;
+                K128 key{0, 0};
+                uint32_t nz = 0;
+                if (li < n_local) {
+                    const uint32_t sl = s.list[li];
+                    key.hi = s.khi[sl];
+                    key.lo = s.klo[sl];
+                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[sl];
+                    nz = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
+                }
+                const uint32_t nz_all = nz;
+                uint32_t missmask = 0;
+                while (nz) {
+                    const uint32_t b = __ffs(nz) - 1;
+                    nz &= nz - 1;
+                    const int f = wlds_find(s.khi, s.klo, k128_append(key, b, k));
+                    if (f >= 0) {
+                        const uint32_t ix = (uint32_t)s.dir_base[f >> 6] +
+                                            (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                        nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | ((unsigned long long)ix << (16 * b));
+                    } else {
+                        missmask |= 1u << b;
+                    }
+                }
+                uint32_t qi = wave_alloc_n<4>(&s.n_q, (uint32_t)__popc(missmask));
+                while (missmask) {
+                    const uint32_t b = __ffs(missmask) - 1;
+                    missmask &= missmask - 1;
+                    unsigned long long code;
+                    if (qi < WCNT_QBUF) {
+                        const K128 sk = k128_append(key, b, k);
+                        s.q_lo[qi] = sk.lo;
+                        s.q_hi[qi] = sk.hi;
+                        s.q_off[qi] = s.eoff[li] + __popc(nz_all & ((1u << b) - 1u));
+                        code = 0xFFFEull;
+                    } else {
+                        code = 0x8000ull | (qi - WCNT_QBUF);
+                    }
+                    nsucc[u] = (nsucc[u] & ~(0xFFFFull << (16 * b))) | (code << (16 * b));
+                    ++qi;
+                }
+            }
+            if (threadIdx.x == 0) {
+                const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
+                s.gbase = base;
+                s.ebase = eb;
+                if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
+                if (eb + n_edges_local > out.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
+                uint64_t ri = bucket;
+                if (cur_mask) {
+                    ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
+                    if (ri >= out.range_cap || ri >= 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 32ull); s.fail = 1; }
+                }
+                s.ri = ri;
+                if (!s.fail) {
+                    SkRange rg;
+                    rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
+                    rg.next = 0; rg.pad = 0;
+                    if (cur_mask) {
+                        rg.next = out.ranges[bucket].next;
+                        out.ranges[bucket].next = (uint32_t)ri;
+                    }
+                    out.ranges[ri] = rg;
+                }
+            }
+            __syncthreads();
+            const uint32_t nq = s.n_q;
+            unsigned long long qgot = 0;
+            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);
+            if (s.fail) break;
+            const uint64_t gbase = s.gbase, ebase = s.ebase;
+            // ---- write nodes and their CSR rows; every slot read is cleared for the next bucket
+            if (threadIdx.x < WCAP / 64) {
+                SkDirEnt de;
+                de.mask = s.dir_mask[threadIdx.x];
+                de.base = (uint32_t)(gbase + s.dir_base[threadIdx.x]);
+                de.pad = s.ri < out.n_buckets ? 1u : 0u;
+                const uint64_t di = s.ri < out.n_buckets ? s.ri - out.own_lo : out.own_cnt + (s.ri - out.n_buckets);
+                out.dirs[di * (WCAP / 64) + threadIdx.x] = de;
+            }
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                if ((uint32_t)(u * WCNT_NT) >= n_local) break;
+                const uint32_t li = threadIdx.x + u * WCNT_NT;
+                if (li >= n_local) continue;
+                const uint32_t i = s.list[li];
+                const unsigned long long khi = s.khi[i], klo = s.klo[i];
+                const uint64_t node = gbase + li;
+                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
+                const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+                const ST stamp = s.stamp[i];
+                s.khi[i] = EMPTY_KEY;
+                s.stamp[i] = (ST)~(ST)0;
+                reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+                out.keys[node] = klo;
+                out.keys_hi[node] = khi;
+                reinterpret_cast<ST *>(out.stamps)[node] = stamp;
+                out.flags[node] = (uint8_t)((uint32_t)(stamp & 1) | ((c[0] != 0) << 1) | ((c[1] != 0) << 2) | ((c[2] != 0) << 3) |
+                                            ((c[3] != 0) << 4));
+                uint64_t e = ebase + s.eoff[li];
+                out.rowptr[node] = (uint32_t)e;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (c[b]) {
+                        const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
+                        out.col[e] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
+                        out.ecnt[e] = c[b];
+                        ++e;
+                    }
+                }
+            }
+            if (threadIdx.x == 64 && nq) {
+                s.qbase = qgot;
+                if (qgot + nq > out.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+            }
+            __syncthreads();
+            if (s.fail) break;
+            if (nq) {
+                const uint64_t qbase = s.qbase;
+                for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)WCNT_QBUF); i += WCNT_NT) {
+                    out.q_lo[qbase + i] = s.q_lo[i];
+                    out.q_hi[qbase + i] = s.q_hi[i];
+                    out.q_col[qbase + i] = (uint32_t)(ebase + s.q_off[i]);
+                }
+                if (nq > (uint32_t)WCNT_QBUF) {  // rare: queries that did not fit the staging, straight from the registers
+#pragma unroll
+                    for (int u = 0; u < NPT; ++u) {
+                        const uint32_t li = threadIdx.x + u * WCNT_NT;
+                        if (li >= n_local) continue;
+                        uint32_t rank = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
+                            if (v >= 0x8000u && v < 0xFFFEu) {
+                                const uint64_t qi = (uint64_t)(v & 0x7FFFu) + WCNT_QBUF;
+                                const uint64_t node = gbase + li;
+                                const K128 sk = k128_append(K128{out.keys_hi[node], out.keys[node]}, (uint32_t)b, k);
+                                out.q_lo[qbase + qi] = sk.lo;
+                                out.q_hi[qbase + qi] = sk.hi;
+                                out.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
+                            }
+                            if (v != 0xFFFFu) ++rank;
+                        }
+                    }
+                }
+            }
+            clean = true;
+        }
+        if (failed || s.fail) return;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// successors that live in another bucket, through the directory (k_succ_resolve with two-word keys)
+// ------------------------------------------------------------------------------------------------
+__device__ inline uint32_t wdir_find(const SkDirEnt *__restrict__ dirs, uint64_t ri, const uint64_t *__restrict__ keys,
+                                     const uint64_t *__restrict__ keys_hi, uint64_t n_nodes, K128 key, bool *whole = nullptr) {
+    constexpr int NBLK = WCAP / 64;
+    uint32_t slot = wslot_of(key);
+    for (int blocks = 0; blocks <= NBLK; ++blocks) {
+        const SkDirEnt de = dirs[ri * NBLK + (slot >> 6)];
+        if (whole && blocks == 0 && de.pad != 1u) { *whole = false; return NO_NODE; }
+        const int bit = (int)(slot & 63);
+        const unsigned long long run_bits = de.mask >> bit;
+        if (!(run_bits & 1ull)) return NO_NODE;
+        const int avail = 64 - bit;
+        const int run = (~run_bits) ? min(avail, __ffsll((unsigned long long)~run_bits) - 1) : avail;
+        const uint64_t idx = (uint64_t)de.base + (uint64_t)__popcll(de.mask & ((1ull << bit) - 1ull));
+        if (idx + run > n_nodes) return NO_NODE;
+        for (int t = 0; t < run; ++t)
+            if (keys[idx + t] == key.lo && keys_hi[idx + t] == key.hi) return (uint32_t)(idx + t);
+        if (run < avail) return NO_NODE;
+        slot = (slot + (uint32_t)run) & (WCAP - 1);
+    }
+    return NO_NODE;
+}
+
+__global__ __launch_bounds__(256) void k_wsucc_resolve(const uint64_t *__restrict__ q_lo, const uint64_t *__restrict__ q_hi,
+                                                       const uint32_t *__restrict__ q_col, uint64_t n, SkGeom g,
+                                                       const SkRange *__restrict__ ranges, uint64_t n_buckets, uint64_t n_ranges,
+                                                       const SkDirEnt *__restrict__ dirs, const uint64_t *__restrict__ keys,
+                                                       const uint64_t *__restrict__ keys_hi, uint64_t n_nodes, uint32_t *out,
+                                                       unsigned long long *scalars) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const K128 key{q_hi[i], q_lo[i]};
+    const uint64_t bucket = sk_bucket_of(wkmer_bucket22(key, g.k, g.m), g);
+    uint32_t id = NO_NODE;
+    if (bucket >= g.own_lo && bucket < g.own_lo + g.own_cnt) {
+        bool whole = true;
+        id = wdir_find(dirs, bucket - g.own_lo, keys, keys_hi, n_nodes, key, &whole);
+        if (!whole) {
+            const uint32_t sh = wsub_hash(key);
+            uint32_t r = ranges[bucket].next;
+            uint64_t ri = 0;
+            bool have = false;
+            for (int guard = 0; r && r < n_ranges && !have && guard < (1 << 20); ++guard) {
+                const SkRange rg = ranges[r];
+                if (rg.node_cnt && (sh & rg.mask) == rg.val) { ri = r; have = true; }
+                r = rg.next;
+            }
+            if (have) id = wdir_find(dirs, g.own_cnt + (ri - n_buckets), keys, keys_hi, n_nodes, key);
+        }
+    }
+    if (id == NO_NODE) { atomicOr(&scalars[0], 128ull); return; }
+    out[q_col ? q_col[i] : i] = id;
+}
+
+}  // namespace dbgk
