@@ -1726,7 +1726,7 @@ extern "C" int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets) {
 
 // ------------------------------------------------------------------------------------------
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint);
-static int build_wsk(dbg *h, int k);
+static int build_wsk(dbg *h, int k, bool *fallback);
 // CSR over distinct edges + start count; shared by both engines
 static int finish_graph(dbg *h) {
     if (!h->csr_built) {
@@ -2142,7 +2142,14 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     }
     if (k > 31) {  // two-word k-mers: the super-k-mer / LDS engine (dbg_wsk.h), or the global reference-keyed table (dbg_wide.h)
         Timer t_total(h->stream);
-        int rc = (h->wide_engine == 1 && h->engine == 0) ? build_wsk(h, k) : build_wide(h, k, table_capacity_hint);
+        int rc;
+        bool fallback = true;
+        if (h->wide_engine == 1 && h->engine == 0) rc = build_wsk(h, k, &fallback);
+        if (fallback) {
+            free_build(h);
+            h->k = k;
+            rc = build_wide(h, k, table_capacity_hint);
+        }
         if (rc == DBG_OK) rc = finish_graph(h);
         if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
         h->stats.ms_build_total = t_total.stop();
@@ -3489,7 +3496,7 @@ static int build_wsk_t(dbg *h, int k) {
         hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, pk_words, pk);
     // ---- extraction into one private segment per persistent workgroup
     const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
-    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 2048);
+    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 1024);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
     uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg, *seg_ne = seg_nk + n_wg;
     std::vector<uint64_t> hseg((size_t)n_wg * 4);
@@ -3515,9 +3522,12 @@ static int build_wsk_t(dbg *h, int k) {
             HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
             HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
             HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
-            if (tiles)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wsk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+            if (tiles) {
+                auto ekern = k_wsk_extract<ST>;
+                HIPCHK(h, hipFuncSetAttribute((const void *)ekern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WSkLds)));
+                hipLaunchKernelGGL(ekern, dim3(n_wg), dim3(WSK_NT), sizeof(WSkLds), h->stream, h->d_bases, h->n_bytes,
                                    h->d_startbits, k, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
+            }
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
@@ -3546,7 +3556,9 @@ static int build_wsk_t(dbg *h, int k) {
         const double want = (double)n_inst * 0.4 / TARGET_DISTINCT;
         while (T < 20 && (double)(1ull << T) < want) ++T;
     }
-    int l1 = T < 9 ? T : (T >= 20 ? 10 : 9), l2 = std::min(10, T - l1);
+    // 10 bits at level 1 from 2^18 buckets on: 2048-slot tables need twice the buckets of the one-word engine, and a third
+    // level over half a million tiny segments costs more than it splits
+    int l1 = T < 9 ? T : (T >= 18 ? 10 : 9), l2 = std::min(10, T - l1);
     int nb2 = 0, nb3 = (T - l1 - l2) > 0 ? 1 << (T - l1 - l2) : 1;
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
@@ -3618,7 +3630,7 @@ static int build_wsk_t(dbg *h, int k) {
         node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2 * h->est_scale_pct / 100.0) +
                                                         (h->est_scale_pct == 100 ? (1u << 20) : 1024u));
     uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
-    uint64_t q_cap = n_rec + 1024;
+    uint64_t q_cap = 2 * n_rec + 1024;  // one per record, more where a bucket is counted in hash sub-ranges
     const uint64_t range_cap = n_buckets + 4096 + n_inst / (WCAP / 4);
     CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
     SkRange *ranges = (SkRange *)h->ar_misc[6].p;
@@ -3670,12 +3682,13 @@ static int build_wsk_t(dbg *h, int k) {
         h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_count = t.stop();
-        if (sc[0] & (8 | 32)) break;
+        if (sc[0] & (8 | 32 | 512)) break;
         bool again = false;
         if ((sc[0] & 16) && (node_cap < node_cap_max || edge_cap < edge_cap_max)) { node_cap = node_cap_max; edge_cap = edge_cap_max; again = true; }
         if ((sc[0] & 64) && q_cap < n_edge_inst + 1024) { q_cap = n_edge_inst + 1024; again = true; }
         if (!again || attempt == 2) break;
     }
+    if (sc[0] & 512) { h->err = "16-bit successor counter overflow"; return DBG_E_CAPACITY; }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
@@ -3706,8 +3719,14 @@ static int build_wsk_t(dbg *h, int k) {
     return DBG_OK;
 }
 
-static int build_wsk(dbg *h, int k) {
-    return h->n_bytes < (1ull << 31) ? build_wsk_t<uint32_t>(h, k) : build_wsk_t<uint64_t>(h, k);
+// 32-bit stamps only (reads below 2 GiB: with 64-bit stamps the 4096-slot table does not fit the LDS); larger inputs and
+// graphs with an edge seen more than 65 535 times (16-bit LDS counters) take the global-table engine
+static int build_wsk(dbg *h, int k, bool *fallback) {
+    *fallback = false;
+    if (h->n_bytes >= (1ull << 31)) { *fallback = true; return DBG_E_CAPACITY; }
+    int rc = build_wsk_t<uint32_t>(h, k);
+    if (rc == DBG_E_CAPACITY && h->err == "16-bit successor counter overflow") *fallback = true;
+    return rc;
 }
 
 template <class ST, int CAP>

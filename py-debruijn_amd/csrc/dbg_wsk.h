@@ -11,7 +11,11 @@
 //     not written yet"), the winner stores the low word and then the high word without the pending bit; a probe
 //     that meets a pending slot looks again.  After the insert phase nothing is pending and every later phase reads
 //     plain keys.
-//   * 2048 slots per bucket (16-byte keys), ~740 nodes per bucket.
+//   * 16-byte keys: to keep 4096 slots per bucket in the 160 KB of LDS the four successor counters of a slot are
+//     16-bit fields (two per dword); an edge seen more than 65 535 times raises a flag and the build falls back to the
+//     global-table engine of dbg_wide.h (as that engine's own packed counters do).  4096 slots matter more here than for
+//     one-word k-mers: one minimizer occurrence of the genome brings ~320 nodes at k = 63 (26 k-mers per record x 30x
+//     coverage + the error k-mers), so a bucket holds only a handful of them and its size varies like a Poisson count.
 // Everything else -- dedupe of identical records, quads of 4 k-mers on 4 lanes, dense node list + CSR edge offsets
 // from ballots, in-bucket successor lookup, one packed global reservation per bucket, directory for the resolver,
 // hash sub-ranges for oversized buckets -- is the design of k_sk_count; see there for the reasons.
@@ -54,17 +58,19 @@ __device__ inline uint32_t wkmer_bucket22(K128 kmer, int k, int m) {
     return bucket_hash22(best_mm);
 }
 
-constexpr int WCAP = 2048;                                              // LDS table slots per bucket
-__device__ inline uint32_t wslot_of(K128 key) { return (uint32_t)(k128_hash(key) >> 53); }           // 11 bits
+constexpr int WCAP = 4096;                                              // LDS table slots per bucket
+__device__ inline uint32_t wslot_of(K128 key) { return (uint32_t)(k128_hash(key) >> 52); }           // 12 bits
 __device__ inline uint32_t wsub_hash(K128 key) { return fmix32((uint32_t)(k128_hash(key) >> 11) ^ 0x27D4EB2Fu); }
 
 // ------------------------------------------------------------------------------------------------
 // extraction: the generic kernel of dbg_sk.h (window minimum by a loop over the w m-mer hashes of the tile) with
 // 64-bit read-start windows and positions instead of bases in the records
 // ------------------------------------------------------------------------------------------------
+constexpr int WSK_NT = 1024;                        // threads of the extraction workgroup (its LDS allows one per CU)
+constexpr int WSK_NH = TILE + WSK_HALO - 32;        // m-mer positions of a tile whose 32-base window is in the tile's LDS image
 struct WSkLds {
     TileLdsW t;
-    uint16_t hm[TILE + WSK_HALO];   // 16-bit m-mer hash per position
+    uint32_t ma[WSK_NH], mb[WSK_NH];  // sliding-window minimum: (16-bit m-mer hash << 16 | tile position), doubled spans
     uint8_t minp[TILE];             // minimizer offset (0..w-1) from the k-mer position, 0xFF = no k-mer
     unsigned long long sbits[TILE / 64 + 1];
     unsigned long long vbits[TILE / 64 + 1];
@@ -73,14 +79,20 @@ struct WSkLds {
     uint32_t nrec;
 };
 
+// Window minimum over w = k - 12 (20..51) m-mer hashes per k-mer position: a doubling table in LDS -- M1 = the hashes,
+// M2[j] = min(M1[j], M1[j + 1]), M4[j] = min(M2[j], M2[j + 2]), ... up to the largest power of two p <= w, then
+// min over [j, j + w) = min(Mp[j], Mp[j + w - p]).  Four or five passes of two LDS reads instead of w reads per position
+// (the plain loop took 37 ms of the first version's 117 at k = 63).  Ties go to the leftmost position: the position
+// is the low half of the packed value.
 template <class ST>
-__global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ bases, uint64_t n_bytes,
-                                                     const uint32_t *__restrict__ startbits, int k, uint64_t n_tiles,
-                                                     uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
-                                                     uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
-                                                     unsigned long long *scalars /* [0] err */) {
-    __shared__ WSkLds s;
-    __shared__ uint64_t red[8];
+__global__ __launch_bounds__(WSK_NT) void k_wsk_extract(const char *__restrict__ bases, uint64_t n_bytes,
+                                                        const uint32_t *__restrict__ startbits, int k, uint64_t n_tiles,
+                                                        uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
+                                                        uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
+                                                        unsigned long long *scalars /* [0] err */) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsk_raw[];
+    WSkLds &s = *reinterpret_cast<WSkLds *>(wsk_raw);
+    __shared__ uint64_t red[2 * (WSK_NT / 64)];
     constexpr int m = SK_MAX_M;
     const int w = k - m + 1;
     const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
@@ -95,10 +107,18 @@ __global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ ba
         const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
         if (bad) atomicOr(&scalars[0], 1ull);
         __syncthreads();
-        for (int j = threadIdx.x; j < TILE + WSK_HALO - 32; j += 256)
-            s.hm[j] = (uint16_t)mmer_hash16((uint32_t)(window32(s.t, j) >> (64 - 2 * m)));
+        for (int j = threadIdx.x; j < WSK_NH; j += WSK_NT)
+            s.ma[j] = (mmer_hash16((uint32_t)(window32(s.t, j) >> (64 - 2 * m))) << 16) | (uint32_t)j;
         __syncthreads();
-        for (int j0 = 0; j0 < TILE; j0 += 256) {
+        uint32_t *A = s.ma, *B = s.mb;
+        int span = 1;
+        while (span * 2 <= w) {  // uniform
+            for (int j = threadIdx.x; j < WSK_NH; j += WSK_NT) B[j] = (j + span < WSK_NH) ? min(A[j], A[j + span]) : A[j];
+            __syncthreads();
+            uint32_t *tmp = A; A = B; B = tmp;
+            span *= 2;
+        }
+        for (int j0 = 0; j0 < TILE; j0 += WSK_NT) {
             const int j = j0 + threadIdx.x;
             const uint64_t p = tile0 + j;
             bool v = false;
@@ -110,12 +130,7 @@ __global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ ba
                 if (v) {
                     n_k += 1;
                     n_e += sk ^ 1u;
-                    uint32_t best = s.hm[j];
-                    mp = 0;
-                    for (int i = 1; i < w; ++i) {
-                        const uint32_t hv = s.hm[j + i];
-                        if (hv < best) { best = hv; mp = i; }
-                    }
+                    mp = (min(A[j], A[j + w - span]) & 0xFFFFu) - (uint32_t)j;
                 }
             }
             s.minp[j] = (uint8_t)mp;
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ ba
             if ((threadIdx.x & 63) == 0) s.vbits[j >> 6] = vb;
         }
         __syncthreads();
-        for (int j0 = 0; j0 < TILE; j0 += 256) {
+        for (int j0 = 0; j0 < TILE; j0 += WSK_NT) {
             const int j = j0 + threadIdx.x;
             const uint32_t mp = s.minp[j];
             const bool st = (mp != 0xFFu) && (j == 0 || (uint32_t)s.minp[j - 1] != mp + 1);
@@ -149,13 +164,13 @@ __global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ ba
         if (cursor + nrec > seg_cap) { overflow = true; break; }
         const uint64_t gbase = seg0 + cursor;
         cursor += nrec;
-        for (int j0 = 0; j0 < TILE; j0 += 256) {
+        for (int j0 = 0; j0 < TILE; j0 += WSK_NT) {
             const int j = j0 + threadIdx.x;
             const unsigned long long sb = s.sbits[j >> 6];
             if ((sb >> (j & 63)) & 1ull) s.list[s.wpre[j >> 6] + __popcll(sb & ((1ull << (j & 63)) - 1))] = (uint16_t)j;
         }
         __syncthreads();
-        for (uint32_t r = threadIdx.x; r < nrec; r += 256) {
+        for (uint32_t r = threadIdx.x; r < nrec; r += WSK_NT) {
             const int j = s.list[r];
             const int wd = j >> 6, bt = j & 63;
             const unsigned long long sb = s.sbits[wd];
@@ -187,12 +202,14 @@ __global__ __launch_bounds__(256) void k_wsk_extract(const char *__restrict__ ba
     n_k = wave_sum_u64(n_k);
     n_e = wave_sum_u64(n_e);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = n_k; red[4 + (threadIdx.x >> 6)] = n_e; }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = n_k; red[WSK_NT / 64 + (threadIdx.x >> 6)] = n_e; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        uint64_t tk = 0, te = 0;
+        for (int i = 0; i < WSK_NT / 64; ++i) { tk += red[i]; te += red[WSK_NT / 64 + i]; }
         seg_cnt[blockIdx.x] = cursor;
-        seg_nk[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
-        seg_ne[blockIdx.x] = red[4] + red[5] + red[6] + red[7];
+        seg_nk[blockIdx.x] = tk;
+        seg_ne[blockIdx.x] = te;
     }
 }
 
@@ -245,7 +262,7 @@ template <class ST>
 struct WCntLds {
     unsigned long long khi[WCAP];   // EMPTY_KEY / hi | W_PEND / hi   (hi < 2^62)
     unsigned long long klo[WCAP];
-    uint32_t cnt[WCAP * 4];
+    uint32_t cnt2[WCAP * 2];        // four 16-bit successor counters per slot: codes 0, 1 in dword 0; 2, 3 in dword 1
     ST stamp[WCAP];
     uint16_t list[WCAP];            // local node index -> slot
     uint16_t eoff[WCAP];            // local node index -> first CSR edge of the node, relative to the bucket
@@ -281,6 +298,11 @@ struct WSkCountOut {
     unsigned long long *scalars;  // [0] err [4] nodes | edges << 32 [5] queries [6] extra ranges
 };
 
+__device__ inline void wcnt_load(const uint32_t *cnt2, uint32_t slot, uint32_t c[4]) {
+    const uint2 v = reinterpret_cast<const uint2 *>(cnt2)[slot];
+    c[0] = v.x & 0xFFFFu; c[1] = v.x >> 16; c[2] = v.y & 0xFFFFu; c[3] = v.y >> 16;
+}
+
 __device__ inline int wlds_find(const unsigned long long *khi, const unsigned long long *klo, K128 key) {
     uint32_t slot = wslot_of(key);
     for (int probe = 0; probe < WCAP; ++probe) {
@@ -301,11 +323,43 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
     WCntLds<ST> &s = *reinterpret_cast<WCntLds<ST> *>(wcnt_raw);
     constexpr int NPT = WCAP / WCNT_NT;
     static_assert(WCNT_DD >= 2 * WCNT_STAGE && WCNT_STAGE <= WCNT_NT, "staging");
+    static_assert(sizeof(WCntLds<ST>) <= 160 * 1024, "LDS");
     bool clean = false;
     if (threadIdx.x == 0) s.fail = 0;
+    // The next bucket's records (and then their bases from the packed reads: a dependent load) are fetched into
+    // registers while this bucket is in its later phases, its record range one bucket earlier still: a bucket is ~15 us
+    // of work, two exposed global round trips at its start were a fifth of that.
+    uint64_t pf_p = 0, pf_w1 = 0, pf_W[5] = {0, 0, 0, 0, 0};
+    ST pf_st = 0;
+    uint64_t nx_beg = 0, nx_n = 0, r2_beg = 0, r2_n = 0;
+    auto load_range = [&](uint64_t b, uint64_t &beg, uint64_t &n) {
+        n = 0;
+        if (b < n_buckets) { beg = b_start[b]; n = b_cnt[b]; }
+    };
+    auto prefetch_recs = [&](uint64_t b) {  // records of bucket b (its range is in r2_*), then the range after it
+        nx_beg = r2_beg;
+        nx_n = r2_n;
+        if (threadIdx.x < min(nx_n, (uint64_t)WCNT_STAGE)) {
+            pf_p = rec_w0[nx_beg + threadIdx.x];
+            pf_w1 = rec_w1[nx_beg + threadIdx.x];
+            pf_st = rec_st[nx_beg + threadIdx.x];
+        }
+        load_range(b + gridDim.x, r2_beg, r2_n);
+    };
+    auto prefetch_words = [&]() {
+        if (threadIdx.x < min(nx_n, (uint64_t)WCNT_STAGE)) {
+            const uint64_t wi = pf_p >> 5;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) pf_W[j] = pk[wi + j];
+        }
+    };
+    load_range(blockIdx.x, r2_beg, r2_n);
+    prefetch_recs(blockIdx.x);
+    prefetch_words();
     for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
-        const uint64_t r_beg = b_start[bucket], r_n = b_cnt[bucket];
-        if (r_n == 0) continue;
+        const uint64_t r_beg = nx_beg, r_n = nx_n;
+        if (r_n == 0) { prefetch_recs(bucket + gridDim.x); prefetch_words(); continue; }
+        bool have_pf = true, words_due = false;
         uint32_t stk_n = 1;
         bool root = true, failed = false;
         if (split_recs && r_n > split_recs) {
@@ -327,7 +381,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 for (int i = threadIdx.x; i < WCAP; i += WCNT_NT) {
                     s.khi[i] = EMPTY_KEY;
                     s.stamp[i] = (ST)~(ST)0;
-                    reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+                    reinterpret_cast<uint2 *>(s.cnt2)[i] = make_uint2(0, 0);
                 }
             }
             clean = false;
@@ -338,13 +392,15 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 if (c0) __syncthreads();
                 if (threadIdx.x == 0) s.n_flat = 0;
                 if (threadIdx.x < n_st) {  // one record per thread: its bases from the packed reads, aligned
-                    const uint64_t p = rec_w0[r_beg + c0 + threadIdx.x], w1 = rec_w1[r_beg + c0 + threadIdx.x];
+                    const bool pf = have_pf && c0 == 0;
+                    const uint64_t p = pf ? pf_p : rec_w0[r_beg + c0 + threadIdx.x];
+                    const uint64_t w1 = pf ? pf_w1 : rec_w1[r_beg + c0 + threadIdx.x];
                     const int nb = k + wrec_len(w1) - 1 + (int)wrec_has_succ(w1);  // bases the record covers (<= 115)
                     const uint64_t wi = p >> 5;
                     const int sh = (int)(p & 31) * 2;
                     uint64_t W[5];
 #pragma unroll
-                    for (int j = 0; j < 5; ++j) W[j] = pk[wi + j];  // (the packed array is padded)
+                    for (int j = 0; j < 5; ++j) W[j] = pf ? pf_W[j] : pk[wi + j];  // (the packed array is padded)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         uint64_t v = sh ? (W[j] << sh) | (W[j + 1] >> (64 - sh)) : W[j];
@@ -354,7 +410,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                         s.rb[threadIdx.x][j] = v;
                     }
                     s.rmeta[threadIdx.x] = w1;
-                    s.rst[threadIdx.x] = rec_st[r_beg + c0 + threadIdx.x];
+                    s.rst[threadIdx.x] = pf ? pf_st : rec_st[r_beg + c0 + threadIdx.x];
                     s.dd_mult[threadIdx.x] = 0;
                 }
                 for (uint32_t i = threadIdx.x; i < WCNT_DD; i += WCNT_NT) s.dd_tab[i] = 0xFFFFFFFFu;
@@ -429,11 +485,20 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                         ++probe;
                     }
                     if (!ok) { s.overflow = 1; continue; }
-                    if (has_succ) atomicAdd(&s.cnt[slot * 4 + b], mult);
+                    if (has_succ) {
+                        const int shf = 16 * (int)(b & 1);
+                        const uint32_t old = atomicAdd(&s.cnt2[slot * 2 + (b >> 1)], mult << shf);
+                        if (((old >> shf) & 0xFFFFu) + mult > 0xFFFFu) atomicOr(&out.scalars[0], 512ull);  // 16-bit counter overflow
+                    }
                     atomicMin(&s.stamp[slot], stamp);
                 }
             }
             __syncthreads();
+            if (have_pf) {  // the registers are free: the next bucket's records, under the rest of this one
+                have_pf = false;
+                prefetch_recs(bucket + gridDim.x);
+                words_due = true;
+            }
             if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
                 const uint32_t bit = cur_mask + 1;
                 if (stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
@@ -454,8 +519,9 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 const bool occ = s.khi[i] != EMPTY_KEY;
                 uint32_t deg = 0;
                 if (occ) {
-                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
-                    deg = (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
+                    uint32_t c[4];
+                    wcnt_load(s.cnt2, (uint32_t)i, c);
+                    deg = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
                 }
                 const unsigned long long mask = __ballot(occ);
                 if ((threadIdx.x & 63) == 0) s.dir_mask[i >> 6] = mask;
@@ -496,8 +562,9 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     const uint32_t sl = s.list[li];
                     key.hi = s.khi[sl];
                     key.lo = s.klo[sl];
-                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[sl];
-                    nz = (c4.x != 0) | ((c4.y != 0) << 1) | ((c4.z != 0) << 2) | ((c4.w != 0) << 3);
+                    uint32_t c[4];
+                    wcnt_load(s.cnt2, sl, c);
+                    nz = (c[0] != 0) | ((c[1] != 0) << 1) | ((c[2] != 0) << 2) | ((c[3] != 0) << 3);
                 }
                 const uint32_t nz_all = nz;
                 uint32_t missmask = 0;
@@ -555,6 +622,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 }
             }
             __syncthreads();
+            if (words_due) { words_due = false; prefetch_words(); }  // the positions have arrived: now the bases they point at
             const uint32_t nq = s.n_q;
             unsigned long long qgot = 0;
             if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);
@@ -577,12 +645,12 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 const uint32_t i = s.list[li];
                 const unsigned long long khi = s.khi[i], klo = s.klo[i];
                 const uint64_t node = gbase + li;
-                const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
-                const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+                uint32_t c[4];
+                wcnt_load(s.cnt2, i, c);
                 const ST stamp = s.stamp[i];
                 s.khi[i] = EMPTY_KEY;
                 s.stamp[i] = (ST)~(ST)0;
-                reinterpret_cast<uint4 *>(s.cnt)[i] = make_uint4(0, 0, 0, 0);
+                reinterpret_cast<uint2 *>(s.cnt2)[i] = make_uint2(0, 0);
                 out.keys[node] = klo;
                 out.keys_hi[node] = khi;
                 reinterpret_cast<ST *>(out.stamps)[node] = stamp;
@@ -638,6 +706,8 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             clean = true;
         }
         if (failed || s.fail) return;
+        if (words_due) prefetch_words();
+        if (have_pf) { prefetch_recs(bucket + gridDim.x); prefetch_words(); }
     }
 }
 
