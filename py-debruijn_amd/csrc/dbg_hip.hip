@@ -3638,6 +3638,16 @@ static int build_wsk_t(dbg *h, int k) {
     SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
     uint64_t *q_lo = nullptr, *q_hi = nullptr;
     uint32_t *q_col = nullptr;
+    // the records' bases, aligned, in bucket order (k_wsk_gather)
+    CHK(buf_ensure(h, h->ar_wide[2], (n_rec + 1) * 32));
+    uint4 *rec_b = (uint4 *)h->ar_wide[2].p;
+    {
+        Timer t(h->stream);
+        if (n_rec)
+            hipLaunchKernelGGL(k_wsk_gather, dim3(grid_for(n_rec, 256)), dim3(256), 0, h->stream, w0[where], w1[where], n_rec, pk, k, rec_b);
+        HIPCHK(h, hipGetLastError());
+        h->stats.ms_compact = t.stop();  // reported in the "compact" slot of dbg_stats_t: this engine has no compaction pass
+    }
     for (int attempt = 0; attempt < 3; ++attempt) {
         CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
         CHK(buf_ensure(h, h->ar_wide[5], node_cap * 8));
@@ -3675,8 +3685,8 @@ static int build_wsk_t(dbg *h, int k) {
             const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);
             uint32_t split_recs = 0;
             if (est_distinct > 0.0) split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(16.0, (WCAP * 0.80) / (est_distinct / (double)n_rec)));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(WCNT_NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where], st[where], pk, k,
-                               n_buckets, out, split_recs);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(WCNT_NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where], st[where],
+                               (const uint4 *)rec_b, k, n_buckets, out, split_recs);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;

@@ -671,7 +671,11 @@ __device__ inline uint32_t slot_of(uint64_t kmer) {
 // With 64-bit stamps (sharded builds) the 4096-slot table leaves room for 640.
 template <class ST, int CAP>
 struct CntCfg {
+    #ifdef DBG_CNT_PROF
+    static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 624 : 768) : 400;  // room for the clocks of the experiment build
+#else
     static constexpr int QBUF = CAP == 4096 ? (sizeof(ST) == 8 ? 640 : 768) : 400;
+#endif
     // 4096 slots fill the LDS: one 1024-thread workgroup per CU.  2048 slots: two 512-thread workgroups per CU
     // that run out of step, so one's barriers and LDS stalls overlap the other's work.
     static constexpr int NT = CAP == 4096 ? 1024 : 512;

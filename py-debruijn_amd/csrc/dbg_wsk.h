@@ -59,8 +59,17 @@ __device__ inline uint32_t wkmer_bucket22(K128 kmer, int k, int m) {
 }
 
 constexpr int WCAP = 4096;                                              // LDS table slots per bucket
-__device__ inline uint32_t wslot_of(K128 key) { return (uint32_t)(k128_hash(key) >> 52); }           // 12 bits
-__device__ inline uint32_t wsub_hash(K128 key) { return fmix32((uint32_t)(k128_hash(key) >> 11) ^ 0x27D4EB2Fu); }
+// table slot and hash sub-range of a two-word k-mer: a multiplicative fold of the four 32-bit halves (k128_hash, two
+// 64-bit mixes, cost ~40 instructions per insert and per successor lookup)
+__device__ inline uint32_t wfold32(K128 a) {
+    return (uint32_t)a.lo * 0x9E3779B1u ^ (uint32_t)(a.lo >> 32) * 0x85EBCA77u ^ (uint32_t)a.hi * 0xC2B2AE3Du ^
+           (uint32_t)(a.hi >> 32) * 0x27D4EB2Fu;
+}
+__device__ inline uint32_t wslot_of(K128 key) {
+    const uint32_t x = wfold32(key);
+    return ((x ^ (x >> 15)) * 0x2C1B3C6Du) >> 20;  // 12 bits
+}
+__device__ inline uint32_t wsub_hash(K128 key) { return fmix32(wfold32(key) ^ 0x165667B1u); }
 
 // ------------------------------------------------------------------------------------------------
 // extraction: the generic kernel of dbg_sk.h (window minimum by a loop over the w m-mer hashes of the tile) with
@@ -248,14 +257,45 @@ __global__ __launch_bounds__(256) void k_wsk_estimate(const uint64_t *__restrict
     }
 }
 
+// The bases of every record, aligned (first base in bits 63:62 of word 0) and zero beyond the record, in record
+// (= bucket) order: one pass of independent 40-byte reads of the packed reads at full occupancy.  Read inside the count
+// kernel, where a bucket's ~140 records are all a workgroup has in flight, the same reads were a dependent round trip
+// through HBM at the start of every bucket: 8 ms of 40 at k = 63.
+__global__ __launch_bounds__(256) void k_wsk_gather(const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
+                                                    uint64_t n_rec, const uint64_t *__restrict__ pk, int k, uint4 *out /* [n_rec][2] */) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    const uint64_t p = rec_w0[r], w1 = rec_w1[r];
+    const int nb = k + wrec_len(w1) - 1 + (int)wrec_has_succ(w1);  // bases the record covers (<= 115)
+    const uint64_t wi = p >> 5;
+    const int sh = (int)(p & 31) * 2;
+    uint64_t W[5], v[4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) W[j] = pk[wi + j];  // (the packed array is padded)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = sh ? (W[j] << sh) | (W[j + 1] >> (64 - sh)) : W[j];
+        const int have = nb - 32 * j;  // bases of this word that belong to the record
+        if (have <= 0) v[j] = 0;
+        else if (have < 32) v[j] &= ~0ull << (64 - 2 * have);
+    }
+    out[2 * r] = make_uint4((uint32_t)v[0], (uint32_t)(v[0] >> 32), (uint32_t)v[1], (uint32_t)(v[1] >> 32));
+    out[2 * r + 1] = make_uint4((uint32_t)v[2], (uint32_t)(v[2] >> 32), (uint32_t)v[3], (uint32_t)(v[3] >> 32));
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-bucket counting in LDS
 // ------------------------------------------------------------------------------------------------
 constexpr int WCNT_NT = 1024;
-constexpr int WCNT_STAGE = 192;      // records staged per round (a bucket holds ~55 at the default geometry)
+constexpr int WCNT_STAGE = 288;      // records staged per round (a bucket holds 140 +- 64 at the default geometry: a second round
+                                     // pays the dedupe / quad list / insert barriers again and loads its records unprefetched)
 constexpr int WCNT_QMAX = 13;        // quads of 4 k-mers per record: ceil(51 / 4)
+#ifdef DBG_CNT_PROF
+constexpr int WCNT_QBUF = 256;       // (room for the clocks of the experiment build)
+#else
 constexpr int WCNT_QBUF = 320;       // cross-bucket successor queries staged per bucket
-constexpr int WCNT_DD = 512;         // dedupe set slots (>= 2 * WCNT_STAGE)
+#endif
+constexpr int WCNT_DD = 1024;        // dedupe set slots (>= 2 * WCNT_STAGE)
 constexpr unsigned long long W_PEND = 1ull << 63;
 
 template <class ST>
@@ -266,7 +306,8 @@ struct WCntLds {
     ST stamp[WCAP];
     uint16_t list[WCAP];            // local node index -> slot
     uint16_t eoff[WCAP];            // local node index -> first CSR edge of the node, relative to the bucket
-    unsigned long long rb[WCNT_STAGE][4];  // staged records: bases, aligned (first base in bits 63:62 of word 0), zero beyond
+    // staged records (bases aligned: first base in bits 63:62 of word 0, zero beyond the record)
+    unsigned long long rb[WCNT_STAGE][4];
     unsigned long long rmeta[WCNT_STAGE];
     ST rst[WCNT_STAGE];
     uint32_t dd_tab[WCNT_DD];
@@ -279,6 +320,9 @@ struct WCntLds {
     unsigned long long gbase, qbase, ebase, ri;
     unsigned long long dir_mask[WCAP / 64];
     uint16_t dir_base[WCAP / 64];
+#ifdef DBG_CNT_PROF
+    unsigned long long prof[32];
+#endif
 };
 
 struct WSkCountOut {
@@ -317,8 +361,8 @@ __device__ inline int wlds_find(const unsigned long long *khi, const unsigned lo
 template <class ST>
 __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                       const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
-                                                      const ST *__restrict__ rec_st, const uint64_t *__restrict__ pk, int k,
-                                                      uint64_t n_buckets, WSkCountOut out, uint32_t split_recs) {
+                                                      const ST *__restrict__ rec_st, const uint4 *__restrict__ rec_b /* k_wsk_gather */,
+                                                      int k, uint64_t n_buckets, WSkCountOut out, uint32_t split_recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wcnt_raw[];
     WCntLds<ST> &s = *reinterpret_cast<WCntLds<ST> *>(wcnt_raw);
     constexpr int NPT = WCAP / WCNT_NT;
@@ -326,10 +370,15 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
     static_assert(sizeof(WCntLds<ST>) <= 160 * 1024, "LDS");
     bool clean = false;
     if (threadIdx.x == 0) s.fail = 0;
-    // The next bucket's records (and then their bases from the packed reads: a dependent load) are fetched into
-    // registers while this bucket is in its later phases, its record range one bucket earlier still: a bucket is ~15 us
-    // of work, two exposed global round trips at its start were a fifth of that.
-    uint64_t pf_p = 0, pf_w1 = 0, pf_W[5] = {0, 0, 0, 0, 0};
+#ifdef DBG_CNT_PROF
+    unsigned long long clast_ = clock64();
+    if (threadIdx.x < 32) s.prof[threadIdx.x] = 0;
+    __syncthreads();
+#endif
+    // The next bucket's records are fetched into registers while this bucket is in its later phases, its record range
+    // one bucket earlier still (as in k_sk_count).
+    uint64_t pf_w1 = 0;
+    uint4 pf_b0 = make_uint4(0, 0, 0, 0), pf_b1 = make_uint4(0, 0, 0, 0);
     ST pf_st = 0;
     uint64_t nx_beg = 0, nx_n = 0, r2_beg = 0, r2_n = 0;
     auto load_range = [&](uint64_t b, uint64_t &beg, uint64_t &n) {
@@ -340,26 +389,19 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
         nx_beg = r2_beg;
         nx_n = r2_n;
         if (threadIdx.x < min(nx_n, (uint64_t)WCNT_STAGE)) {
-            pf_p = rec_w0[nx_beg + threadIdx.x];
             pf_w1 = rec_w1[nx_beg + threadIdx.x];
             pf_st = rec_st[nx_beg + threadIdx.x];
+            pf_b0 = rec_b[2 * (nx_beg + threadIdx.x)];
+            pf_b1 = rec_b[2 * (nx_beg + threadIdx.x) + 1];
         }
         load_range(b + gridDim.x, r2_beg, r2_n);
     };
-    auto prefetch_words = [&]() {
-        if (threadIdx.x < min(nx_n, (uint64_t)WCNT_STAGE)) {
-            const uint64_t wi = pf_p >> 5;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) pf_W[j] = pk[wi + j];
-        }
-    };
     load_range(blockIdx.x, r2_beg, r2_n);
     prefetch_recs(blockIdx.x);
-    prefetch_words();
     for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
         const uint64_t r_beg = nx_beg, r_n = nx_n;
-        if (r_n == 0) { prefetch_recs(bucket + gridDim.x); prefetch_words(); continue; }
-        bool have_pf = true, words_due = false;
+        if (r_n == 0) { prefetch_recs(bucket + gridDim.x); continue; }
+        bool have_pf = true;
         uint32_t stk_n = 1;
         bool root = true, failed = false;
         if (split_recs && r_n > split_recs) {
@@ -370,6 +412,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             stk_n = parts;
             root = false;
             __syncthreads();
+            CNT_TICK(0);
         }
         while (stk_n) {
             uint32_t cur_mask = 0, cur_val = 0;
@@ -386,35 +429,29 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             }
             clean = false;
             if (threadIdx.x == 0) { s.overflow = 0; s.n_local = 0; s.n_q = 0; }
+            CNT_TICK(13);
             // ---- insert
             for (uint64_t c0 = 0; c0 < r_n; c0 += WCNT_STAGE) {
                 const uint32_t n_st = (uint32_t)min((uint64_t)WCNT_STAGE, r_n - c0);
                 if (c0) __syncthreads();
                 if (threadIdx.x == 0) s.n_flat = 0;
-                if (threadIdx.x < n_st) {  // one record per thread: its bases from the packed reads, aligned
+                if (threadIdx.x < n_st) {  // one record per thread (the first round of a bucket comes from the prefetch registers)
                     const bool pf = have_pf && c0 == 0;
-                    const uint64_t p = pf ? pf_p : rec_w0[r_beg + c0 + threadIdx.x];
-                    const uint64_t w1 = pf ? pf_w1 : rec_w1[r_beg + c0 + threadIdx.x];
-                    const int nb = k + wrec_len(w1) - 1 + (int)wrec_has_succ(w1);  // bases the record covers (<= 115)
-                    const uint64_t wi = p >> 5;
-                    const int sh = (int)(p & 31) * 2;
-                    uint64_t W[5];
-#pragma unroll
-                    for (int j = 0; j < 5; ++j) W[j] = pf ? pf_W[j] : pk[wi + j];  // (the packed array is padded)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        uint64_t v = sh ? (W[j] << sh) | (W[j + 1] >> (64 - sh)) : W[j];
-                        const int have = nb - 32 * j;  // bases of this word that belong to the record
-                        if (have <= 0) v = 0;
-                        else if (have < 32) v &= ~0ull << (64 - 2 * have);
-                        s.rb[threadIdx.x][j] = v;
-                    }
-                    s.rmeta[threadIdx.x] = w1;
-                    s.rst[threadIdx.x] = pf ? pf_st : rec_st[r_beg + c0 + threadIdx.x];
+                    const uint64_t ri = r_beg + c0 + threadIdx.x;
+                    const uint4 b0 = pf ? pf_b0 : rec_b[2 * ri], b1 = pf ? pf_b1 : rec_b[2 * ri + 1];
+                    s.rb[threadIdx.x][0] = ((unsigned long long)b0.y << 32) | b0.x;
+                    s.rb[threadIdx.x][1] = ((unsigned long long)b0.w << 32) | b0.z;
+                    s.rb[threadIdx.x][2] = ((unsigned long long)b1.y << 32) | b1.x;
+                    s.rb[threadIdx.x][3] = ((unsigned long long)b1.w << 32) | b1.z;
+                    s.rmeta[threadIdx.x] = pf ? pf_w1 : rec_w1[ri];
+                    s.rst[threadIdx.x] = pf ? pf_st : rec_st[ri];
                     s.dd_mult[threadIdx.x] = 0;
                 }
+                CNT_TICK(14);
                 for (uint32_t i = threadIdx.x; i < WCNT_DD; i += WCNT_NT) s.dd_tab[i] = 0xFFFFFFFFu;
+                CNT_TICK(15);
                 __syncthreads();
+            CNT_TICK(1);
                 if (s.overflow) break;
                 // ---- identical records collapse to one representative with a multiplicity and the smallest stamp
                 if (threadIdx.x < n_st) {
@@ -438,6 +475,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     if (rep != r) atomicMin(&s.rst[rep], s.rst[r]);
                 }
                 __syncthreads();
+            CNT_TICK(2);
                 {
                     const uint32_t r = threadIdx.x;
                     uint32_t nquad = 0;
@@ -446,6 +484,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     for (uint32_t q = 0; q < nquad; ++q) s.flat[base + q] = (uint16_t)((r << 4) | q);
                 }
                 __syncthreads();
+            CNT_TICK(3);
                 const uint32_t n_flat = s.n_flat;
                 for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += WCNT_NT / 4) {
                     const uint32_t e = s.flat[f];
@@ -493,11 +532,12 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     atomicMin(&s.stamp[slot], stamp);
                 }
             }
+            CNT_TICK(4);
             __syncthreads();
+            CNT_TICK(5);
             if (have_pf) {  // the registers are free: the next bucket's records, under the rest of this one
                 have_pf = false;
                 prefetch_recs(bucket + gridDim.x);
-                words_due = true;
             }
             if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
                 const uint32_t bit = cur_mask + 1;
@@ -544,7 +584,9 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     }
                 }
             }
+            CNT_TICK(6);
             __syncthreads();
+            CNT_TICK(7);
             const uint32_t n_local = s.n_local & 0xFFFFu, n_edges_local = s.n_local >> 16;
             unsigned long long got = 0;
             if (threadIdx.x == 0)
@@ -598,6 +640,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     ++qi;
                 }
             }
+            CNT_TICK(8);
             if (threadIdx.x == 0) {
                 const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
                 s.gbase = base;
@@ -621,8 +664,9 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     out.ranges[ri] = rg;
                 }
             }
+            CNT_TICK(9);
             __syncthreads();
-            if (words_due) { words_due = false; prefetch_words(); }  // the positions have arrived: now the bases they point at
+            CNT_TICK(10);
             const uint32_t nq = s.n_q;
             unsigned long long qgot = 0;
             if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);
@@ -668,11 +712,13 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     }
                 }
             }
+            CNT_TICK(11);
             if (threadIdx.x == 64 && nq) {
                 s.qbase = qgot;
                 if (qgot + nq > out.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
             }
             __syncthreads();
+            CNT_TICK(12);
             if (s.fail) break;
             if (nq) {
                 const uint64_t qbase = s.qbase;
@@ -706,9 +752,14 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             clean = true;
         }
         if (failed || s.fail) return;
-        if (words_due) prefetch_words();
-        if (have_pf) { prefetch_recs(bucket + gridDim.x); prefetch_words(); }
+        if (have_pf) prefetch_recs(bucket + gridDim.x);
     }
+#ifdef DBG_CNT_PROF
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 31; ++i) atomicAdd(&g_cnt_prof[i], s.prof[i]);
+        atomicAdd(&g_cnt_prof[31], 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

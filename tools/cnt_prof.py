@@ -8,14 +8,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "py-debruijn_amd"))
 import _dbg
 
+K = int(os.environ.get("SWEEP_K", "31"))
 reads = int(os.environ.get("SWEEP_READS", "10000000"))
 g = _dbg.Graph()
 g.synth_reads(1, reads * 5, reads, 150, 0.01)
 lib = _dbg.load_library()
 out = (C.c_ulonglong * 32)()
-g.build(31)
+g.build(K)
 lib.dbg_debug_cnt_prof(out, 1)
-g.build(31)
+g.build(K)
 lib.dbg_debug_cnt_prof(out, 1)
 names = {0: "queries out + top barrier", 1: "clear + stage + barrier", 2: "dedupe + barrier", 3: "quad list + barrier",
          4: "insert", 5: "barrier after insert", 6: "dense list", 7: "barrier after list", 8: "lookups: u0 loads",
@@ -27,6 +28,6 @@ st = g.stats()
 print(f"{out[31]} workgroups, {tot / out[31]:.0f} clocks each; count {st['ms_count']:.2f} ms, {st['n_buckets']} buckets")
 for i in main:
     print(f"  {names[i]:28s} {100.0 * out[i] / tot:5.1f} %  = {st['ms_count'] * out[i] / tot:6.2f} ms")
-sub = {20: "(since previous subtick)", 13: "u0 find loop", 14: "u0 wave_alloc_n<4>", 15: "u0 miss staging"}
+sub = {20: "(since previous subtick)", 13: "u0 find loop / wide: clear", 14: "u0 wave_alloc_n<4> / wide: stage stores", 15: "u0 miss staging / wide: dd clear"}
 for i, n in sub.items():
     print(f"    sub {n:28s} {100.0 * out[i] / tot:5.1f} %  = {st['ms_count'] * out[i] / tot:6.2f} ms")
