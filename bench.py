@@ -302,7 +302,7 @@ def main():
     achieved_step = n_k_rank * b_alg(L, k) / (dt / args.steps) / 1e9
 
     if rank == 0:
-        kernel = "k_sk_count" if k <= 31 else "k_wcount"
+        kernel = "k_sk_count" if k <= 31 else "k_wsk_count"
         phases = {key: round(sum(p[key] for p in ms_phases) / len(ms_phases), 3)
                   for key in ("ms_extract", "ms_partition", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total")}
         traffic, traffic_src = (pmc_traffic(kernel) if (not sharded and reads_per_rank == 10_000_000 and args.err == 0.01 and
