@@ -46,10 +46,11 @@ def exchange_counts(dist, counts, device):
 # rank sends to ITSELF arrives exactly up to 1 GiB; from 1.5 GiB on only its first half is written (1.5 -> 0.75,
 # 2 -> 1, 2.5 -> 1.25, 3 -> 1.5, 4 -> 2 GiB; the rest of the destination keeps its old contents), identically for
 # 1-byte and 8-byte elements and with or without explicit split sizes -- so the loss is a byte-count matter inside
-# RCCL's send-to-self path, not torch's split-size arithmetic.  Consequences here: (1) the self part of every
-# all-to-all is a plain device copy and never goes through the collective; (2) messages to other ranks stay at or below
-# 1 GiB, the largest size seen exact (whether the xGMI path shares the defect cannot be tested on one GPU);
-# (3) every message is checked against a digest of its sender (ExchangeCheck), so a damaged one raises.
+# RCCL's send-to-self path, not torch's split-size arithmetic.  Consequences here: (1) no message of a call exceeds
+# 1 GiB, the largest size seen exact -- for the self message that is the measured limit, for messages to other ranks
+# (whether the xGMI path shares the defect cannot be tested on one GPU) it is the same conservative bound; larger
+# transfers go in rounds; (2) with one rank the exchange is a plain device copy; (3) every message is checked against a
+# digest of its sender (ExchangeCheck), so a damaged one raises instead of building a wrong graph.
 MAX_MESSAGE_BYTES = 1 << 30
 
 
@@ -60,23 +61,12 @@ def _alltoallv_once(dist, tensor, send_counts, recv_counts):
         out = torch.empty(n_out, dtype=tensor.dtype)
         dist.all_to_all_single(out, tensor.cpu().contiguous(), recv_counts, send_counts)
         return out.to(tensor.device)
+    if len(send_counts) == 1 and dist.get_backend() == "nccl":
+        return tensor.contiguous().clone()  # one rank: the exchange is a device copy, RCCL's send-to-self is not involved
+    # every message is at most MAX_MESSAGE_BYTES here (alltoallv cuts larger ones into rounds), the size range in which
+    # the send-to-self path was seen exact too
     out = torch.empty(n_out, dtype=tensor.dtype, device=tensor.device)
-    if dist.get_backend() != "nccl":  # in-process stand-in of the tests
-        dist.all_to_all_single(out, tensor.contiguous(), recv_counts, send_counts)
-        return out
-    # nccl: the message to this rank itself is a device copy, not part of the collective (see MAX_MESSAGE_BYTES);
-    # the others go as views of the two buffers (grouped send / recv, no staging copies)
-    me, w = dist.get_rank(), len(send_counts)
-    tensor = tensor.contiguous()
-    s_off = [sum(send_counts[:d]) for d in range(w)]
-    r_off = [sum(recv_counts[:d]) for d in range(w)]
-    assert send_counts[me] == recv_counts[me]
-    if send_counts[me]:
-        out[r_off[me]:r_off[me] + recv_counts[me]] = tensor[s_off[me]:s_off[me] + send_counts[me]]
-    if w > 1:
-        ins = [tensor[s_off[d]:s_off[d] + (0 if d == me else send_counts[d])] for d in range(w)]
-        outs = [out[r_off[d]:r_off[d] + (0 if d == me else recv_counts[d])] for d in range(w)]
-        dist.all_to_all(outs, ins)
+    dist.all_to_all_single(out, tensor.contiguous(), recv_counts, send_counts)
     return out
 
 

@@ -49,6 +49,7 @@ def build(reads2d, k, **opts):
     dict(engine=0, bucket_bits=9),
     dict(engine=0, bucket_bits=12, lds_slots=2048),
     dict(engine=0, bucket_bits=18),
+    dict(engine=0, bucket_bits=22),                  # three multisplit levels: 10 + 10 + 2 bits, all 22 of the bucket hash
     dict(engine=0, bucket_bits=1, lds_slots=2048),   # forces LDS overflow splits
 ])
 def test_engine_matches_c_oracle(k, opts):

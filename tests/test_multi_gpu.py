@@ -140,8 +140,9 @@ def test_damaged_exchange_is_detected():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,n_reads,read_len", [(31, 24000, 150), (21, 8000, 100), (63, 8000, 150)])
-def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len):
+@pytest.mark.parametrize("k,n_reads,read_len,bucket_bits", [(31, 24000, 150, 0), (21, 8000, 100, 0), (63, 8000, 150, 0),
+                                                            (31, 8000, 150, 21)])  # 21 bits: 9 (senders) + 10 + 2, third level
+def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len, bucket_bits):
     """shard_bits = 3 through the C ABI before a real 8-GPU node sees it: eight handles on cuda:0, one thread per rank,
     the real multi_gpu.sharded_build with an in-process exchange; union of the shards == the C oracle."""
     import _dbg
@@ -150,6 +151,8 @@ def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len):
     def one(dist, rank):
         reads = rank_reads(8, rank, n_reads, read_len)
         g = _dbg.Graph(device=0)
+        if bucket_bits:
+            g.set_option("bucket_bits", bucket_bits)
         g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
         multi_gpu.sharded_build(g, k, dist)
         keys, stamps, counts, _ = g.export_nodes()
