@@ -5,6 +5,11 @@ import sys
 
 import pytest
 
+try:  # torch bundles a HIP runtime of its own: it must be in the process before anything loads the system one
+    import torch  # noqa: F401  (see _dbg.load_library; some tests open the library with ctypes directly)
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "py-debruijn_amd")
 for p in (ROOT, PKG):

@@ -281,3 +281,24 @@ def test_per_range_edge_order_and_pull_reads_with_64bit_stamps():
     assert res[0][4] == res[1][4] > 1000 and res[0][3] == res[1][3] > 1000
     assert np.array_equal(res[0][2], res[1][2])
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+def test_bench_digest_on_the_device_equals_the_oracle_digest():
+    """bench.py compares the GPU graph with the multi-threaded CPU baseline at full size through a 64-bit digest over
+    (k-mer, stamp, 4 counts) of every node; here the device-side digest (torch int64 arithmetic) against the numpy one
+    of the C oracle's export, and against orc_build_mt's own."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    reads = synth.reads_ascii(21, 200_000, 40_000, 100, 0.01)
+    off = np.arange(0, reads.size + 1, 100, dtype=np.uint64)
+    g = _dbg.Graph()
+    g.set_reads(reads.reshape(-1), off)
+    g.build(31)
+    want = orc_c.build(reads.reshape(-1), off, 31)
+    mt = orc_c.build_mt(reads.reshape(-1), off, 31, 4)
+    d = bench.node_digest_gpu(g)
+    assert d == orc_c.digest(want["keys"], want["stamps"], want["counts"]) == mt["digest"]
+    assert g.sizes()["n_edges"] == mt["n_edges"] and g.sizes()["n_nodes"] == mt["n_nodes"]
