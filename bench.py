@@ -249,7 +249,8 @@ def main():
     else:
         reads_per_rank = args.reads or (10_000_000 if world == 1 else 12_500_000)
         n_total = reads_per_rank * world
-        which = ("BASELINE.json configs[1]" if world == 1 and reads_per_rank == 10_000_000 else
+        which = ("the read set of BASELINE.json configs[1] at another k" if world == 1 and reads_per_rank == 10_000_000 and k != 31 else
+                 "BASELINE.json configs[1]" if world == 1 and reads_per_rank == 10_000_000 else
                  "BASELINE.json configs[2]" if n_total == 100_000_000 and world == 8 else
                  f"BASELINE.json configs[2] scaled to {world}/8 of its reads" if reads_per_rank == 12_500_000 else "custom size")
         workload = f"{n_total} x {L} bp synthetic reads ({reads_per_rank} per GPU): {which}"
