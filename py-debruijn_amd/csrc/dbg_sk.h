@@ -1020,35 +1020,52 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 __syncthreads();  // entries visible to every thread's pop
                 continue;
             }
-            // ---- dense list of occupied slots + CSR edge offsets: one packed LDS atomic per wave hands out a
-            //      block of node indices and the matching block of edge slots, so rows stay in node order
-            for (int i = threadIdx.x; i < CAP; i += CNT_NT) {
-                const bool occ = s.keys[i] != EMPTY_KEY;
-                uint32_t deg = 0;
-                if (occ) {
-                    const uint4 c4 = reinterpret_cast<const uint4 *>(s.cnt)[i];
-                    deg = (c4.x != 0) + (c4.y != 0) + (c4.z != 0) + (c4.w != 0);
-                }
-                const unsigned long long mask = __ballot(occ);
-                if ((threadIdx.x & 63) == 0) s.dir_mask[i >> 6] = mask;
-                if (mask) {
-                    // exclusive prefix of deg (0..4) over the wave: four ballots, no cross-lane scan
-                    uint32_t eexc = 0, etot = 0;
+            // ---- dense list of occupied slots + CSR edge offsets.  A wave looks at its CAP / CNT_NT blocks of 64 slots
+            //      together: all their LDS reads go out back to back (one wait instead of one per block), and ONE packed LDS
+            //      atomic hands the wave its node indices and the matching edge slots for all of them, so rows stay in
+            //      node order (per block this was a chain of read -> ballots -> atomic round trip -> writes, four times)
+            {
+                constexpr int NB = CAP / CNT_NT;
+                unsigned long long kk[NB];
+                uint4 cc[NB];
 #pragma unroll
-                    for (int j = 1; j <= 4; ++j) {
+                for (int t = 0; t < NB; ++t) {
+                    const int i = threadIdx.x + t * CNT_NT;
+                    kk[t] = s.keys[i];
+                    cc[t] = reinterpret_cast<const uint4 *>(s.cnt)[i];
+                }
+                unsigned long long mask[NB];
+                uint32_t below[NB], eexc[NB], nn[NB], ne[NB], tot = 0;
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const bool occ = kk[t] != EMPTY_KEY;
+                    const uint32_t deg = occ ? (cc[t].x != 0) + (cc[t].y != 0) + (cc[t].z != 0) + (cc[t].w != 0) : 0u;
+                    mask[t] = __ballot(occ);
+                    below[t] = lanes_below(mask[t]);
+                    eexc[t] = 0;
+                    ne[t] = 0;
+#pragma unroll
+                    for (int j = 1; j <= 4; ++j) {  // exclusive prefix of deg (0..4) over the wave: four ballots, no cross-lane scan
                         const unsigned long long mj = __ballot(deg >= (uint32_t)j);
-                        eexc += lanes_below(mj);
-                        etot += (uint32_t)__popcll(mj);
+                        eexc[t] += lanes_below(mj);
+                        ne[t] += (uint32_t)__popcll(mj);
                     }
-                    uint32_t base = 0;
-                    if ((threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if ((threadIdx.x & 63) == 0) s.dir_base[i >> 6] = (uint16_t)base;
-                    if (occ) {
-                        const uint32_t li = (base & 0xFFFFu) + lanes_below(mask);
+                    nn[t] = (uint32_t)__popcll(mask[t]);
+                    tot += nn[t] | (ne[t] << 16);
+                }
+                uint32_t base = 0;
+                if (tot && (threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, tot);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int i = threadIdx.x + t * CNT_NT;
+                    if ((threadIdx.x & 63) == 0) { s.dir_mask[i >> 6] = mask[t]; s.dir_base[i >> 6] = (uint16_t)base; }
+                    if (kk[t] != EMPTY_KEY) {
+                        const uint32_t li = (base & 0xFFFFu) + below[t];
                         s.list[li] = (uint16_t)i;
-                        s.eoff[li] = (uint16_t)((base >> 16) + eexc);
+                        s.eoff[li] = (uint16_t)((base >> 16) + eexc[t]);
                     }
+                    base += nn[t] | (ne[t] << 16);
                 }
             }
             CNT_TICK(6);

@@ -554,34 +554,50 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 __syncthreads();
                 continue;
             }
-            // ---- dense list of occupied slots + CSR edge offsets
-            for (int i = threadIdx.x; i < WCAP; i += WCNT_NT) {
-                const bool occ = s.khi[i] != EMPTY_KEY;
-                uint32_t deg = 0;
-                if (occ) {
-                    uint32_t c[4];
-                    wcnt_load(s.cnt2, (uint32_t)i, c);
-                    deg = (c[0] != 0) + (c[1] != 0) + (c[2] != 0) + (c[3] != 0);
+            // ---- dense list of occupied slots + CSR edge offsets: a wave takes its four 64-slot blocks together (reads
+            //      back to back, ONE packed LDS atomic for all of them), as in k_sk_count
+            {
+                constexpr int NB = WCAP / WCNT_NT;
+                unsigned long long kk[NB];
+                uint2 cc[NB];
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int i = threadIdx.x + t * WCNT_NT;
+                    kk[t] = s.khi[i];
+                    cc[t] = reinterpret_cast<const uint2 *>(s.cnt2)[i];
                 }
-                const unsigned long long mask = __ballot(occ);
-                if ((threadIdx.x & 63) == 0) s.dir_mask[i >> 6] = mask;
-                if (mask) {
-                    uint32_t eexc = 0, etot = 0;
+                unsigned long long mask[NB];
+                uint32_t below[NB], eexc[NB], nn[NB], ne[NB], tot = 0;
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const bool occ = kk[t] != EMPTY_KEY;
+                    const uint32_t deg = occ ? ((cc[t].x & 0xFFFFu) != 0) + ((cc[t].x >> 16) != 0) + ((cc[t].y & 0xFFFFu) != 0) + ((cc[t].y >> 16) != 0) : 0u;
+                    mask[t] = __ballot(occ);
+                    below[t] = lanes_below(mask[t]);
+                    eexc[t] = 0;
+                    ne[t] = 0;
 #pragma unroll
                     for (int j = 1; j <= 4; ++j) {
                         const unsigned long long mj = __ballot(deg >= (uint32_t)j);
-                        eexc += lanes_below(mj);
-                        etot += (uint32_t)__popcll(mj);
+                        eexc[t] += lanes_below(mj);
+                        ne[t] += (uint32_t)__popcll(mj);
                     }
-                    uint32_t base = 0;
-                    if ((threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, (uint32_t)__popcll(mask) | (etot << 16));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if ((threadIdx.x & 63) == 0) s.dir_base[i >> 6] = (uint16_t)base;
-                    if (occ) {
-                        const uint32_t li = (base & 0xFFFFu) + lanes_below(mask);
+                    nn[t] = (uint32_t)__popcll(mask[t]);
+                    tot += nn[t] | (ne[t] << 16);
+                }
+                uint32_t base = 0;
+                if (tot && (threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, tot);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int t = 0; t < NB; ++t) {
+                    const int i = threadIdx.x + t * WCNT_NT;
+                    if ((threadIdx.x & 63) == 0) { s.dir_mask[i >> 6] = mask[t]; s.dir_base[i >> 6] = (uint16_t)base; }
+                    if (kk[t] != EMPTY_KEY) {
+                        const uint32_t li = (base & 0xFFFFu) + below[t];
                         s.list[li] = (uint16_t)i;
-                        s.eoff[li] = (uint16_t)((base >> 16) + eexc);
+                        s.eoff[li] = (uint16_t)((base >> 16) + eexc[t]);
                     }
+                    base += nn[t] | (ne[t] << 16);
                 }
             }
             CNT_TICK(6);
