@@ -220,6 +220,12 @@ int dbg_export_contigs(dbg_t *h, uint64_t *offsets, char *chars, uint64_t *score
                        uint32_t *seq_in_start);
 /* the same without the text: offsets[n_contigs+1] (contig i has offsets[i+1]-offsets[i] characters) */
 int dbg_export_contig_index(dbg_t *h, uint64_t *offsets, uint64_t *scores, uint64_t *start_stamp, uint32_t *seq_in_start);
+/* f2: contig sort + FASTA text on the device (II_assembleFromReads.py:64-69).  The contigs of the last materialised walk,
+ * sorted by score descending and stable like `sequences.sort(key=getScore, reverse=True)`, as the text the driver
+ * writes: ">SEQUENCE_{i}_{k}mer\n{contig}\n" per contig.  *bytes receives the size of the text (call with buf == NULL to
+ * ask for it); order_out (may be NULL): [n_contigs] index of the contig at every output position, indices as in
+ * dbg_export_contigs. */
+int dbg_export_sorted_fasta(dbg_t *h, uint32_t *order_out, char *buf, uint64_t buf_len, uint64_t *bytes);
 /* Text of ONE contig (buf_len >= its length from the index): what a caller uses when dbg_walk kept the index only
  * because the whole text exceeds max_chars (contigs overlap massively at scale).  The first call after a walk builds
  * the binary-lifting tables of the chain successors (n_nodes x ceil(log2 n_nodes) x 4 bytes), later calls are one

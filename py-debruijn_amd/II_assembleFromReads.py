@@ -38,8 +38,11 @@ def assemble(sequences, k_lowerlimit, k_upperlimit, threshold, out_path=None):
         if k == k_upperlimit:
             if out_path is not None:
                 with open(out_path, mode='a+') as out_file:  # append mode, as in the reference
-                    for i in range(len(sequences)):
-                        out_file.writelines('>SEQUENCE_{}_{}mer\n{}\n'.format(i, k, sequences[i]))
+                    if hasattr(contigs, "sorted_fasta"):
+                        out_file.write(contigs.sorted_fasta())  # the same records, sorted and formatted on the device
+                    else:
+                        for i in range(len(sequences)):
+                            out_file.writelines('>SEQUENCE_{}_{}mer\n{}\n'.format(i, k, sequences[i]))
             break
         print('max length: ', len(max(sequences, key=lambda x: len(x))))
         print('number of output for k={}: '.format(k), len(sequences))

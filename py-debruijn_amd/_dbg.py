@@ -31,7 +31,7 @@ SYMBOLS = (
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
     "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
-    "dbg_support_read_scores", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
+    "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
 )
 
 
@@ -127,6 +127,7 @@ def load_library():
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_build_multipass": (C.c_int, [H, C.c_int, C.c_int]),
+        "dbg_export_sorted_fasta": (C.c_int, [H, vp, vp, C.c_uint64, u64p]),
         "dbg_support_read_scores": (C.c_int, [H, vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "dbg_part_count": (C.c_int, [H, C.POINTER(C.c_int)]),
         "dbg_part_sizes": (C.c_int, [H, C.c_int, u64p, u64p, u64p]),
@@ -365,6 +366,17 @@ class Graph:
         self._chk(self._lib.dbg_export_contigs(self._h, _ptr(off), _ptr(chars), _ptr(score), _ptr(stamp), _ptr(seq)))
         return off, chars, score, stamp, seq
 
+
+    def export_sorted_fasta(self):
+        """The contigs of the last (materialised) walk, sorted by score like the reference's driver, as FASTA text
+        (II_assembleFromReads.py:64-69) -> (bytes, order uint32[n_contigs])."""
+        n = C.c_uint64()
+        self._chk(self._lib.dbg_export_sorted_fasta(self._h, None, None, 0, C.byref(n)))
+        buf = np.empty(n.value, dtype=np.uint8)
+        order = np.empty(self.sizes()["n_contigs"], dtype=np.uint32)
+        self._chk(self._lib.dbg_export_sorted_fasta(self._h, _ptr(order) if order.size else None, _ptr(buf) if buf.size else None,
+                                                    buf.size, C.byref(n)))
+        return buf.tobytes(), order
 
     # ---- read-support scores (IV_sortOutputs.py:10-15)
     def support_read_scores(self, read_chars, read_off, scores, is_float, contig_chars, contig_off):

@@ -4691,3 +4691,116 @@ extern "C" int dbg_support_read_scores(dbg_t *h, const char *read_chars, const u
     if (d_tmp) (void)hipFree(d_tmp);
     return rc;
 }
+
+// ==========================================================================================
+// Contig sort + FASTA text on the device (II_assembleFromReads.py:64-69): the contigs of the last
+// (materialised) walk in the order `sequences.sort(key=getScore, reverse=True)` leaves them in -- stable, so ties keep
+// the emission order (start nodes in dict order, emission order inside a start) -- as the text the driver writes:
+// ">SEQUENCE_{i}_{k}mer\n{contig}\n".
+// ==========================================================================================
+struct FaRecLen {  // bytes of record i: header + contig + newline
+    const uint32_t *order;
+    const uint64_t *off;
+    uint32_t k_digits;
+    __host__ __device__ static uint32_t digits(uint64_t v) { uint32_t d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+    __device__ uint64_t operator()(uint64_t i) const {
+        const uint32_t c = order[i];
+        return 10 + digits(i) + 1 + k_digits + 4 + (off[c + 1] - off[c]) + 1;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_fa_keys(uint64_t n, const uint32_t *__restrict__ ids, const uint64_t *__restrict__ src64,
+                                                 const uint32_t *__restrict__ src32, int invert, uint64_t *keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = ids ? ids[i] : (uint32_t)i;
+    const uint64_t v = src64 ? src64[c] : (uint64_t)src32[c];
+    keys[i] = invert ? ~v : v;
+}
+
+__global__ __launch_bounds__(256) void k_fa_text(uint64_t n_bytes, uint64_t n_ctg, const uint64_t *__restrict__ pos,
+                                                 const uint32_t *__restrict__ order, const uint64_t *__restrict__ off,
+                                                 const char *__restrict__ chars, uint32_t k, char *out) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bytes) return;
+    uint64_t lo = 0, hi = n_ctg;  // pos[lo] <= b < pos[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (pos[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uint64_t i = lo, rel = b - pos[i];
+    const uint32_t c = order[i];
+    const uint32_t di = FaRecLen::digits(i), dk = FaRecLen::digits(k);
+    const uint64_t hdr = 10 + di + 1 + dk + 4, len = off[c + 1] - off[c];
+    char ch;
+    if (rel < 10) ch = ">SEQUENCE_"[rel];
+    else if (rel < 10 + di) { uint64_t v = i; for (uint32_t s = (uint32_t)(10 + di - 1 - rel); s; --s) v /= 10; ch = (char)('0' + v % 10); }
+    else if (rel == 10 + di) ch = '_';
+    else if (rel < 11 + di + dk) { uint32_t v = k; for (uint32_t s = (uint32_t)(11 + di + dk - 1 - rel); s; --s) v /= 10; ch = (char)('0' + v % 10); }
+    else if (rel < hdr) ch = "mer\n"[rel - (11 + di + dk)];
+    else if (rel < hdr + len) ch = chars[off[c] + (rel - hdr)];
+    else ch = '\n';
+    out[b] = ch;
+}
+
+extern "C" int dbg_export_sorted_fasta(dbg_t *h, uint32_t *order_out, char *buf, uint64_t buf_len, uint64_t *bytes) {
+    if (!h || !bytes) return DBG_E_ARG;
+    if (!h->walked) {
+        h->err = h->walk_indexed ? "contig text was not materialised (larger than max_chars)" : "dbg_walk must run first";
+        return DBG_E_ARG;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint64_t n = h->n_contigs;
+    *bytes = 0;
+    if (!n) return DBG_OK;
+    if (n >= 0xFFFFFFF0ull) { h->err = "too many contigs for one sort"; return DBG_E_CAPACITY; }
+    uint64_t *ka = nullptr, *kb = nullptr, *pos = nullptr;
+    uint32_t *ia = nullptr, *ib = nullptr;
+    char *d_out = nullptr;
+    void *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int rc = DBG_OK;
+    do {
+        if ((rc = dev_alloc(h, &ka, n)) || (rc = dev_alloc(h, &kb, n)) || (rc = dev_alloc(h, &ia, n)) || (rc = dev_alloc(h, &ib, n)) ||
+            (rc = dev_alloc(h, &pos, n + 1)))
+            break;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, ka, kb, ia, ib, (size_t)n, 0u, 64u, h->stream);
+        if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+        if (e != hipSuccess) { h->err = std::string("sorted fasta: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
+        const dim3 grid(grid_for(n, 256));
+        // emission order = (start stamp, emission index inside the start): two stable passes, minor key first
+        hipLaunchKernelGGL(k_iota32, grid, dim3(256), 0, h->stream, n, ia);
+        hipLaunchKernelGGL(k_fa_keys, grid, dim3(256), 0, h->stream, n, (const uint32_t *)nullptr, (const uint64_t *)nullptr,
+                           (const uint32_t *)h->d_ctg_seq, 0, ka);
+        e = rocprim::radix_sort_pairs(tmp, tmp_bytes, ka, kb, ia, ib, (size_t)n, 0u, 32u, h->stream);
+        hipLaunchKernelGGL(k_fa_keys, grid, dim3(256), 0, h->stream, n, (const uint32_t *)ib, (const uint64_t *)h->d_ctg_stamp,
+                           (const uint32_t *)nullptr, 0, ka);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, ka, kb, ib, ia, (size_t)n, 0u, 64u, h->stream);
+        // ... then the driver's sort: by score, descending, stable
+        hipLaunchKernelGGL(k_fa_keys, grid, dim3(256), 0, h->stream, n, (const uint32_t *)ia, (const uint64_t *)h->d_ctg_score,
+                           (const uint32_t *)nullptr, 1, ka);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, ka, kb, ia, ib, (size_t)n, 0u, 64u, h->stream);
+        if (e != hipSuccess) { h->err = std::string("sorted fasta: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
+        uint64_t total = 0;
+        if ((rc = exclusive_scan(h, n, FaRecLen{ib, h->d_ctg_off, FaRecLen::digits((uint64_t)h->k)}, pos, &total)) != DBG_OK) break;
+        *bytes = total;
+        if (order_out) {
+            e = hipMemcpyAsync(order_out, ib, n * 4, hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = DBG_E_HIP; break; }
+        }
+        if (buf) {
+            if (buf_len < total) { h->err = "buffer smaller than the FASTA text"; rc = DBG_E_ARG; break; }
+            if ((rc = dev_alloc(h, &d_out, total)) != DBG_OK) break;
+            hipLaunchKernelGGL(k_fa_text, dim3(grid_for(total, 256)), dim3(256), 0, h->stream, total, n, pos, ib, h->d_ctg_off,
+                               h->d_ctg_chars, (uint32_t)h->k, d_out);
+            e = hipMemcpyAsync(buf, d_out, total, hipMemcpyDeviceToHost, h->stream);
+            if (e != hipSuccess) { h->err = hipGetErrorString(e); rc = DBG_E_HIP; break; }
+        }
+        e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { h->err = std::string("sorted fasta: ") + hipGetErrorString(e); rc = DBG_E_HIP; break; }
+    } while (0);
+    if (tmp) (void)hipFree(tmp);
+    dev_free(ka); dev_free(kb); dev_free(ia); dev_free(ib); dev_free(pos); dev_free(d_out);
+    return rc;
+}

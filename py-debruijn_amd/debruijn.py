@@ -314,8 +314,19 @@ class _Tracked(list):
 
 
 class ContigList(list):
-    """list[str] of contigs plus the device-computed getScore of each (``.scores``)."""
+    """list[str] of contigs plus the device-computed getScore of each (``.scores``).
+
+    ``sorted_fasta()`` returns the text the reference's driver writes for this list -- contigs sorted by score,
+    descending and stable, as ``>SEQUENCE_{i}_{k}mer`` records (II_assembleFromReads.py:64-69) -- sorted and formatted
+    on the device (dbg_export_sorted_fasta); valid until the graph handle builds or walks again."""
     scores = None
+    _graph = None
+    _generation = None
+
+    def sorted_fasta(self):
+        if self._graph is None or self._generation != self._graph.generation:
+            raise ValueError("the device contigs of this list are gone (the handle built another graph)")
+        return self._graph.export_sorted_fasta()[0].decode("latin-1")
 
 
 MAX_CONTIG_CHARS = 0  # dbg_walk's max_chars; 0 = the library default (1 GiB of contig text kept on the device)
@@ -538,6 +549,7 @@ def output_contigs(g, branch_kmer, already_pull_out):
     text = chars.tobytes().decode("latin-1")
     out = ContigList(text[int(off[i]):int(off[i + 1])] for i in order)
     out.scores = [int(score[i]) for i in order]
+    out._graph, out._generation = graph, graph.generation
     return out
 
 

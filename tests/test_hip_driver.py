@@ -147,3 +147,19 @@ def test_output_contigs_refuses_a_graph_that_was_replaced(tmp_path):
         with pytest.raises(ValueError, match="replaced"):
             prod.output_contigs(first[0], first[2], first[3])
         assert len(prod.output_contigs(second[0], second[2], second[3])) > 0
+
+
+def test_sorted_fasta_from_the_device_equals_the_host_formatting():
+    """dbg_export_sorted_fasta: the driver's sort (score descending, stable) and its record format
+    (II_assembleFromReads.py:64-69), done on the device, against the same done on the host from the contig list."""
+    import debruijn as prod
+    import synth
+    for seed, k, final in ((61, 15, True), (62, 21, False), (63, 9, True)):
+        reads = synth.reads_list(seed, 3000, 400, 80, 0.01)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g, pull, branch, pulled, ect = prod.construct_graph(reads, k, threshold=2, final=final)
+            contigs = prod.output_contigs(g, branch, pulled)
+        scores = prod.get_score_device(contigs)
+        order = sorted(range(len(contigs)), key=lambda i: scores[i], reverse=True)
+        want = "".join('>SEQUENCE_{}_{}mer\n{}\n'.format(i, k, contigs[j]) for i, j in enumerate(order))
+        assert len(contigs) > 10 and contigs.sorted_fasta() == want
