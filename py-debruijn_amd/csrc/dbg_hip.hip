@@ -2148,6 +2148,7 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
         if (fallback) {
             free_build(h);
             h->k = k;
+            h->stats = dbg_stats_t{};
             rc = build_wide(h, k, table_capacity_hint);
         }
         if (rc == DBG_OK) rc = finish_graph(h);

@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256) void k_wsk_gather(const uint64_t *__restrict__
 // ------------------------------------------------------------------------------------------------
 // per-bucket counting in LDS
 // ------------------------------------------------------------------------------------------------
-constexpr int WCNT_NT = 1024;
+#ifndef DBG_WCNT_NT
+#define DBG_WCNT_NT 1024
+#endif
+constexpr int WCNT_NT = DBG_WCNT_NT;
 constexpr int WCNT_STAGE = 288;      // records staged per round (a bucket holds 140 +- 64 at the default geometry: a second round
                                      // pays the dedupe / quad list / insert barriers again and loads its records unprefetched)
 constexpr int WCNT_QMAX = 13;        // quads of 4 k-mers per record: ceil(51 / 4)

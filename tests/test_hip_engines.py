@@ -202,3 +202,79 @@ def test_edge_order_and_pull_reads_from_bucket_records_equal_the_pass_over_the_r
     assert got[0][0].shape[0] > 100 and got[0][3] > 10
     assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
     assert got[0][3] == got[1][3] and np.array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.parametrize("k", [32, 40, 63])
+@pytest.mark.parametrize("opts", [
+    dict(),                                   # the super-k-mer / LDS engine of dbg_wsk.h, automatic geometry
+    dict(bucket_bits=3),                      # 8 buckets: every table overflows and is counted in hash sub-ranges
+    dict(bucket_bits=9),
+    dict(bucket_bits=14),
+    dict(bucket_bits=21),                     # three multisplit levels
+    dict(wide_engine=0),                      # the global reference-keyed table of dbg_wide.h
+])
+def test_two_word_engine_matches_c_oracle(k, opts):
+    reads = synth.reads_ascii(8, 40000, 4000, 120, 0.01)
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, 120, dtype=np.uint64), k)
+    g = build(reads, k, **opts)
+    sz = g.sizes()
+    assert sz["n_kmer_instances"] == want["n_kmer_instances"] and sz["n_edge_instances"] == want["n_edge_instances"]
+    assert sz["n_nodes"] == want["n_nodes"]
+    keys, stamps, counts, flags = g.export_nodes()
+    hi = g.export_keys_hi()
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(hi[o], want["keys_hi"])
+    assert np.array_equal(stamps[o], want["stamps"]) and np.array_equal(counts[o], want["counts"])
+    assert np.array_equal(flags & 1, (stamps & np.uint64(1)).astype(np.uint8))
+    succ = g.export_succ()
+    rp, col, cnt = g.export_csr()
+    assert int(rp[-1]) == sz["n_edges"] == int((counts != 0).sum())
+    assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+    # successors: the (2k)-bit shifted k-mer
+    full = (hi.astype(object) << 64) | keys.astype(object)
+    mask = (1 << (2 * k)) - 1
+    for code in range(4):
+        has = counts[:, code] != 0
+        assert np.all(succ[has, code] != 0xFFFFFFFF) and np.all(succ[~has, code] == 0xFFFFFFFF)
+        got = full[succ[has, code]]
+        assert np.array_equal(got, ((full[has] << 2) | code) & mask)
+
+
+def test_two_word_engine_counter_overflow_falls_back():
+    """The LDS engine for k > 31 keeps 16-bit successor counters; an edge seen more than 65 535 times must send the
+    build to the global-table engine, with the same result."""
+    read = synth.reads_ascii(3, 200, 1, 60, 0.0)[0]
+    reads = np.tile(read, (70000, 1))
+    k = 33
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, 60, dtype=np.uint64), k)
+    assert int(want["counts"].max()) == 70000
+    g = build(reads, k)
+    keys, stamps, counts, flags = g.export_nodes()
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(g.export_keys_hi()[o], want["keys_hi"])
+    assert np.array_equal(counts[o], want["counts"]) and np.array_equal(stamps[o], want["stamps"])
+    assert g.stats()["n_records"] == 0  # the fallback engine has no records
+
+
+def test_two_word_engine_ragged_reads():
+    """Variable-length reads (including len <= k, len == k + 1 and empty) packed back to back, k = 40."""
+    rng = np.random.default_rng(6)
+    genome = synth.reads_ascii(10, 6000, 1, 6000, 0.0)[0]
+    reads = []
+    for _ in range(2500):
+        L = int(rng.integers(0, 130))
+        s = int(rng.integers(0, 6000 - 130))
+        reads.append(genome[s:s + L])
+    blob = np.concatenate(reads) if reads else np.zeros(0, np.uint8)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum([r.size for r in reads], out=off[1:])
+    k = 40
+    want = orc_c.build(blob, off, k)
+    g = _dbg.Graph()
+    g.set_reads(blob, off)
+    g.build(k)
+    assert g.sizes()["n_nodes"] == want["n_nodes"] and g.sizes()["n_kmer_instances"] == want["n_kmer_instances"]
+    keys, stamps, counts, flags = g.export_nodes()
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(g.export_keys_hi()[o], want["keys_hi"])
+    assert np.array_equal(counts[o], want["counts"]) and np.array_equal(stamps[o], want["stamps"])
