@@ -245,7 +245,12 @@ int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const
  * st uint32); send_counts[n_shards] records go to each owner, contiguous and in owner order */
 int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
                       const void **d_st);
-/* records per level-1 bucket (the 512 top-9-bit groups of the bucket hash) of the last dbg_shard_extract, k <= 31:
+/* What the last dbg_shard_extract handed out: *w0_words = 64-bit words per record in d_w0 (1: super-k-mer records of
+ * k <= 31, or the low key word of the k-mer instances of k > 31 with "wide_engine" 0; 4: the aligned bases of a
+ * super-k-mer record of k > 31), *stamp_bytes = bytes per entry of d_st (4, or 8 for the instance tuples).  The
+ * exchange moves counts[d] x words elements of d_w0. */
+int dbg_shard_record_layout(dbg_t *h, int *w0_words, int *stamp_bytes);
+/* records per level-1 bucket (the 512 top-9-bit groups of the bucket hash) of the last dbg_shard_extract (k <= 31, and k > 31 on the LDS engine):
  * owner d holds the buckets [d * 512 / n_shards, (d + 1) * 512 / n_shards), in order, so send_counts[d] is their sum */
 int dbg_shard_bucket_counts(dbg_t *h, uint64_t *counts512);
 /* step 2: records received from rank r are recv_counts[r] consecutive entries (rank order);

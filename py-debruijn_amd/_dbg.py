@@ -29,7 +29,7 @@ SYMBOLS = (
     "dbg_mark_pull_reads", "dbg_walk", "dbg_get_sizes", "dbg_get_stats", "dbg_export_nodes", "dbg_export_keys_hi",
     "dbg_export_succ",
     "dbg_export_csr", "dbg_export_pull_ranks", "dbg_export_pull_reads", "dbg_export_contigs",
-    "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
+    "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_record_layout", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
     "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
 )
@@ -124,6 +124,7 @@ def load_library():
         "dbg_device_views": (C.c_int, [H] + [C.POINTER(vp)] * 5),
         "dbg_shard_extract": (C.c_int, [H, C.c_int, C.c_int, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "dbg_shard_bucket_counts": (C.c_int, [H, u64p]),
+        "dbg_shard_record_layout": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
         "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_build_multipass": (C.c_int, [H, C.c_int, C.c_int]),
@@ -433,7 +434,8 @@ class Graph:
 
     # ---- multi-GPU sharding (buffers are torch tensors on this handle's device; see multi_gpu.py)
     def shard_extract(self, k, n_shards):
-        """-> (send_counts list, (w0, w1, st) tensors viewing library memory, grouped by owner)."""
+        """-> (send_counts list, (w0, w1, st) tensors viewing library memory, grouped by owner).
+        w0 holds ``shard_record_layout()[0]`` words per record (1, or 4 for the two-word k-mers' records by value)."""
         counts = (C.c_uint64 * n_shards)()
         p0, p1, p2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._chk(self._lib.dbg_shard_extract(self._h, int(k), int(n_shards), counts, C.byref(p0), C.byref(p1),
@@ -441,9 +443,17 @@ class Graph:
         counts = [int(c) for c in counts]
         n = sum(counts)
         dev = self.sizes_device()
-        # k <= 31: super-k-mer records (w0, w1, 32-bit stamp); k > 31: k-mer instances (lo, hi | next << 62, 64-bit meta)
-        return counts, (device_tensor(p0.value, n, "int64", dev), device_tensor(p1.value, n, "int64", dev),
-                        device_tensor(p2.value, n, "int32" if int(k) <= 31 else "int64", dev))
+        words, st_bytes = self.shard_record_layout()
+        # k <= 31: super-k-mer records (w0, w1, 32-bit stamp); k > 31: records by value (4 words of bases, meta, 32-bit stamp)
+        # or, with "wide_engine" 0, k-mer instances (lo, hi | next << 62, 64-bit meta)
+        return counts, (device_tensor(p0.value, words * n, "int64", dev), device_tensor(p1.value, n, "int64", dev),
+                        device_tensor(p2.value, n, "int32" if st_bytes == 4 else "int64", dev))
+
+    def shard_record_layout(self):
+        """(64-bit words per record in the first tensor of shard_extract, bytes per stamp)."""
+        a, b = C.c_int(), C.c_int()
+        self._chk(self._lib.dbg_shard_record_layout(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def sizes_device(self):
         return getattr(self, "_device_index", default_device())
@@ -463,7 +473,7 @@ class Graph:
         qs, qc = (C.c_uint64 * n_shards)(), (C.c_uint64 * n_shards)()
         pk = C.c_void_p()
         sbc = None
-        if sender_bucket_counts is not None and int(k) <= 31:
+        if sender_bucket_counts is not None:
             flat = [int(x) for row in sender_bucket_counts for x in row]
             assert len(flat) == 512, "one count per (sender, owned level-1 bucket)"
             sbc = (C.c_uint64 * 512)(*flat)

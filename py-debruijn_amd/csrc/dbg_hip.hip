@@ -158,6 +158,7 @@ struct ShardState {
     uint64_t n_remote = 0;
     uint64_t n_kmer_inst_local = 0;          // k-mer instances of the reads this rank extracted
     std::vector<uint64_t> l1_counts;         // records per level-1 bucket (512) of the last dbg_shard_extract
+    int rec_words = 1, rec_stamp_bytes = 4;  // what dbg_shard_extract handed out: words per record in d_w0, bytes per stamp
 };
 static ShardState &shard_of(dbg *h);
 static void multipass_free(dbg *h);
@@ -371,6 +372,14 @@ struct KmerInstances {  // k-mer instances of read i
     const uint64_t *off;
     uint64_t k;
     __device__ uint64_t operator()(uint64_t i) const { const uint64_t len = off[i + 1] - off[i]; return len >= k ? len - k + 1 : 0; }
+};
+struct WRecLenAt {   // k-mers of wide record i
+    const uint64_t *w1;
+    __device__ uint64_t operator()(uint64_t i) const { return (uint64_t)wrec_len(w1[i]); }
+};
+struct WRecSuccAt {  // 1 if the last k-mer of wide record i has a successor
+    const uint64_t *w1;
+    __device__ uint64_t operator()(uint64_t i) const { return (uint64_t)wrec_has_succ(w1[i]); }
 };
 struct FlagSet {
     const uint8_t *f;
@@ -3481,85 +3490,105 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     return DBG_OK;
 }
 
-// ---- two-word k-mers on the super-k-mer engine (dbg_wsk.h): extraction -> two or three multisplit levels -> k_wsk_count
-//      -> k_wsucc_resolve.  Single GPU; the geometry logic is that of sk_count_from_segments with 2048-slot tables.
+// ---- two-word k-mers on the super-k-mer engine (dbg_wsk.h): extraction -> two or three multisplit levels -> k_wsk_gather
+//      -> k_wsk_count -> k_wsucc_resolve.  The geometry logic is that of sk_count_from_segments.
+
+__global__ __launch_bounds__(256) void k_wsk_iota128(uint64_t n, uint64_t *w0) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w0[i] = i * 128;  // received record i keeps its bases in words [4 i, 4 i + 4) of the "packed reads"
+}
+
+// part 1: 2-bit packed reads + records (position, meta, stamp) in one private segment per persistent workgroup (set 0)
 template <class ST>
-static int build_wsk_t(dbg *h, int k) {
+static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], uint64_t **seg_start_out,
+                       uint64_t **seg_cnt_out, uint32_t *n_seg_out, uint64_t *n_rec_out) {
     const int m = SK_MAX_M, w = k - m + 1;
     unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
     uint64_t sc[8] = {0};
-    // ---- 2-bit packed reads (the records point into them)
     const uint64_t pk_words = (h->n_bytes + 31) / 32;
     CHK(buf_ensure(h, h->ar_wide[0], (pk_words + 8) * 8));
     uint64_t *pk = (uint64_t *)h->ar_wide[0].p;
     HIPCHK(h, hipMemsetAsync(pk + pk_words, 0, 8 * 8, h->stream));
     if (pk_words)
         hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, pk_words, pk);
-    // ---- extraction into one private segment per persistent workgroup
     const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 1024);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
     uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg, *seg_ne = seg_nk + n_wg;
     std::vector<uint64_t> hseg((size_t)n_wg * 4);
-    uint64_t *w0[2], *w1[2];
-    ST *st[2];
     uint64_t n_rec = 0;
-    {
-        Timer t(h->stream);
-        const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
-        const double density = std::min(1.0, 2.6 / (double)(w + 1) + 1.3 * (double)(h->n_reads + 1) / (double)(h->n_bytes + 1) + 0.01);
-        uint64_t seg_cap = (uint64_t)((double)(tiles_per_wg * TILE) * density) + 256;
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            const uint64_t rec_cap = seg_cap * n_wg;
-            for (int set = 0; set < 2; ++set) {
-                CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
-                CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
-                CHK(buf_ensure(h, h->ar_rec[set][2], rec_cap * sizeof(ST)));
-                w0[set] = (uint64_t *)h->ar_rec[set][0].p;
-                w1[set] = (uint64_t *)h->ar_rec[set][1].p;
-                st[set] = (ST *)h->ar_rec[set][2].p;
-            }
-            for (uint32_t g = 0; g < n_wg; ++g) hseg[g] = (uint64_t)g * seg_cap;
-            HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
-            HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
-            if (tiles) {
-                auto ekern = k_wsk_extract<ST>;
-                HIPCHK(h, hipFuncSetAttribute((const void *)ekern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WSkLds)));
-                hipLaunchKernelGGL(ekern, dim3(n_wg), dim3(WSK_NT), sizeof(WSkLds), h->stream, h->d_bases, h->n_bytes,
-                                   h->d_startbits, k, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
-            }
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(h, hipStreamSynchronize(h->stream));
-            if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
-            if (!(sc[0] & 4)) break;
-            if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
-            seg_cap = tiles_per_wg * TILE;
+    Timer t(h->stream);
+    const uint64_t tiles_per_wg = (tiles + n_wg - 1) / n_wg;
+    const double density = std::min(1.0, 2.6 / (double)(w + 1) + 1.3 * (double)(h->n_reads + 1) / (double)(h->n_bytes + 1) + 0.01);
+    uint64_t seg_cap = (uint64_t)((double)(tiles_per_wg * TILE) * density) + 256;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const uint64_t rec_cap = seg_cap * n_wg;
+        for (int set = 0; set < 2; ++set) {
+            CHK(buf_ensure(h, h->ar_rec[set][0], rec_cap * 8));
+            CHK(buf_ensure(h, h->ar_rec[set][1], rec_cap * 8));
+            CHK(buf_ensure(h, h->ar_rec[set][2], rec_cap * sizeof(ST)));
+            w0[set] = (uint64_t *)h->ar_rec[set][0].p;
+            w1[set] = (uint64_t *)h->ar_rec[set][1].p;
+            st[set] = (ST *)h->ar_rec[set][2].p;
         }
-        h->n_kmer_inst = h->n_edge_inst = 0;
-        for (uint32_t g = 0; g < n_wg; ++g) {
-            n_rec += hseg[n_wg + g];
-            h->n_kmer_inst += hseg[2 * n_wg + g];
-            h->n_edge_inst += hseg[3 * n_wg + g];
+        for (uint32_t g = 0; g < n_wg; ++g) hseg[g] = (uint64_t)g * seg_cap;
+        HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
+        if (tiles) {
+            auto ekern = k_wsk_extract<ST>;
+            HIPCHK(h, hipFuncSetAttribute((const void *)ekern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WSkLds)));
+            hipLaunchKernelGGL(ekern, dim3(n_wg), dim3(WSK_NT), sizeof(WSkLds), h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, k, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
         }
-        h->host_seg_cnt.assign(hseg.begin() + n_wg, hseg.begin() + 2 * (size_t)n_wg);
-        h->stats.ms_extract = t.stop();
-        h->stats.n_records = n_rec;
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(hseg.data(), seg_start, (size_t)n_wg * 4 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (sc[0] & 1) { h->err = "reads hold a byte outside ACGT"; return DBG_E_ALPHABET; }
+        if (!(sc[0] & 4)) break;
+        if (attempt == 1) { h->err = "super-k-mer record buffer overflow"; return DBG_E_CAPACITY; }
+        seg_cap = tiles_per_wg * TILE;
     }
-    const uint64_t n_inst = h->n_kmer_inst, n_edge_inst = h->n_edge_inst;
+    h->n_kmer_inst = h->n_edge_inst = 0;
+    for (uint32_t g = 0; g < n_wg; ++g) {
+        n_rec += hseg[n_wg + g];
+        h->n_kmer_inst += hseg[2 * n_wg + g];
+        h->n_edge_inst += hseg[3 * n_wg + g];
+    }
+    h->host_seg_cnt.assign(hseg.begin() + n_wg, hseg.begin() + 2 * (size_t)n_wg);
+    h->stats.ms_extract = t.stop();
+    h->stats.n_records = n_rec;
+    *pk_out = pk; *seg_start_out = seg_start; *seg_cnt_out = seg_cnt; *n_seg_out = n_wg; *n_rec_out = n_rec;
+    return DBG_OK;
+}
+
+// part 2: records -> node arrays + CSR.  Either the segments wsk_extract wrote (single GPU: level 1 runs here), or -- a
+// shard of a multi-GPU build -- records received from every sender, split by the 512 level-1 groups already (`pre`):
+// the build starts at level 2, which rebases the 32-bit stamps, and a successor whose bucket another shard owns is
+// left unresolved (the gathered graph resolves every successor anyway, dbg_import_graph).
+template <class ST, class STI>
+static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_start, const uint64_t *seg_cnt, uint32_t n_seg,
+                     uint64_t n_rec, uint64_t n_inst, uint64_t n_edge_inst, const uint64_t *in_w0, const uint64_t *in_w1,
+                     const ST *in_st, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], int shard_bits, int my_shard,
+                     const Presplit *pre) {
+    const int m = SK_MAX_M, w = k - m + 1;
+    unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
+    uint64_t sc[8] = {0};
+    const double own = shard_bits ? (double)(1 << shard_bits) : 1.0;
     // ---- bucket geometry
     constexpr double TARGET_DISTINCT = WCAP * 0.36;
     int T = h->bucket_bits;
     const bool auto_T = (T == 0);
     if (auto_T) {
-        const double want = (double)n_inst * 0.4 / TARGET_DISTINCT;
+        const double want = (double)n_inst * own * 0.4 / TARGET_DISTINCT;
         while (T < 20 && (double)(1ull << T) < want) ++T;
     }
-    // 10 bits at level 1 from 2^18 buckets on: 2048-slot tables need twice the buckets of the one-word engine, and a third
-    // level over half a million tiny segments costs more than it splits
-    int l1 = T < 9 ? T : (T >= 18 ? 10 : 9), l2 = std::min(10, T - l1);
+    if (T < shard_bits) T = shard_bits;
+    if (pre) T = std::max(9, T);
+    // 10 bits at level 1 from 2^18 buckets on (single GPU): a third level over half a million tiny segments costs more
+    // than it splits; the senders of a sharded build split by 9 bits, there the third level takes what is left
+    int l1 = pre ? 9 : (T < 9 ? T : (T >= 18 ? 10 : 9)), l2 = std::min(10, T - l1);
     int nb2 = 0, nb3 = (T - l1 - l2) > 0 ? 1 << (T - l1 - l2) : 1;
     const int nb1 = 1 << l1;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
@@ -3568,24 +3597,60 @@ static int build_wsk_t(dbg *h, int k) {
     double est_distinct = 0.0;
     const int top = 6 + SK_BUCKET_BITS;
     Timer t_part(h->stream);
-    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_wg, n_wg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1], top - l1, nb1,
-                                    c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], 0, nullptr, nullptr,
-                                    h->host_seg_cnt.data())));
+    const int bps = pre ? nb1 >> shard_bits : 0;
+    const uint64_t b_lo = pre ? (uint64_t)my_shard * bps : 0;
+    uint64_t *ps_start = nullptr, *ps_cnt = nullptr, *ps_add = nullptr;
+    uint32_t ps_n = 0;
+    if (pre) {
+        ps_n = (uint32_t)(bps * pre->n_senders);
+        std::vector<uint64_t> &hs = h->host_scpre;  // lives in the handle: the upload is asynchronous
+        hs.assign((size_t)ps_n * 3, 0);
+        for (int r = 0; r < pre->n_senders; ++r) {
+            uint64_t at = pre->recv_off[r];
+            for (int b = 0; b < bps; ++b) {
+                const size_t i = (size_t)b * pre->n_senders + r;
+                hs[i] = at;
+                hs[ps_n + i] = pre->counts[(size_t)r * bps + b];
+                hs[2 * (size_t)ps_n + i] = pre->stamp_add[r];
+                at += pre->counts[(size_t)r * bps + b];
+            }
+        }
+        CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)ps_n * 3 * 8));
+        ps_start = (uint64_t *)h->ar_misc[0].p; ps_cnt = ps_start + ps_n; ps_add = ps_cnt + ps_n;
+        HIPCHK(h, hipMemcpyAsync(ps_start, hs.data(), hs.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    } else {
+        CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, in_w0, in_w1, in_st, w0[1], w1[1], st[1], top - l1,
+                                        nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], 0, nullptr, nullptr,
+                                        h->host_seg_cnt.size() == n_seg ? h->host_seg_cnt.data() : nullptr)));
+    }
     if (auto_T && l1 >= 9 && n_rec) {
-        const uint64_t inst_bucket = (uint64_t)((double)n_inst / nb1) * 2 + 1024;
+        const uint64_t inst_bucket = (uint64_t)((double)n_inst * own / nb1) * 2 + 1024;
         uint64_t set_cap = 1024;
         while (set_cap < inst_bucket * 2) set_cap <<= 1;
         CHK(buf_ensure(h, h->ar_misc[8], set_cap * 8));
         HIPCHK(h, hipMemsetAsync(h->ar_misc[8].p, 0xFF, set_cap * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_scalars + 40, 0, 16, h->stream));
-        hipLaunchKernelGGL(k_wsk_estimate, dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt, 0u, w0[1], w1[1], k, pk,
-                           (unsigned long long *)h->ar_misc[8].p, set_cap - 1, (unsigned long long *)(h->d_scalars + 40));
+        if (pre) {
+            for (int r = 0; r < pre->n_senders; ++r)
+                hipLaunchKernelGGL(k_wsk_estimate, dim3(128), dim3(256), 0, h->stream, ps_start, ps_cnt, (uint32_t)r, in_w0, in_w1, k, pk,
+                                   (unsigned long long *)h->ar_misc[8].p, set_cap - 1, (unsigned long long *)(h->d_scalars + 40));
+        } else {
+            hipLaunchKernelGGL(k_wsk_estimate, dim3(512), dim3(256), 0, h->stream, c1_start, c1_cnt, 0u, w0[1], w1[1], k, pk,
+                               (unsigned long long *)h->ar_misc[8].p, set_cap - 1, (unsigned long long *)(h->d_scalars + 40));
+        }
         uint64_t est[2] = {0, 0};
         HIPCHK(h, hipMemcpyAsync(est, h->d_scalars + 40, 16, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
         if (est[0]) {
-            est_distinct = (double)n_inst * (double)est[1] / (double)est[0];
-            const double want = est_distinct / ((double)h->target_distinct > 0 ? (double)h->target_distinct : TARGET_DISTINCT);
+            double distinct = (double)n_inst * own * (double)est[1] / (double)est[0];
+            if (pre) {  // scale the sample by records: the instance total is not known yet
+                uint64_t probe_recs = 0;
+                for (int r = 0; r < pre->n_senders; ++r) probe_recs += pre->counts[(size_t)r * bps];
+                distinct = probe_recs ? (double)est[1] * (double)n_rec / (double)probe_recs * own : 0.0;
+            }
+            est_distinct = distinct / own;
+            const double want = distinct / ((double)h->target_distinct > 0 ? (double)h->target_distinct : TARGET_DISTINCT);
             const double want2 = std::max<double>(1.0, std::ceil(want / nb1));
             if (want2 <= 1024.0) { nb2 = (int)want2; nb3 = 1; }
             else { nb2 = 1024; nb3 = (int)std::min<double>((double)(1 << (SK_BUCKET_BITS - l1 - 10)), std::ceil(want2 / 1024.0)); }
@@ -3593,6 +3658,7 @@ static int build_wsk_t(dbg *h, int k) {
         }
     }
     if (nb2 == 0 && l2 > 0) nb2 = 1 << l2;
+    if (pre && l2 == 0) { l2 = 1; nb2 = 1; }
     if (l2 == 0) nb3 = 1;
     const int fb2 = (nb3 == 1 && ((nb2 > 0 && (nb2 & (nb2 - 1)) != 0) || (auto_T && l1 >= 9 && nb2 > 1))) ? SK_BUCKET_BITS - l1 : 0;
     const uint64_t n_l2 = l2 > 0 ? (uint64_t)nb1 * (uint64_t)nb2 : (uint64_t)nb1;
@@ -3609,12 +3675,24 @@ static int build_wsk_t(dbg *h, int k) {
     }
     if (l2 > 0) {
         const int sh2 = fb2 ? top - SK_BUCKET_BITS : top - l1 - l2_pow;
-        CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, 1, n_rec, w0[1], w1[1], st[1], w0[0], w1[0], st[0], sh2,
-                                        nb2, l2_start, l2_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
+        if (pre) {
+            HIPCHK(h, hipMemsetAsync(b_start, 0, n_buckets * 16, h->stream));
+            if (nb3 > 1) HIPCHK(h, hipMemsetAsync(l2_start, 0, n_l2 * 16, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_scalars + 56, 0, 16, h->stream));
+            CHK((multisplit_level<ST, true, STI>(h, ps_start, ps_cnt, ps_n, (uint32_t)pre->n_senders, n_rec, in_w0, in_w1,
+                                                 (const STI *)pre->in_st, w0[0], w1[0], st[0], sh2, nb2, l2_start + b_lo * nb2,
+                                                 l2_cnt + b_lo * nb2, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2, ps_add,
+                                                 (unsigned long long *)nullptr)));
+        } else {
+            CHK((multisplit_level<ST, true>(h, c1_start, c1_cnt, (uint32_t)nb1, 1, n_rec, w0[1], w1[1], st[1], w0[0], w1[0], st[0], sh2,
+                                            nb2, l2_start, l2_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb2)));
+        }
         where = 0;
         if (nb3 > 1) {
-            CHK((multisplit_level<ST, true>(h, l2_start, l2_cnt, (uint32_t)n_l2, 1, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
-                                            top - SK_BUCKET_BITS, nb3, b_start, b_cnt, h->ar_misc[2], h->ar_misc[3], h->ar_misc[4], fb3)));
+            const uint64_t p_lo = pre ? b_lo * nb2 : 0, p_n = pre ? (uint64_t)bps * nb2 : n_l2;
+            CHK((multisplit_level<ST, true>(h, l2_start + p_lo, l2_cnt + p_lo, (uint32_t)p_n, 1, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
+                                            st[1], top - SK_BUCKET_BITS, nb3, b_start + p_lo * nb3, b_cnt + p_lo * nb3, h->ar_misc[2],
+                                            h->ar_misc[3], h->ar_misc[4], fb3)));
             where = 1;
         }
     } else {
@@ -3623,22 +3701,6 @@ static int build_wsk_t(dbg *h, int k) {
     }
     h->stats.ms_partition = t_part.stop();
     h->stats.n_buckets = n_buckets;
-    // ---- per-bucket counting
-    const uint64_t node_cap_max = std::min<uint64_t>(n_inst, 0xFFFFFFF0ull);
-    const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
-    uint64_t node_cap = node_cap_max;
-    if (est_distinct > 0.0)
-        node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2 * h->est_scale_pct / 100.0) +
-                                                        (h->est_scale_pct == 100 ? (1u << 20) : 1024u));
-    uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
-    uint64_t q_cap = 2 * n_rec + 1024;  // one per record, more where a bucket is counted in hash sub-ranges
-    const uint64_t range_cap = n_buckets + 4096 + n_inst / (WCAP / 4);
-    CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
-    SkRange *ranges = (SkRange *)h->ar_misc[6].p;
-    CHK(buf_ensure(h, h->ar_dir, range_cap * (WCAP / 64) * sizeof(SkDirEnt)));
-    SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
-    uint64_t *q_lo = nullptr, *q_hi = nullptr;
-    uint32_t *q_col = nullptr;
     // the records' bases, aligned, in bucket order (k_wsk_gather)
     CHK(buf_ensure(h, h->ar_wide[2], (n_rec + 1) * 32));
     uint4 *rec_b = (uint4 *)h->ar_wide[2].p;
@@ -3649,6 +3711,32 @@ static int build_wsk_t(dbg *h, int k) {
         HIPCHK(h, hipGetLastError());
         h->stats.ms_compact = t.stop();  // reported in the "compact" slot of dbg_stats_t: this engine has no compaction pass
     }
+    if (pre) {  // the instance totals of what was received: a reduction over the meta words (the senders did not count per owner)
+        uint64_t tot_len = 0, tot_succ = 0;
+        CHK(reduce_sum(h, n_rec, WRecLenAt{w1[where]}, &tot_len));
+        CHK(reduce_sum(h, n_rec, WRecSuccAt{w1[where]}, &tot_succ));
+        n_inst = tot_len;
+        n_edge_inst = tot_len - n_rec + tot_succ;
+        h->n_kmer_inst = n_inst;
+        h->n_edge_inst = n_edge_inst;
+    }
+    // ---- per-bucket counting
+    const uint64_t node_cap_max = std::min<uint64_t>(n_inst, 0xFFFFFFF0ull);
+    const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
+    uint64_t node_cap = node_cap_max;
+    if (est_distinct > 0.0)
+        node_cap = std::min<uint64_t>(node_cap_max, (uint64_t)(est_distinct * 1.2 * h->est_scale_pct / 100.0) +
+                                                        (h->est_scale_pct == 100 ? (1u << 20) : 1024u));
+    uint64_t edge_cap = std::min<uint64_t>(edge_cap_max, node_cap + node_cap / 4 + 16);
+    uint64_t q_cap = 2 * n_rec + 1024;  // one per record, more where a bucket is counted in hash sub-ranges
+    const uint64_t own_cnt = n_buckets >> shard_bits, own_lo = (uint64_t)my_shard * own_cnt;
+    const uint64_t range_cap = n_buckets + 4096 + n_inst / (WCAP / 4);
+    CHK(buf_ensure(h, h->ar_misc[6], range_cap * sizeof(SkRange)));
+    SkRange *ranges = (SkRange *)h->ar_misc[6].p;
+    CHK(buf_ensure(h, h->ar_dir, (own_cnt + (range_cap - n_buckets)) * (WCAP / 64) * sizeof(SkDirEnt)));
+    SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
+    uint64_t *q_lo = nullptr, *q_hi = nullptr;
+    uint32_t *q_col = nullptr;
     for (int attempt = 0; attempt < 3; ++attempt) {
         CHK(buf_ensure(h, h->ar_node[0], node_cap * 8));
         CHK(buf_ensure(h, h->ar_wide[5], node_cap * 8));
@@ -3674,9 +3762,9 @@ static int build_wsk_t(dbg *h, int k) {
         Timer t(h->stream);
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
-        HIPCHK(h, hipMemsetAsync(dirs, 0, n_buckets * (WCAP / 64) * sizeof(SkDirEnt), h->stream));
+        HIPCHK(h, hipMemsetAsync(dirs, 0, own_cnt * (WCAP / 64) * sizeof(SkDirEnt), h->stream));
         WSkCountOut out{h->d_keys, h->d_keys_hi, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
-                        q_lo, q_hi, q_col, q_cap, ranges, n_buckets, range_cap, dirs, 0, n_buckets, sc_dev};
+                        q_lo, q_hi, q_col, q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, sc_dev};
         auto kern = k_wsk_count<ST>;
         const size_t lds = sizeof(WCntLds<ST>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3713,12 +3801,12 @@ static int build_wsk_t(dbg *h, int k) {
     h->dense_pending = true;
     const uint64_t n_q = sc[5], n_ranges = n_buckets + sc[6];
     h->stats.n_queries = n_q;
-    SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, nb3, fb3, 0, 0, 0, n_buckets};
+    SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, nb3, fb3, shard_bits, my_shard, own_lo, own_cnt};
     {
         Timer t(h->stream);
         if (n_q) {
             hipLaunchKernelGGL(k_wsucc_resolve, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, q_lo, q_hi, q_col, n_q, geom, ranges,
-                               n_buckets, n_ranges, dirs, h->d_keys, h->d_keys_hi, h->n_nodes, h->d_col, sc_dev);
+                               n_buckets, n_ranges, dirs, h->d_keys, h->d_keys_hi, h->n_nodes, h->d_col, shard_bits ? 1 : 0, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -3726,8 +3814,20 @@ static int build_wsk_t(dbg *h, int k) {
         }
         h->stats.ms_succ = t.stop();
     }
+    h->sk_geom = geom; h->sk_n_buckets = n_buckets; h->sk_n_ranges = n_ranges; h->sk_cap = WCAP;
     h->sk_src.valid = false;  // the per-range kernels of dbg_refine_edge_order / dbg_mark_pull_reads read one-word records
+    (void)w;
     return DBG_OK;
+}
+
+template <class ST>
+static int build_wsk_t(dbg *h, int k) {
+    uint64_t *pk = nullptr, *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
+    ST *st[2];
+    uint32_t n_seg = 0;
+    CHK(wsk_extract<ST>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    return wsk_count<ST, ST>(h, k, pk, seg_start, seg_cnt, n_seg, n_rec, h->n_kmer_inst, h->n_edge_inst, w0[0], w1[0], st[0], w0, w1, st,
+                             0, 0, nullptr);
 }
 
 // 32-bit stamps only (reads below 2 GiB: with 64-bit stamps the 4096-slot table does not fit the LDS); larger inputs and
@@ -3952,13 +4052,125 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
     return DBG_OK;
 }
 
+// ---- two-word k-mers, sharded, on the LDS engine: the unit on the wire is the super-k-mer record BY VALUE -- its bases
+//      (k_wsk_gather: four aligned words), meta word and rank-local stamp, 44 bytes for ~26 k-mer instances at k = 63
+//      (the instance tuples of shard_extract_wide are 24 bytes each).  The receiver takes the received bases as its
+//      packed reads: record i sits at base position 128 i.
+static int shard_extract_wsk(dbg *h, int k, int n_shards, uint64_t *send_counts, const void **d_rb, const void **d_w1,
+                             const void **d_st) {
+    free_build(h);
+    h->stats = dbg_stats_t{};
+    CHK(compute_alphabet(h));
+    if (!h->is_dna) { h->err = "sharded builds take ACGT reads"; return DBG_E_ALPHABET; }
+    uint64_t *pk = nullptr, *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
+    uint32_t *st[2];
+    uint32_t n_seg = 0;
+    CHK(wsk_extract<uint32_t>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    const int nb1 = 512;
+    CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+    uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
+    Timer t(h->stream);
+    CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+                                          6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3],
+                                          h->ar_misc[4], 0, nullptr, nullptr, h->host_seg_cnt.data())));
+    std::vector<uint64_t> cnt(nb1);
+    HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
+    CHK(buf_ensure(h, h->ar_wide[2], (n_rec + 1) * 32));
+    uint4 *rec_b = (uint4 *)h->ar_wide[2].p;
+    if (n_rec)
+        hipLaunchKernelGGL(k_wsk_gather, dim3(grid_for(n_rec, 256)), dim3(256), 0, h->stream, w0[1], w1[1], n_rec, pk, k, rec_b);
+    HIPCHK(h, hipGetLastError());
+    h->stats.ms_partition = t.stop();
+    for (int d = 0; d < n_shards; ++d) {
+        send_counts[d] = 0;
+        for (int b = d * nb1 / n_shards; b < (d + 1) * nb1 / n_shards; ++b) send_counts[d] += cnt[b];
+    }
+    *d_rb = rec_b;
+    *d_w1 = w1[1];
+    *d_st = st[1];
+    ShardState &sh = shard_of(h);
+    sh.n_shards = n_shards;
+    sh.k = k;
+    sh.n_kmer_inst_local = h->n_kmer_inst;
+    sh.l1_counts = cnt;
+    sh.rec_words = 4;
+    sh.rec_stamp_bytes = 4;
+    return DBG_OK;
+}
+
+static int shard_build_wsk(dbg *h, int k, int n_shards, int my_shard, const uint64_t *d_rb, const uint64_t *d_w1,
+                           const uint32_t *d_st32, const uint64_t *recv_counts, const uint64_t *stamp_base,
+                           const uint64_t *sender_bucket_counts, uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys) {
+    int shard_bits = 0;
+    while ((1 << shard_bits) < n_shards) ++shard_bits;
+    uint64_t n_rec = 0;
+    std::vector<uint64_t> seg(n_shards), add(n_shards);
+    const int bps = 512 >> shard_bits;
+    for (int r = 0; r < n_shards; ++r) {
+        seg[r] = n_rec;
+        n_rec += recv_counts[r];
+        add[r] = stamp_base[r] << 1;
+        uint64_t tot = 0;
+        for (int b = 0; b < bps; ++b) tot += sender_bucket_counts[(size_t)r * bps + b];
+        if (tot != recv_counts[r]) { h->err = "sender_bucket_counts do not add up to recv_counts"; return DBG_E_ARG; }
+    }
+    free_build(h);
+    uint64_t *w0[2], *w1[2], *st[2];
+    for (int set = 0; set < 2; ++set) {
+        CHK(buf_ensure(h, h->ar_rec[set][0], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_rec[set][1], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_rec[set][2], (n_rec + 16) * 8));
+        w0[set] = (uint64_t *)h->ar_rec[set][0].p;
+        w1[set] = (uint64_t *)h->ar_rec[set][1].p;
+        st[set] = (uint64_t *)h->ar_rec[set][2].p;
+    }
+    CHK(buf_ensure(h, h->ar_shard[2], (n_rec + 16) * 8));
+    uint64_t *in_w0 = (uint64_t *)h->ar_shard[2].p;
+    if (n_rec) hipLaunchKernelGGL(k_wsk_iota128, dim3(grid_for(n_rec, 256)), dim3(256), 0, h->stream, n_rec, in_w0);
+    h->k = k;
+    h->stats.n_records = n_rec;
+    ShardState &sh = shard_of(h);
+    sh.n_shards = n_shards; sh.my_shard = my_shard; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
+    sh.q_start.assign(n_shards, 0);
+    sh.q_cnt.assign(n_shards, 0);
+    Presplit pre;
+    pre.n_senders = n_shards;
+    pre.counts = sender_bucket_counts;
+    pre.recv_off = seg.data();
+    pre.stamp_add = add.data();
+    pre.in_st = d_st32;
+    const int w = k - SK_MAX_M + 1;
+    Timer t_total(h->stream);
+    int rc = wsk_count<uint64_t, uint32_t>(h, k, d_rb, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w, n_rec * (uint64_t)w, in_w0, d_w1,
+                                           (const uint64_t *)nullptr, w0, w1, st, shard_bits, my_shard, &pre);
+    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+    for (int d = 0; d < n_shards; ++d) { q_starts[d] = 0; q_counts[d] = 0; }
+    *d_q_keys = nullptr;
+    h->partial_graph = n_shards > 1;
+    h->stats.ms_build_total = t_total.stop();
+    return DBG_OK;
+}
+
+extern "C" int dbg_shard_record_layout(dbg_t *h, int *w0_words, int *stamp_bytes) {
+    if (!h || !h->shard_state) { if (h) h->err = "dbg_shard_extract must run first"; return DBG_E_ARG; }
+    ShardState &sh = shard_of(h);
+    if (w0_words) *w0_words = sh.rec_words;
+    if (stamp_bytes) *stamp_bytes = sh.rec_stamp_bytes;
+    return DBG_OK;
+}
+
 extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0,
                                  const void **d_w1, const void **d_st) {
     CHK(shard_args_ok(h, k, n_shards));
     if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
     if (h->n_bytes >= (1ull << 31)) { h->err = "a shard's reads must stay below 2 GiB (32-bit local stamps)"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
-    if (k > 31) return shard_extract_wide(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
+    if (k > 31) {
+        if (h->wide_engine == 1) return shard_extract_wsk(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
+        int rcw = shard_extract_wide(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
+        if (rcw == DBG_OK) { shard_of(h).rec_words = 1; shard_of(h).rec_stamp_bytes = 8; }
+        return rcw;
+    }
     free_build(h);
     h->stats = dbg_stats_t{};
     uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
@@ -3988,6 +4200,8 @@ extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_c
     sh.k = k;
     sh.n_kmer_inst_local = h->n_kmer_inst;
     sh.l1_counts = cnt;
+    sh.rec_words = 1;
+    sh.rec_stamp_bytes = 4;
     return DBG_OK;
 }
 
@@ -4007,9 +4221,13 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
     if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !q_starts || !q_counts || !d_q_keys)
         return DBG_E_ARG;
     HIPCHK(h, hipSetDevice(h->device));
-    if (k > 31)
+    if (k > 31) {
+        if (h->wide_engine == 1 && sender_bucket_counts)
+            return shard_build_wsk(h, k, n_shards, my_shard, (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint32_t *)d_st32,
+                                   recv_counts, stamp_base, sender_bucket_counts, q_starts, q_counts, d_q_keys);
         return shard_build_wide(h, k, n_shards, my_shard, (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)d_st32,
                                 recv_counts, stamp_base, q_starts, q_counts, d_q_keys);
+    }
     int shard_bits = 0;
     while ((1 << shard_bits) < n_shards) ++shard_bits;
     uint64_t n_rec = 0;
@@ -4176,7 +4394,7 @@ extern "C" int dbg_import_graph(dbg_t *h, int k, int n_shards, const uint64_t *s
     uint64_t base[8] = {0}, n = 0;
     for (int s = 0; s < n_shards; ++s) {
         base[s] = n;
-        if (shard_nodes[s] >= (1ull << 29)) { h->err = "a shard holds at most 2^29 nodes"; return DBG_E_ARG; }
+        if (k <= 31 && shard_nodes[s] >= (1ull << 29)) { h->err = "a shard holds at most 2^29 nodes"; return DBG_E_ARG; }
         n += shard_nodes[s];
     }
     if (n >= 0xFFFFFFF0ull) { h->err = "more than 2^32-16 nodes"; return DBG_E_CAPACITY; }

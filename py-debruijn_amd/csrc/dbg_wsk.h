@@ -290,19 +290,26 @@ __global__ __launch_bounds__(256) void k_wsk_gather(const uint64_t *__restrict__
 #define DBG_WCNT_NT 1024
 #endif
 constexpr int WCNT_NT = DBG_WCNT_NT;
-constexpr int WCNT_STAGE = 288;      // records staged per round (a bucket holds 140 +- 64 at the default geometry: a second round
-                                     // pays the dedupe / quad list / insert barriers again and loads its records unprefetched)
-constexpr int WCNT_QMAX = 13;        // quads of 4 k-mers per record: ceil(51 / 4)
+// Staging sizes by stamp type.  32-bit stamps (a single GPU's reads below 2 GiB): 288 records per round -- a bucket holds
+// 140 +- 64 at the default geometry, and a second round pays the dedupe / quad list / insert barriers again.  64-bit
+// stamps (sharded builds: global positions): the stamp array takes 16 KB more of the 160, so 128 records and fewer
+// staged queries.
+template <class ST>
+struct WCntCfg {
+    static constexpr int STAGE = sizeof(ST) == 8 ? 128 : 288;
 #ifdef DBG_CNT_PROF
-constexpr int WCNT_QBUF = 256;       // (room for the clocks of the experiment build)
+    static constexpr int QBUF = sizeof(ST) == 8 ? 128 : 256;  // (room for the clocks of the experiment build)
 #else
-constexpr int WCNT_QBUF = 320;       // cross-bucket successor queries staged per bucket
+    static constexpr int QBUF = sizeof(ST) == 8 ? 160 : 320;  // cross-bucket successor queries staged per bucket
 #endif
-constexpr int WCNT_DD = 1024;        // dedupe set slots (>= 2 * WCNT_STAGE)
+    static constexpr int DD = sizeof(ST) == 8 ? 256 : 1024;    // dedupe set slots (>= 2 * STAGE)
+};
+constexpr int WCNT_QMAX = 13;        // quads of 4 k-mers per record: ceil(51 / 4)
 constexpr unsigned long long W_PEND = 1ull << 63;
 
 template <class ST>
 struct WCntLds {
+    static constexpr int WCNT_STAGE = WCntCfg<ST>::STAGE, WCNT_QBUF = WCntCfg<ST>::QBUF, WCNT_DD = WCntCfg<ST>::DD;
     unsigned long long khi[WCAP];   // EMPTY_KEY / hi | W_PEND / hi   (hi < 2^62)
     unsigned long long klo[WCAP];
     uint32_t cnt2[WCAP * 2];        // four 16-bit successor counters per slot: codes 0, 1 in dword 0; 2, 3 in dword 1
@@ -369,6 +376,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
     extern __shared__ __attribute__((aligned(16))) unsigned char wcnt_raw[];
     WCntLds<ST> &s = *reinterpret_cast<WCntLds<ST> *>(wcnt_raw);
     constexpr int NPT = WCAP / WCNT_NT;
+    constexpr int WCNT_STAGE = WCntCfg<ST>::STAGE, WCNT_QBUF = WCntCfg<ST>::QBUF, WCNT_DD = WCntCfg<ST>::DD;
     static_assert(WCNT_DD >= 2 * WCNT_STAGE && WCNT_STAGE <= WCNT_NT, "staging");
     static_assert(sizeof(WCntLds<ST>) <= 160 * 1024, "LDS");
     bool clean = false;
@@ -811,6 +819,7 @@ __global__ __launch_bounds__(256) void k_wsucc_resolve(const uint64_t *__restric
                                                        const SkRange *__restrict__ ranges, uint64_t n_buckets, uint64_t n_ranges,
                                                        const SkDirEnt *__restrict__ dirs, const uint64_t *__restrict__ keys,
                                                        const uint64_t *__restrict__ keys_hi, uint64_t n_nodes, uint32_t *out,
+                                                       int allow_foreign /* a shard: successors owned elsewhere stay unresolved */,
                                                        unsigned long long *scalars) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -833,8 +842,11 @@ __global__ __launch_bounds__(256) void k_wsucc_resolve(const uint64_t *__restric
             if (have) id = wdir_find(dirs, g.own_cnt + (ri - n_buckets), keys, keys_hi, n_nodes, key);
         }
     }
+    else if (allow_foreign) return;
     if (id == NO_NODE) { atomicOr(&scalars[0], 128ull); return; }
     out[q_col ? q_col[i] : i] = id;
 }
+
+static_assert(sizeof(WCntLds<uint64_t>) <= 160 * 1024 && sizeof(WCntLds<uint32_t>) <= 160 * 1024, "LDS of the two-word count kernel");
 
 }  // namespace dbgk

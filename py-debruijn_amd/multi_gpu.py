@@ -175,12 +175,16 @@ def sharded_build(g, k, dist, check=True):
     xc = ExchangeCheck(dist) if check else _NoCheck(dist)
     send_counts, (w0, w1, st) = g.shard_extract(k, w)
     device = w0.device
+    # words per record in the first array: 1, or 4 where the records of two-word k-mers travel by value (their bases)
+    words = g.shard_record_layout()[0] if hasattr(g, "shard_record_layout") else 1
     # one small all-gather carries everything the ranks need to know about each other: the bytes of reads every rank
-    # holds (stamp bases) and, for k <= 31, how its records split over the 512 level-1 buckets -- the receive counts are
-    # sums of those, and the owner can start its build at the second multisplit level
-    presplit = k <= 31 and hasattr(g, "shard_bucket_counts")
-    meta = [g.sizes()["n_bytes"]] + (g.shard_bucket_counts() if presplit else list(send_counts))
+    # holds (stamp bases), the record layout (all ranks must agree) and how its records split over the 512 level-1
+    # buckets -- the receive counts are sums of those, and the owner can start its build at the second multisplit level
+    presplit = hasattr(g, "shard_bucket_counts") and (k <= 31 or words == 4)
+    meta = [g.sizes()["n_bytes"], words] + (g.shard_bucket_counts() if presplit else list(send_counts))
     metas = _all_gather_ints(dist, meta, device)
+    if any(m_r[1] != words for m_r in metas):
+        raise RuntimeError("sharded build: the ranks disagree about the record layout (different engines or input sizes)")
     bases, acc = [], 0
     for m_r in metas:
         bases.append(acc)
@@ -188,11 +192,11 @@ def sharded_build(g, k, dist, check=True):
     sender_buckets = None
     if presplit:
         bps = 512 // w
-        sender_buckets = [m_r[1 + me * bps: 1 + (me + 1) * bps] for m_r in metas]
+        sender_buckets = [m_r[2 + me * bps: 2 + (me + 1) * bps] for m_r in metas]
         recv_counts = [sum(row) for row in sender_buckets]
     else:
-        recv_counts = [m_r[1 + me] for m_r in metas]
-    r_w0 = xc.alltoallv(w0, send_counts, recv_counts, "records w0")
+        recv_counts = [m_r[2 + me] for m_r in metas]
+    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0")
     r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1")
     r_st = xc.alltoallv(st, send_counts, recv_counts, "records st")
     xc.verify()  # before anything is built from them
@@ -206,7 +210,10 @@ def sharded_build(g, k, dist, check=True):
     # successors owned by other shards: keys out, node ids back.  The library lists the queries
     # grouped by owner with its own group in between: pack the remote groups for the wire.
     q_recv = exchange_counts(dist, q_counts, device)
-    if sum(q_counts) + sum(q_recv):
+    # every rank must take the same branch (the exchange below is collective): decide on the total over all ranks
+    total_q = torch.tensor([sum(q_counts)], dtype=torch.int64, device="cpu" if _is_gloo(dist) else device)
+    dist.all_reduce(total_q, op=dist.ReduceOp.SUM)
+    if int(total_q.item()):
         groups = [q_keys[s:s + c] for s, c in zip(q_starts, q_counts)]
         packed = torch.cat(groups) if groups else q_keys[:0]
         keys_in = xc.alltoallv(packed, q_counts, q_recv, "successor queries")

@@ -17,7 +17,7 @@ import multi_gpu as mg
 
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
-n, k = int(float(os.environ.get("READS", "10")) * 1e6), 31
+n, k = int(float(os.environ.get("READS", "10")) * 1e6), int(os.environ.get("K", "31"))
 g = _dbg.Graph(device=0)
 g.synth_reads(1, n * 5, n, 150, 0.01)
 for it in range(3):
@@ -30,19 +30,20 @@ for it in range(3):
     t0 = time.perf_counter(); send_counts, (w0, w1, st) = g.shard_extract(k, w); lap("shard_extract", t0)
     device = w0.device
     t0 = time.perf_counter()
-    metas = mg._all_gather_ints(dist, [g.sizes()["n_bytes"]] + g.shard_bucket_counts(), device)
+    words = g.shard_record_layout()[0]
+    metas = mg._all_gather_ints(dist, [g.sizes()["n_bytes"], words] + g.shard_bucket_counts(), device)
     bases = [0]
-    sender_buckets = [m_r[1:513] for m_r in metas]
+    sender_buckets = [m_r[2:514] for m_r in metas]
     recv_counts = [sum(row) for row in sender_buckets]
     lap("meta_all_gather", t0)
     xc = mg.ExchangeCheck(dist) if os.environ.get("CHECK", "1") == "1" else mg._NoCheck(dist)
     t0 = time.perf_counter()
-    r_w0 = xc.alltoallv(w0, send_counts, recv_counts, "w0"); r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "w1")
+    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "w0"); r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "w1")
     r_st = xc.alltoallv(st, send_counts, recv_counts, "st"); xc.verify(); lap("alltoallv_records(+digests)", t0)
     pre = sender_buckets if os.environ.get("PRESPLIT", "1") == "1" else None
     t0 = time.perf_counter(); q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases, pre); lap("shard_build", t0)
     st_ = g.stats()
-    T["  build phases"] = {x: round(st_[x], 2) for x in ("ms_partition", "ms_count", "ms_succ", "ms_build_total")}
+    T["  build phases"] = {x: round(st_[x], 2) for x in ("ms_partition", "ms_compact", "ms_count", "ms_succ", "ms_build_total")}
     t0 = time.perf_counter(); q_recv = mg.exchange_counts(dist, q_counts, device)
     groups = [q_keys[s:s + c] for s, c in zip(q_starts, q_counts)]
     packed = torch.cat(groups) if groups else q_keys[:0]
