@@ -2960,8 +2960,8 @@ extern "C" int dbg_debug_ms_prof(unsigned long long *out8, int reset) {  // expe
 
 #ifdef DBG_CNT_PROF
 extern "C" int dbg_debug_cnt_prof(unsigned long long *out32, int reset) {  // experiment builds only (tools/cnt_prof.py)
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(dbgk::g_cnt_prof), 256) != hipSuccess) return DBG_E_HIP;
-    if (reset) { unsigned long long z[32] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dbgk::g_cnt_prof), z, 256) != hipSuccess) return DBG_E_HIP; }
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(dbgk::g_cnt_prof), 512) != hipSuccess) return DBG_E_HIP;
+    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(dbgk::g_cnt_prof), z, 512) != hipSuccess) return DBG_E_HIP; }
     return DBG_OK;
 }
 #endif
@@ -3512,7 +3512,8 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
     if (pk_words)
         hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, pk_words, pk);
     const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
-    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 1024);
+    const bool reg_kernel = (w == 51);  // k = 63: the register kernel (256 threads, several workgroups per CU)
+    const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), reg_kernel ? 2048 : 1024);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
     uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg, *seg_ne = seg_nk + n_wg;
     std::vector<uint64_t> hseg((size_t)n_wg * 4);
@@ -3535,7 +3536,10 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
         HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
-        if (tiles) {
+        if (tiles && reg_kernel) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wsk_extract_w<ST, 51>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
+                               h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
+        } else if (tiles) {
             auto ekern = k_wsk_extract<ST>;
             HIPCHK(h, hipFuncSetAttribute((const void *)ekern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WSkLds)));
             hipLaunchKernelGGL(ekern, dim3(n_wg), dim3(WSK_NT), sizeof(WSkLds), h->stream, h->d_bases, h->n_bytes,
@@ -3577,7 +3581,11 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
     uint64_t sc[8] = {0};
     const double own = shard_bits ? (double)(1 << shard_bits) : 1.0;
     // ---- bucket geometry
-    constexpr double TARGET_DISTINCT = WCAP * 0.36;
+    // mean distinct k-mers per final bucket.  Lower than the one-word engine's 0.36 * slots: one minimizer occurrence brings
+    // ~320 nodes at k = 63, so bucket sizes vary like a Poisson count of a handful of loci, and a bucket that outgrows the
+    // table is counted in hash sub-ranges (measured, 10 M x 150 bp: k = 63 30.2 / 30.5 / 31.0 / 32.9 / 35.5 ms of count
+    // kernel at 1100 / 900 / 1000 / 1475 / 1700; k = 47 and k = 32 best at 1000 as well)
+    constexpr double TARGET_DISTINCT = 1000.0;
     int T = h->bucket_bits;
     const bool auto_T = (T == 0);
     if (auto_T) {

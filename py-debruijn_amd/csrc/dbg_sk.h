@@ -701,7 +701,7 @@ struct CntLds {
     unsigned long long dir_mask[CAP / 64];  // occupancy of every 64-slot block of the final table
     uint16_t dir_base[CAP / 64];            // local node index of the block's first node
 #ifdef DBG_CNT_PROF
-    unsigned long long prof[32];
+    unsigned long long prof[64];
 #endif
 };
 
@@ -805,10 +805,12 @@ __device__ inline uint32_t wave_alloc_n(uint32_t *counter, uint32_t n) {
 }
 
 #ifdef DBG_CNT_PROF
-__device__ unsigned long long g_cnt_prof[32];
+__device__ unsigned long long g_cnt_prof[64];
 #define CNT_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); s.prof[i] += now_ - clast_; clast_ = now_; } } while (0)
 #define CNT_SUBTICK(i) do { if (threadIdx.x == 0) { const unsigned long long now_ = clock64(); s.prof[i] += now_ - csub_; csub_ = now_; } } while (0)
+#define CNT_EVENT(i) do { if (threadIdx.x == 0) s.prof[i] += 1; } while (0)
 #else
+#define CNT_EVENT(i) do {} while (0)
 #define CNT_TICK(i) do {} while (0)
 #define CNT_SUBTICK(i) do {} while (0)
 #endif
@@ -844,7 +846,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
 
 #ifdef DBG_CNT_PROF
     unsigned long long clast_ = clock64(), csub_ = clast_;
-    if (threadIdx.x < 32) s.prof[threadIdx.x] = 0;
+    if (threadIdx.x < 64) s.prof[threadIdx.x] = 0;
     __syncthreads();
 #endif
     bool clean = false;  // uniform: every slot of the table is EMPTY / zero / max

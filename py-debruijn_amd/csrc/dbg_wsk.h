@@ -257,6 +257,169 @@ __global__ __launch_bounds__(256) void k_wsk_estimate(const uint64_t *__restrict
     }
 }
 
+// Fast extraction for a compile-time window W = k - 12 (k = 63 -> W = 51, the width BASELINE.json configs[4] names):
+// the register scheme of k_sk_extract_w (dbg_sk.h).  Every lane owns 32 consecutive positions, reads 96 bases and 96
+// read-start bits once, rolls the 32 + W - 1 m-mer hashes it needs in registers and takes the window minimum by the van
+// Herk / Gil-Werman block scheme -- about 3 min operations per position and three barriers less per tile than the
+// doubling table of k_wsk_extract, which stays for the other widths.  Same hash, same leftmost tie-break
+// (packed = hash16 << 8 | offset), same records.
+struct WSkLdsW {
+    TileLdsW t;
+    uint8_t minp[TILE];
+    unsigned long long sbits[TILE / 64 + 1];
+    unsigned long long vbits[TILE / 64 + 1];
+    uint32_t wpre[TILE / 64 + 1];
+    uint16_t list[TILE];
+    uint8_t edge[256];
+    uint32_t nrec;
+};
+
+template <class ST, int W>
+__global__ __launch_bounds__(256, 2) void k_wsk_extract_w(const char *__restrict__ bases, uint64_t n_bytes,
+                                                          const uint32_t *__restrict__ startbits, uint64_t n_tiles,
+                                                          uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
+                                                          uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
+                                                          unsigned long long *scalars /* [0] err */) {
+    constexpr int M = SK_MAX_M, K = W + M - 1, NV = 32 + W - 1;
+    static_assert(TILE == 256 * 32, "one lane per 32 positions");
+    static_assert(K >= 32 && K <= 63 && NV + M - 1 <= 96 && 32 + K <= 96 && WSK_HALO >= 96, "window must fit three 32-base registers");
+    __shared__ WSkLdsW s;
+    __shared__ uint64_t red[8];
+    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
+    uint64_t cursor = 0;
+    constexpr uint64_t mid_mask = (1ull << (K - 1)) - 1ull;
+    uint64_t n_k = 0, n_e = 0;
+    bool overflow = false;
+    const int j0 = threadIdx.x * 32;
+    for (uint64_t tile = t_beg; tile < t_end; ++tile) {
+        const uint64_t tile0 = tile * TILE;
+        __syncthreads();
+        const uint32_t bad = load_tile(s.t, bases, n_bytes, startbits, tile0);
+        if (bad) atomicOr(&scalars[0], 1ull);
+        __syncthreads();
+        // ---- register phase
+        const uint64_t wv[4] = {window32(s.t, j0), window32(s.t, j0 + 32), window32(s.t, j0 + 64), 0};
+        uint32_t pv[NV], P[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int wi = i >> 5, sh = 2 * (i & 31);
+            const uint64_t win = (sh == 0) ? wv[wi] : (wi < 2) ? ((wv[wi] << sh) | (wv[wi + 1] >> (64 - sh))) : (wv[wi] << sh);
+            pv[i] = (mmer_hash16((uint32_t)(win >> (64 - 2 * M))) << 8) | (uint32_t)i;
+            P[i] = (i % W == 0) ? pv[i] : min(P[i - 1], pv[i]);
+        }
+        const uint64_t sb_lo = ((uint64_t)s.t.sb[(j0 >> 5) + 1] << 32) | s.t.sb[j0 >> 5];
+        const uint64_t sb_hi = s.t.sb[(j0 >> 5) + 2];
+        uint32_t vmask = 0, skmask = 0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const uint64_t sw = q ? (sb_lo >> q) | (sb_hi << (64 - q)) : sb_lo;  // start bits of positions j0 + q ...
+            const uint32_t s0 = (uint32_t)(sw & 1ull), sk = (uint32_t)(sw >> K) & 1u;
+            const bool v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0) && (tile0 + j0 + q + (uint64_t)K <= n_bytes);
+            vmask |= (uint32_t)v << q;
+            skmask |= sk << q;
+        }
+        n_k += __popc(vmask);
+        n_e += __popc(vmask & ~skmask);
+        uint32_t off[32];
+        {
+            uint32_t S = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = NV - 1; i >= 0; --i) {
+                S = (i % W == W - 1 || i == NV - 1) ? pv[i] : min(S, pv[i]);
+                if (i < 32) {
+                    const uint32_t mn = (i % W == 0) ? P[i + W - 1] : min(S, P[i + W - 1]);
+                    off[i] = ((vmask >> i) & 1u) ? ((mn & 0xFFu) - (uint32_t)i) : 0xFFu;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 32; q += 4)
+            reinterpret_cast<uint32_t *>(s.minp)[(j0 + q) >> 2] = off[q] | (off[q + 1] << 8) | (off[q + 2] << 16) | (off[q + 3] << 24);
+        s.edge[threadIdx.x] = (uint8_t)off[31];
+        reinterpret_cast<uint32_t *>(s.vbits)[threadIdx.x] = vmask;
+        __syncthreads();
+        uint32_t smask = 0;
+        {
+            uint32_t prev = threadIdx.x ? (uint32_t)s.edge[threadIdx.x - 1] : 0xFFu;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const bool st = (off[q] != 0xFFu) && (prev == 0xFFu || prev != off[q] + 1);
+                smask |= (uint32_t)st << q;
+                prev = off[q];
+            }
+            reinterpret_cast<uint32_t *>(s.sbits)[threadIdx.x] = smask;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            uint32_t a = __popcll(s.sbits[threadIdx.x]), b = __popcll(s.sbits[threadIdx.x + 64]);
+            uint32_t ia = a, ib = b;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t oa = __shfl_up(ia, d, 64), ob = __shfl_up(ib, d, 64);
+                if ((int)threadIdx.x >= d) { ia += oa; ib += ob; }
+            }
+            const uint32_t tot_a = __shfl(ia, 63, 64);
+            s.wpre[threadIdx.x] = ia - a;
+            s.wpre[threadIdx.x + 64] = tot_a + ib - b;
+            if (threadIdx.x == 63) s.nrec = tot_a + ib;
+            if (threadIdx.x == 0) { s.sbits[TILE / 64] = 0; s.vbits[TILE / 64] = 0; }
+        }
+        __syncthreads();
+        const uint32_t nrec = s.nrec;
+        if (cursor + nrec > seg_cap) { overflow = true; break; }
+        const uint64_t gbase = seg0 + cursor;
+        cursor += nrec;
+        {
+            uint32_t sm = smask;
+            uint32_t li = s.wpre[threadIdx.x >> 1] + ((threadIdx.x & 1) ? __popc((uint32_t)s.sbits[threadIdx.x >> 1]) : 0);
+            while (sm) {
+                const int q = __ffs(sm) - 1;
+                sm &= sm - 1;
+                s.list[li++] = (uint16_t)(j0 + q);
+            }
+        }
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < nrec; r += 256) {
+            const int j = s.list[r];
+            const int wd = j >> 6, bt = j & 63;
+            const unsigned long long sb = s.sbits[wd];
+            const unsigned long long nxt_s = (bt == 63) ? 0ull : (sb >> (bt + 1));
+            const unsigned long long nxt_i = (bt == 63) ? 0ull : ((~s.vbits[wd]) >> (bt + 1));
+            const int room = 63 - bt;
+            const unsigned long long stop = nxt_s | nxt_i;
+            int len;
+            if (stop) {
+                len = 1 + (__ffsll((unsigned long long)stop) - 1);
+            } else {
+                const unsigned long long stop2 = s.sbits[wd + 1] | ~s.vbits[wd + 1];
+                len = 1 + room + (__ffsll((unsigned long long)stop2) - 1);
+            }
+            if (j + len > TILE) len = TILE - j;
+            const uint64_t p = tile0 + j;
+            const uint32_t s0 = (uint32_t)(startwin64(s.t, j) & 1ull);
+            const uint32_t sk_last = (uint32_t)(startwin64(s.t, j + len - 1) >> K) & 1u;
+            const uint32_t has_succ = sk_last ^ 1u;
+            const uint32_t mp = j + s.minp[j];
+            const uint32_t bh = bucket_hash22((uint32_t)(window32(s.t, mp) >> (64 - 2 * M)));
+            const uint64_t o = gbase + r;
+            rec_w0[o] = p;
+            rec_w1[o] = ((uint64_t)(len - 1) << SK_META_BITS) | ((uint64_t)bh << 6) | has_succ;
+            rec_st[o] = (ST)((p << 1) | (s0 ^ 1u));
+        }
+    }
+    if (overflow && threadIdx.x == 0) atomicOr(&scalars[0], 4ull);
+    n_k = wave_sum_u64(n_k);
+    n_e = wave_sum_u64(n_e);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = n_k; red[4 + (threadIdx.x >> 6)] = n_e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        seg_cnt[blockIdx.x] = cursor;
+        seg_nk[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        seg_ne[blockIdx.x] = red[4] + red[5] + red[6] + red[7];
+    }
+}
+
 // The bases of every record, aligned (first base in bits 63:62 of word 0) and zero beyond the record, in record
 // (= bucket) order: one pass of independent 40-byte reads of the packed reads at full occupancy.  Read inside the count
 // kernel, where a bucket's ~140 records are all a workgroup has in flight, the same reads were a dependent round trip
@@ -331,7 +494,7 @@ struct WCntLds {
     unsigned long long dir_mask[WCAP / 64];
     uint16_t dir_base[WCAP / 64];
 #ifdef DBG_CNT_PROF
-    unsigned long long prof[32];
+    unsigned long long prof[64];
 #endif
 };
 
@@ -355,6 +518,18 @@ struct WSkCountOut {
 __device__ inline void wcnt_load(const uint32_t *cnt2, uint32_t slot, uint32_t c[4]) {
     const uint2 v = reinterpret_cast<const uint2 *>(cnt2)[slot];
     c[0] = v.x & 0xFFFFu; c[1] = v.x >> 16; c[2] = v.y & 0xFFFFu; c[3] = v.y >> 16;
+}
+
+// LDS accesses of the claim protocol: relaxed workgroup-scope atomics (plain ds_read / ds_write, never cached in a
+// register) with a compiler-only fence after each -- the hardware order is the issue order, see the insert loop of k_wsk_count
+__device__ inline void wlds_store(unsigned long long *p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+}
+__device__ inline unsigned long long wlds_load(const unsigned long long *p) {
+    const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    return v;
 }
 
 __device__ inline int wlds_find(const unsigned long long *khi, const unsigned long long *klo, K128 key) {
@@ -383,7 +558,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
     if (threadIdx.x == 0) s.fail = 0;
 #ifdef DBG_CNT_PROF
     unsigned long long clast_ = clock64();
-    if (threadIdx.x < 32) s.prof[threadIdx.x] = 0;
+    if (threadIdx.x < 64) s.prof[threadIdx.x] = 0;
     __syncthreads();
 #endif
     // The next bucket's records are fetched into registers while this bucket is in its later phases, its record range
@@ -407,12 +582,32 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
         }
         load_range(b + gridDim.x, r2_beg, r2_n);
     };
+    // The first round of the NEXT bucket goes from the prefetch registers into the staging arrays at the start of this
+    // bucket's node write (the arrays are idle after the insert): staged at the top of the next bucket, the wait for the
+    // registers also waited for every global store of the node write before it (one counter for loads and stores).
+    auto stage_regs = [&](uint32_t n_st) {
+        if (threadIdx.x == 0) s.n_flat = 0;
+        if (threadIdx.x < n_st) {
+            s.rb[threadIdx.x][0] = ((unsigned long long)pf_b0.y << 32) | pf_b0.x;
+            s.rb[threadIdx.x][1] = ((unsigned long long)pf_b0.w << 32) | pf_b0.z;
+            s.rb[threadIdx.x][2] = ((unsigned long long)pf_b1.y << 32) | pf_b1.x;
+            s.rb[threadIdx.x][3] = ((unsigned long long)pf_b1.w << 32) | pf_b1.z;
+            s.rmeta[threadIdx.x] = pf_w1;
+            s.rst[threadIdx.x] = pf_st;
+            s.dd_mult[threadIdx.x] = 0;
+        }
+        for (uint32_t i = threadIdx.x; i < WCNT_DD; i += WCNT_NT) s.dd_tab[i] = 0xFFFFFFFFu;
+    };
+    bool staged = false;  // uniform: the staging arrays hold the first round of the bucket in nx_*
     load_range(blockIdx.x, r2_beg, r2_n);
     prefetch_recs(blockIdx.x);
     for (uint64_t bucket = blockIdx.x; bucket < n_buckets; bucket += gridDim.x) {
         const uint64_t r_beg = nx_beg, r_n = nx_n;
+        bool lds_staged = staged;
+        staged = false;
         if (r_n == 0) { prefetch_recs(bucket + gridDim.x); continue; }
         bool have_pf = true;
+        const bool small_bucket = r_n * 51 < 0xFFFFull;  // a record holds at most 51 k-mers
         uint32_t stk_n = 1;
         bool root = true, failed = false;
         if (split_recs && r_n > split_recs) {
@@ -445,58 +640,69 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             for (uint64_t c0 = 0; c0 < r_n; c0 += WCNT_STAGE) {
                 const uint32_t n_st = (uint32_t)min((uint64_t)WCNT_STAGE, r_n - c0);
                 if (c0) __syncthreads();
-                if (threadIdx.x == 0) s.n_flat = 0;
-                if (threadIdx.x < n_st) {  // one record per thread (the first round of a bucket comes from the prefetch registers)
-                    const bool pf = have_pf && c0 == 0;
-                    const uint64_t ri = r_beg + c0 + threadIdx.x;
-                    const uint4 b0 = pf ? pf_b0 : rec_b[2 * ri], b1 = pf ? pf_b1 : rec_b[2 * ri + 1];
-                    s.rb[threadIdx.x][0] = ((unsigned long long)b0.y << 32) | b0.x;
-                    s.rb[threadIdx.x][1] = ((unsigned long long)b0.w << 32) | b0.z;
-                    s.rb[threadIdx.x][2] = ((unsigned long long)b1.y << 32) | b1.x;
-                    s.rb[threadIdx.x][3] = ((unsigned long long)b1.w << 32) | b1.z;
-                    s.rmeta[threadIdx.x] = pf ? pf_w1 : rec_w1[ri];
-                    s.rst[threadIdx.x] = pf ? pf_st : rec_st[ri];
-                    s.dd_mult[threadIdx.x] = 0;
-                }
-                CNT_TICK(14);
-                for (uint32_t i = threadIdx.x; i < WCNT_DD; i += WCNT_NT) s.dd_tab[i] = 0xFFFFFFFFu;
-                CNT_TICK(15);
-                __syncthreads();
-            CNT_TICK(1);
-                if (s.overflow) break;
-                // ---- identical records collapse to one representative with a multiplicity and the smallest stamp
-                if (threadIdx.x < n_st) {
-                    const uint32_t r = threadIdx.x;
-                    const unsigned long long b0 = s.rb[r][0], b1 = s.rb[r][1], b2 = s.rb[r][2], b3 = s.rb[r][3];
-                    const unsigned long long mt = s.rmeta[r] & ~(((1ull << SK_BUCKET_BITS) - 1) << 6);  // length + flag
-                    uint32_t hslot = (uint32_t)(mix64(b0 ^ mix64(b1 + 0x9E3779B97F4A7C15ull) ^ mix64(b2 ^ (b3 * 0xD6E8FEB86659FD93ull)) ^ mt) >> 40) &
-                                     (WCNT_DD - 1);
-                    uint32_t rep = r;
-                    for (uint32_t probe = 0; probe < WCNT_DD; ++probe) {
-                        uint32_t cur = s.dd_tab[hslot];
-                        if (cur == 0xFFFFFFFFu) {
-                            cur = atomicCAS(&s.dd_tab[hslot], 0xFFFFFFFFu, r);
-                            if (cur == 0xFFFFFFFFu) break;
+                if (lds_staged && c0 == 0) {
+                    CNT_TICK(14);
+                    CNT_EVENT(21);
+                } else {
+                    CNT_EVENT(22);
+                    if (have_pf && c0 == 0) {
+                        stage_regs(n_st);
+                    } else {
+                        if (threadIdx.x == 0) s.n_flat = 0;
+                        if (threadIdx.x < n_st) {  // one record per thread
+                            const uint64_t ri = r_beg + c0 + threadIdx.x;
+                            const uint4 b0 = rec_b[2 * ri], b1 = rec_b[2 * ri + 1];
+                            s.rb[threadIdx.x][0] = ((unsigned long long)b0.y << 32) | b0.x;
+                            s.rb[threadIdx.x][1] = ((unsigned long long)b0.w << 32) | b0.z;
+                            s.rb[threadIdx.x][2] = ((unsigned long long)b1.y << 32) | b1.x;
+                            s.rb[threadIdx.x][3] = ((unsigned long long)b1.w << 32) | b1.z;
+                            s.rmeta[threadIdx.x] = rec_w1[ri];
+                            s.rst[threadIdx.x] = rec_st[ri];
+                            s.dd_mult[threadIdx.x] = 0;
                         }
-                        if (s.rb[cur][0] == b0 && s.rb[cur][1] == b1 && s.rb[cur][2] == b2 && s.rb[cur][3] == b3 &&
-                            (s.rmeta[cur] & ~(((1ull << SK_BUCKET_BITS) - 1) << 6)) == mt) { rep = cur; break; }
-                        hslot = (hslot + 1) & (WCNT_DD - 1);
+                        for (uint32_t i = threadIdx.x; i < WCNT_DD; i += WCNT_NT) s.dd_tab[i] = 0xFFFFFFFFu;
                     }
-                    atomicAdd(&s.dd_mult[rep], 1u);
-                    if (rep != r) atomicMin(&s.rst[rep], s.rst[r]);
+                    CNT_TICK(15);
+                    __syncthreads();
+                    CNT_TICK(1);
+                    if (c0 && s.overflow) break;  // an earlier round of this pass overflowed the table
                 }
-                __syncthreads();
-            CNT_TICK(2);
+                lds_staged = false;
+                // ---- identical records collapse to one representative with a multiplicity and the smallest stamp; the
+                //      representatives list their quads of 4 k-mers in the same pass (a record knows that it is one when
+                //      its own claim succeeds)
                 {
-                    const uint32_t r = threadIdx.x;
                     uint32_t nquad = 0;
-                    if (r < n_st && s.dd_mult[r]) nquad = ((uint32_t)wrec_len(s.rmeta[r]) + 3) >> 2;
+                    const uint32_t r = threadIdx.x;
+                    if (r < n_st) {
+                        const unsigned long long b0 = s.rb[r][0], b1 = s.rb[r][1], b2 = s.rb[r][2], b3 = s.rb[r][3];
+                        const unsigned long long mt = s.rmeta[r] & ~(((1ull << SK_BUCKET_BITS) - 1) << 6);  // length + flag
+                        uint32_t hslot = (uint32_t)(mix64(b0 ^ mix64(b1 + 0x9E3779B97F4A7C15ull) ^ mix64(b2 ^ (b3 * 0xD6E8FEB86659FD93ull)) ^ mt) >> 40) &
+                                         (WCNT_DD - 1);
+                        uint32_t rep = r;
+                        for (uint32_t probe = 0; probe < WCNT_DD; ++probe) {
+                            uint32_t cur = s.dd_tab[hslot];
+                            if (cur == 0xFFFFFFFFu) {
+                                cur = atomicCAS(&s.dd_tab[hslot], 0xFFFFFFFFu, r);
+                                if (cur == 0xFFFFFFFFu) break;
+                            }
+                            if (s.rb[cur][0] == b0 && s.rb[cur][1] == b1 && s.rb[cur][2] == b2 && s.rb[cur][3] == b3 &&
+                                (s.rmeta[cur] & ~(((1ull << SK_BUCKET_BITS) - 1) << 6)) == mt) { rep = cur; break; }
+                            hslot = (hslot + 1) & (WCNT_DD - 1);
+                        }
+                        atomicAdd(&s.dd_mult[rep], 1u);
+                        if (rep != r) atomicMin(&s.rst[rep], s.rst[r]);
+                        else nquad = ((uint32_t)wrec_len(mt) + 3) >> 2;
+                    }
                     const uint32_t base = wave_alloc_n<WCNT_QMAX>(&s.n_flat, nquad);
                     for (uint32_t q = 0; q < nquad; ++q) s.flat[base + q] = (uint16_t)((r << 4) | q);
                 }
                 __syncthreads();
-            CNT_TICK(3);
+                CNT_TICK(3);
                 const uint32_t n_flat = s.n_flat;
+#ifdef DBG_CNT_PROF
+                const unsigned long long wt0_ = clock64();
+#endif
                 for (uint32_t f = threadIdx.x >> 2; f < n_flat; f += WCNT_NT / 4) {
                     const uint32_t e = s.flat[f];
                     const uint32_t r = e >> 4;
@@ -517,31 +723,45 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     const uint32_t mult = s.dd_mult[r];
                     uint32_t slot = wslot_of(key);
                     bool ok = false;
-                    for (int probe = 0, spins = 0; probe < CNT_PROBE_LIMIT && spins < (1 << 20); ) {
-                        unsigned long long cur = __hip_atomic_load(&s.khi[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // Claim first: most k-mers a bucket sees are new (identical records were collapsed), and one
+                    // compare-and-swap answers all three cases -- empty (now ours), this k-mer's high word, another's.
+                    // The LDS executes one wave's operations in order, so the low word is visible before the final
+                    // high word without a wait between the two stores; a reader that sees the final high word reads
+                    // the low word afterwards (its address depends on nothing, its issue on the compare).
+                    // A pending high word equal to ours is looked at again in the NEXT iteration of this loop, never in
+                    // a loop of its own: the claimant may be a lane of this wave, and it publishes in its own branch of
+                    // the iteration.
+                    for (int probe = 0, spins = 0; probe < CNT_PROBE_LIMIT && spins < (1 << 16); ) {
+                        const unsigned long long cur = atomicCAS(&s.khi[slot], EMPTY_KEY, key.hi | W_PEND);
                         if (cur == EMPTY_KEY) {
-                            cur = atomicCAS(&s.khi[slot], EMPTY_KEY, key.hi | W_PEND);
-                            if (cur == EMPTY_KEY) {  // claimed: publish the low word, then the high word without the pending bit
-                                __hip_atomic_store(&s.klo[slot], key.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                __hip_atomic_store(&s.khi[slot], key.hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                ok = true;
-                                break;
-                            }
+                            wlds_store(&s.klo[slot], key.lo);
+                            wlds_store(&s.khi[slot], key.hi);
+                            ok = true;
+                            break;
                         }
-                        if (cur & W_PEND) { ++spins; continue; }  // its low word is on the way: look again
-                        if (cur == key.hi &&
-                            __hip_atomic_load(&s.klo[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == key.lo) { ok = true; break; }
+                        if ((cur & ~W_PEND) == key.hi) {  // this k-mer or one that shares its high word
+                            if (cur & W_PEND) { ++spins; continue; }
+                            if (wlds_load(&s.klo[slot]) == key.lo) { ok = true; break; }
+                        }
                         slot = (slot + 1) & (WCAP - 1);
                         ++probe;
                     }
                     if (!ok) { s.overflow = 1; continue; }
                     if (has_succ) {
                         const int shf = 16 * (int)(b & 1);
-                        const uint32_t old = atomicAdd(&s.cnt2[slot * 2 + (b >> 1)], mult << shf);
-                        if (((old >> shf) & 0xFFFFu) + mult > 0xFFFFu) atomicOr(&out.scalars[0], 512ull);  // 16-bit counter overflow
+                        if (small_bucket) {  // uniform: fewer than 2^16 k-mer instances in the whole bucket -- no counter can wrap,
+                            atomicAdd(&s.cnt2[slot * 2 + (b >> 1)], mult << shf);  // and nobody waits for the old value
+                        } else {
+                            const uint32_t old = atomicAdd(&s.cnt2[slot * 2 + (b >> 1)], mult << shf);
+                            if (((old >> shf) & 0xFFFFu) + mult > 0xFFFFu) atomicOr(&out.scalars[0], 512ull);  // 16-bit counter overflow
+                        }
                     }
                     atomicMin(&s.stamp[slot], stamp);
                 }
+#ifdef DBG_CNT_PROF
+                if ((threadIdx.x & 63) == 0) s.prof[32 + (threadIdx.x >> 6)] += clock64() - wt0_;
+                if (threadIdx.x == 0) { s.prof[48] += n_flat; s.prof[49] += n_st; }
+#endif
             }
             CNT_TICK(4);
             __syncthreads();
@@ -699,6 +919,10 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);
             if (s.fail) break;
             const uint64_t gbase = s.gbase, ebase = s.ebase;
+            if (stk_n == 0 && !have_pf) {  // uniform: last pass of this bucket, the registers hold the next one's first round
+                stage_regs((uint32_t)min(nx_n, (uint64_t)WCNT_STAGE));
+                staged = true;
+            }
             // ---- write nodes and their CSR rows; every slot read is cleared for the next bucket
             if (threadIdx.x < WCAP / 64) {
                 SkDirEnt de;
@@ -783,7 +1007,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
     }
 #ifdef DBG_CNT_PROF
     if (threadIdx.x == 0) {
-        for (int i = 0; i < 31; ++i) atomicAdd(&g_cnt_prof[i], s.prof[i]);
+        for (int i = 0; i < 64; ++i) if (i != 31) atomicAdd(&g_cnt_prof[i], s.prof[i]);
         atomicAdd(&g_cnt_prof[31], 1ull);
     }
 #endif

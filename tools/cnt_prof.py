@@ -13,7 +13,7 @@ reads = int(os.environ.get("SWEEP_READS", "10000000"))
 g = _dbg.Graph()
 g.synth_reads(1, reads * 5, reads, 150, 0.01)
 lib = _dbg.load_library()
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 64)()
 g.build(K)
 lib.dbg_debug_cnt_prof(out, 1)
 g.build(K)
@@ -31,3 +31,6 @@ for i in main:
 sub = {20: "(since previous subtick)", 13: "u0 find loop / wide: clear", 14: "u0 wave_alloc_n<4> / wide: stage stores", 15: "u0 miss staging / wide: dd clear"}
 for i, n in sub.items():
     print(f"    sub {n:28s} {100.0 * out[i] / tot:5.1f} %  = {st['ms_count'] * out[i] / tot:6.2f} ms")
+print(f"  events: staged rounds {out[21]}, rounds staged at the top {out[22]}")
+print("  insert clocks per wave (share of wave 0):", " ".join(f"{out[32 + w] / max(1, out[32]):.2f}" for w in range(16)))
+print(f"  quads per round {out[48] / max(1, out[21] + out[22]):.0f}, records per round {out[49] / max(1, out[21] + out[22]):.0f}")
