@@ -842,7 +842,8 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
     static_assert(STAGE <= CNT_NT, "one staged record per thread");
     static_assert(sizeof(LdsT) <= 160 * 1024, "LDS");
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    uint16_t *flat = s.eoff;
+    uint16_t *flat = s.list;
+    constexpr uint64_t BH_FIELD = ((1ull << SK_BUCKET_BITS) - 1) << 6;  // of a staged w1: the record's multiplicity (the bucket is known)
 
 #ifdef DBG_CNT_PROF
     unsigned long long clast_ = clock64(), csub_ = clast_;
@@ -913,52 +914,50 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                 if (c0) __syncthreads();
                 if (threadIdx.x == 0) s.n_flat = 0;
                 if (c0 == 0 && have_prefetch) {
-                    if (threadIdx.x < n_st) { s.q_key[threadIdx.x] = pf_w0; s.q_meta[threadIdx.x] = pf_w1; s.st_stage[threadIdx.x] = pf_st; }
+                    if (threadIdx.x < n_st) { s.q_key[threadIdx.x] = pf_w0; s.q_meta[threadIdx.x] = pf_w1 & ~BH_FIELD; s.st_stage[threadIdx.x] = pf_st; }
                 } else {
                     for (uint32_t r = threadIdx.x; r < n_st; r += CNT_NT) {
                         s.q_key[r] = rec_w0[r_beg + c0 + r];
-                        s.q_meta[r] = rec_w1[r_beg + c0 + r];
+                        s.q_meta[r] = rec_w1[r_beg + c0 + r] & ~BH_FIELD;
                         s.st_stage[r] = rec_st[r_beg + c0 + r];
                     }
                 }
-                // dedupe scratch (eoff[] / list[] are free until the table is final): hash set of record indices
-                // and the multiplicity of every representative
+                // dedupe scratch (eoff[] / list[] are free until the table is final): hash set of record indices in eoff[],
+                // the quad list in list[]; the multiplicity of a representative counts up in the bucket-hash field of its
+                // staged w1 (the insert reads that word anyway)
                 uint32_t *dd_tab = reinterpret_cast<uint32_t *>(s.eoff);   // DD_SLOTS entries
-                uint32_t *dd_mult = reinterpret_cast<uint32_t *>(s.list);  // STAGE entries
                 constexpr uint32_t DD_SLOTS = CAP / 2;                      // sizeof(eoff) / 4; >= 2 * STAGE
-                static_assert(DD_SLOTS >= 2 * STAGE && CAP / 2 >= STAGE, "dedupe scratch");
+                static_assert(DD_SLOTS >= 2 * STAGE && STAGE < (1u << 20), "dedupe scratch");
                 for (uint32_t i = threadIdx.x; i < DD_SLOTS; i += CNT_NT) dd_tab[i] = 0xFFFFFFFFu;
-                for (uint32_t i = threadIdx.x; i < n_st; i += CNT_NT) dd_mult[i] = 0;
                 __syncthreads();
                 CNT_TICK(1);
                 if (phase_limit == 1) { skip_rest = true; break; }  // clear + stage
                 if (s.overflow) break;  // uniform: read after the barrier
                 // ---- identical records (same window of the genome seen by several reads) collapse to one
                 //      representative with a multiplicity and the smallest stamp: at 30x coverage this is
-                //      most of the error-free data, so the per-k-mer table work drops by about that factor
-                if (threadIdx.x < n_st) {
-                    const uint32_t r = threadIdx.x;
-                    const unsigned long long w0 = s.q_key[r], w1 = s.q_meta[r];
-                    uint32_t hslot = fmix32(fold32(w0) ^ (fold32(w1) * 0x9E3779B1u)) & (DD_SLOTS - 1);
-                    uint32_t rep = r;
-                    for (uint32_t probe = 0; probe < DD_SLOTS; ++probe) {
-                        uint32_t cur = dd_tab[hslot];
-                        if (cur == 0xFFFFFFFFu) {
-                            cur = atomicCAS(&dd_tab[hslot], 0xFFFFFFFFu, r);
-                            if (cur == 0xFFFFFFFFu) break;  // r is the representative
-                        }
-                        if (s.q_key[cur] == w0 && s.q_meta[cur] == w1) { rep = cur; break; }
-                        hslot = (hslot + 1) & (DD_SLOTS - 1);
-                    }
-                    atomicAdd(&dd_mult[rep], 1u);
-                    if (rep != r) atomicMin(&s.st_stage[rep], s.st_stage[r]);
-                }
-                __syncthreads();
-                CNT_TICK(2);
-                {  // quad list of the representatives (STAGE <= CNT_NT: one record per thread)
+                //      most of the error-free data, so the per-k-mer table work drops by about that factor.
+                //      A record knows that it is a representative when its own claim succeeds, and lists its quads
+                //      of 4 k-mers in the same pass (STAGE <= CNT_NT: one record per thread).
+                {
                     const uint32_t r = threadIdx.x;
                     uint32_t nquad = 0;
-                    if (r < n_st && dd_mult[r]) nquad = ((uint32_t)((s.q_meta[r] >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
+                    if (r < n_st) {
+                        const unsigned long long w0 = s.q_key[r], w1 = s.q_meta[r];
+                        uint32_t hslot = fmix32(fold32(w0) ^ (fold32(w1) * 0x9E3779B1u)) & (DD_SLOTS - 1);
+                        uint32_t rep = r;
+                        for (uint32_t probe = 0; probe < DD_SLOTS; ++probe) {
+                            uint32_t cur = dd_tab[hslot];
+                            if (cur == 0xFFFFFFFFu) {
+                                cur = atomicCAS(&dd_tab[hslot], 0xFFFFFFFFu, r);
+                                if (cur == 0xFFFFFFFFu) break;  // r is the representative
+                            }
+                            if (s.q_key[cur] == w0 && ((s.q_meta[cur] ^ w1) & ~BH_FIELD) == 0) { rep = cur; break; }
+                            hslot = (hslot + 1) & (DD_SLOTS - 1);
+                        }
+                        atomicAdd(reinterpret_cast<uint32_t *>(&s.q_meta[rep]), 1u << 6);  // low dword: bits 27..6 = multiplicity
+                        if (rep != r) atomicMin(&s.st_stage[rep], s.st_stage[r]);
+                        else nquad = ((uint32_t)((w1 >> 1) & 31) + 4) >> 2;  // ceil(len / 4)
+                    }
                     const uint32_t base = wave_alloc_n<8>(&s.n_flat, nquad);
                     for (uint32_t q = 0; q < nquad; ++q) flat[base + q] = (uint16_t)((r << 3) | q);
                 }
@@ -973,7 +972,7 @@ __global__ __launch_bounds__((CntCfg<ST, CAP>::NT)) void k_sk_count(const uint64
                     const int len = (int)((w1 >> 1) & 31) + 1;
                     if (i >= len) continue;
                     const ST st0 = s.st_stage[r];
-                    const uint32_t mult = dd_mult[r];
+                    const uint32_t mult = (uint32_t)(w1 >> 6) & ((1u << SK_BUCKET_BITS) - 1u);
                     const uint64_t hi = w1 & (~0ull << SK_META_BITS);
                     const uint32_t hs = (uint32_t)(w1 & 1);
                     const uint64_t win = rec_window(w0, hi, i);
