@@ -10,9 +10,9 @@ Workloads:
   N > 1 (default)    BASELINE.json configs[2] scaled by N/8: 12.5 M reads per rank over an N x 62.5 Mbp genome, hash-prefix
                      sharded build with RCCL all-to-all (multi_gpu.sharded_build); N = 8 is configs[2] itself
                      (100 M x 150 bp).  Per-GPU work is fixed: "scaling": "weak".
-  --scaling strong   a FIXED total (--total-reads, default 14 M: a rank of the sharded path holds < 2 GiB of reads, its
-                     local stamps are 32-bit) split over the ranks: "scaling": "strong".  N = 1 runs the sharded path
-                     on one rank so that every N runs the same code.
+  --scaling strong   a FIXED total (--total-reads, default 14 M: the N = 1 leg is ONE shard, and a shard names 2^29 - 16
+                     nodes; 14 M reads give 5.1e8) split over the ranks: "scaling": "strong".  N = 1 runs the sharded
+                     path on one rank so that every N runs the same code.
 The driver launches N > 1 as  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel AND whole step) and

@@ -45,7 +45,7 @@ typedef struct dbg dbg_t;
 #define DBG_E_CAPACITY (-4) /* hash table or an output limit was exceeded */
 #define DBG_E_NOMEM (-5)    /* host or device allocation failed */
 
-#define DBG_ABI_VERSION 2
+#define DBG_ABI_VERSION 3
 
 /* node flag bits (dbg_export_nodes: flags[]) */
 #define DBG_F_INDEG 0x01u    /* Node.indegree (0 or 1), debruijn.py:134,141-142 */
@@ -163,6 +163,23 @@ int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *stamps, uint8_
 int dbg_part_device_views(dbg_t *h, int part, const void **d_keys, const void **d_stamps, int *stamp_bytes,
                           const void **d_flags, const void **d_row_ptr32, const void **d_col, const void **d_col_part,
                           const void **d_cnt);
+/* ---- ranks x passes (BASELINE.json configs[3] on several GPUs): a rank of a sharded build that builds its shard as
+ *      n_passes parts.  Input as for dbg_shard_build with sender_bucket_counts (stamp_bytes 4 or 8); part p of rank r is
+ *      VIRTUAL shard r * n_passes + p of n_shards * n_passes (<= 64), and col_part of a column holds the virtual shard
+ *      of the successor.  Successors owned by other RANKS are open afterwards:
+ *        dbg_part_queries  the successor k-mers of `part`, group of virtual shard v at [q_starts[v], + q_counts[v]) of
+ *                          *d_q_keys (uint64, device); arrays of n_shards * n_passes entries, own rank's groups count 0
+ *        dbg_part_answer   the owner: node ids (uint32, device; local to `part`) of n k-mers it was asked about
+ *        dbg_part_apply    the asker: d_answers (uint32, device) = answers of virtual shard `owner` to that whole group
+ *        dbg_multipass_finish  frees the query lists; fails if any successor stayed unresolved
+ *      (multi_gpu.sharded_build_multipass runs these around two all-to-alls per pass). */
+int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_shard, int n_passes, const void *d_w0, const void *d_w1,
+                              const void *d_st, int stamp_bytes, const uint64_t *recv_counts, const uint64_t *stamp_base,
+                              const uint64_t *sender_bucket_counts);
+int dbg_part_queries(dbg_t *h, int part, uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys);
+int dbg_part_answer(dbg_t *h, int part, const void *d_q_keys, uint64_t n, void *d_answers);
+int dbg_part_apply(dbg_t *h, int part, int owner, const void *d_answers);
+int dbg_multipass_finish(dbg_t *h);
 
 /* ---- exact successor order (Counter semantics of debruijn.py:159-165 and :215-216): finds the first
  *      occurrence of every out-edge of the nodes with >= 2 distinct successors (one more pass over the
@@ -242,13 +259,17 @@ int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const
  *      (owner shard << 29) | node id on that shard; stamps are global ((byte offset in the
  *      rank-major concatenation of all reads) << 1 | pos != 0). */
 /* step 1: this rank's reads -> super-k-mer records grouped by owner (device arrays: w0, w1 uint64,
- * st uint32); send_counts[n_shards] records go to each owner, contiguous and in owner order */
+ * st = rank-local stamps: uint32 while this rank's reads stay below 2 GiB, else uint64 (k <= 31 only; option
+ * "shard_stamp64" 1 forces the wide ones) -- dbg_shard_record_layout says which); send_counts[n_shards] records go to
+ * each owner, contiguous and in owner order */
 int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
                       const void **d_st);
 /* What the last dbg_shard_extract handed out: *w0_words = 64-bit words per record in d_w0 (1: super-k-mer records of
  * k <= 31, or the low key word of the k-mer instances of k > 31 with "wide_engine" 0; 4: the aligned bases of a
- * super-k-mer record of k > 31), *stamp_bytes = bytes per entry of d_st (4, or 8 for the instance tuples).  The
- * exchange moves counts[d] x words elements of d_w0. */
+ * super-k-mer record of k > 31), *stamp_bytes = bytes per entry of d_st (4; 8 for the instance tuples and for
+ * k <= 31 records of a rank that holds 2 GiB of reads or more).  The exchange moves counts[d] x words elements of d_w0;
+ * all senders of one dbg_shard_build must use ONE stamp width (a rank with 4-byte stamps zero-extends them when another
+ * rank has 8: multi_gpu.sharded_build). */
 int dbg_shard_record_layout(dbg_t *h, int *w0_words, int *stamp_bytes);
 /* records per level-1 bucket (the 512 top-9-bit groups of the bucket hash) of the last dbg_shard_extract (k <= 31, and k > 31 on the LDS engine):
  * owner d holds the buckets [d * 512 / n_shards, (d + 1) * 512 / n_shards), in order, so send_counts[d] is their sum */
@@ -259,10 +280,12 @@ int dbg_shard_bucket_counts(dbg_t *h, uint64_t *counts512);
  * [q_starts[d], q_starts[d] + q_counts[d]).
  * sender_bucket_counts: NULL, or [n_shards][512 / n_shards] -- for every sender its dbg_shard_bucket_counts entries of
  * the buckets THIS shard owns.  With it the receiver skips the first multisplit level (the senders did it before the
- * exchange) and rebases the stamps inside the second one. */
+ * exchange) and rebases the stamps inside the second one.
+ * stamp_bytes: width of the entries of d_st32 -- 0 = the layout's default (4; 8 for k-mer instance tuples), 4, or 8
+ * (k <= 31 with sender_bucket_counts: senders that hold 2 GiB of reads or more). */
 int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w0, const void *d_w1, const void *d_st32,
                     const uint64_t *recv_counts, const uint64_t *stamp_base, uint64_t *q_starts, uint64_t *q_counts,
-                    const void **d_q_keys, const uint64_t *sender_bucket_counts);
+                    const void **d_q_keys, const uint64_t *sender_bucket_counts, int stamp_bytes);
 /* step 3: node ids (uint32, device) of n successor k-mers other ranks asked this shard about */
 int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void *d_answers);
 /* step 4: d_answers (uint32, device) laid out like *d_q_keys of step 2; completes successors + CSR */

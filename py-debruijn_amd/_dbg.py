@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DBG_LIB") or os.path.join(_HERE, "libdbg_hip.so")  # 
 DBG_OK, DBG_E_ARG, DBG_E_HIP, DBG_E_ALPHABET, DBG_E_CAPACITY, DBG_E_NOMEM = 0, -1, -2, -3, -4, -5
 F_INDEG, F_KEEP_MASK, F_KEEP_SHIFT, F_BRANCH, F_PULLED = 0x01, 0x1E, 1, 0x20, 0x40
 NO_NODE = 0xFFFFFFFF
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
@@ -32,6 +32,7 @@ SYMBOLS = (
     "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_record_layout", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
     "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
+    "dbg_shard_build_multipass", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
 )
 
 
@@ -125,12 +126,17 @@ def load_library():
         "dbg_shard_extract": (C.c_int, [H, C.c_int, C.c_int, u64p, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "dbg_shard_bucket_counts": (C.c_int, [H, u64p]),
         "dbg_shard_record_layout": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-        "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p]),
+        "dbg_shard_build": (C.c_int, [H, C.c_int, C.c_int, C.c_int, vp, vp, vp, u64p, u64p, u64p, u64p, C.POINTER(vp), u64p, C.c_int]),
         "dbg_shard_answer": (C.c_int, [H, vp, C.c_uint64, vp]),
         "dbg_build_multipass": (C.c_int, [H, C.c_int, C.c_int]),
         "dbg_export_sorted_fasta": (C.c_int, [H, vp, vp, C.c_uint64, u64p]),
         "dbg_support_read_scores": (C.c_int, [H, vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "dbg_part_count": (C.c_int, [H, C.POINTER(C.c_int)]),
+        "dbg_shard_build_multipass": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, u64p, u64p, u64p]),
+        "dbg_part_queries": (C.c_int, [H, C.c_int, u64p, u64p, C.POINTER(vp)]),
+        "dbg_part_answer": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp]),
+        "dbg_part_apply": (C.c_int, [H, C.c_int, C.c_int, vp]),
+        "dbg_multipass_finish": (C.c_int, [H]),
         "dbg_part_sizes": (C.c_int, [H, C.c_int, u64p, u64p, u64p]),
         "dbg_export_part": (C.c_int, [H, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "dbg_part_device_views": (C.c_int, [H, C.c_int] + [C.POINTER(vp)] * 2 + [C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5),
@@ -396,6 +402,47 @@ class Graph:
         self.generation += 1
         self._chk(self._lib.dbg_build_multipass(self._h, int(k), int(n_passes)))
 
+    # ---- ranks x passes: a rank of a sharded build that builds its shard in parts (multi_gpu.sharded_build_multipass)
+    def shard_build_multipass(self, k, n_shards, my_shard, n_passes, w0, w1, st, recv_counts, stamp_base, sender_bucket_counts):
+        """Received records (torch tensors, split by the senders' level-1 groups) -> n_passes parts on this handle; part p
+        is virtual shard my_shard * n_passes + p.  Successors owned by other ranks stay open (part_queries)."""
+        self.generation += 1
+        rc = (C.c_uint64 * n_shards)(*[int(x) for x in recv_counts])
+        sb = (C.c_uint64 * n_shards)(*[int(x) for x in stamp_base])
+        flat = [int(x) for row in sender_bucket_counts for x in row]
+        assert len(flat) == 512, "one count per (sender, owned level-1 group)"
+        sbc = (C.c_uint64 * 512)(*flat)
+        self._keep = [w0, w1, st]
+        self._mp_virtual = n_shards * n_passes
+        self._chk(self._lib.dbg_shard_build_multipass(self._h, int(k), int(n_shards), int(my_shard), int(n_passes),
+                                                      C.c_void_p(w0.data_ptr()), C.c_void_p(w1.data_ptr()),
+                                                      C.c_void_p(st.data_ptr()), int(st.element_size()), rc, sb, sbc))
+        self._keep = []
+
+    def part_queries(self, part):
+        """-> (q_starts, q_counts, keys tensor): the part's open successor k-mers grouped by owning virtual shard."""
+        nv = self._mp_virtual
+        qs, qc = (C.c_uint64 * nv)(), (C.c_uint64 * nv)()
+        pk = C.c_void_p()
+        self._chk(self._lib.dbg_part_queries(self._h, int(part), qs, qc, C.byref(pk)))
+        qs, qc = [int(x) for x in qs], [int(x) for x in qc]
+        total = max([a + b for a, b in zip(qs, qc) if b] + [0])
+        return qs, qc, device_tensor(pk.value, total, "int64", self.sizes_device())
+
+    def part_answer(self, part, keys):
+        import torch
+        ans = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
+        if keys.numel():
+            self._chk(self._lib.dbg_part_answer(self._h, int(part), C.c_void_p(keys.data_ptr()), keys.numel(),
+                                                C.c_void_p(ans.data_ptr())))
+        return ans
+
+    def part_apply(self, part, owner, answers):
+        self._chk(self._lib.dbg_part_apply(self._h, int(part), int(owner), C.c_void_p(answers.data_ptr()) if answers.numel() else None))
+
+    def multipass_finish(self):
+        self._chk(self._lib.dbg_multipass_finish(self._h))
+
     def part_count(self):
         n = C.c_int()
         self._chk(self._lib.dbg_part_count(self._h, C.byref(n)))
@@ -480,7 +527,7 @@ class Graph:
         self._keep = [w0, w1, st]
         self._chk(self._lib.dbg_shard_build(self._h, int(k), int(n_shards), int(my_shard), C.c_void_p(w0.data_ptr()),
                                             C.c_void_p(w1.data_ptr()), C.c_void_p(st.data_ptr()), rc, sb, qs, qc,
-                                            C.byref(pk), sbc))
+                                            C.byref(pk), sbc, int(st.element_size())))
         self._keep = []
         qs, qc = [int(x) for x in qs], [int(x) for x in qc]
         total = max([a + b for a, b in zip(qs, qc)] + [0])

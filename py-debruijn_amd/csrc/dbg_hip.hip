@@ -133,6 +133,7 @@ struct dbg {
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
+    int shard_stamp64 = 0;    // option: dbg_shard_extract hands out 64-bit rank-local stamps even below 2 GiB of reads (tests)
     uint64_t sk_n_ranges = 0, sk_n_buckets = 0;
     SkGeom sk_geom{};            // hash -> bucket mapping of the last partitioned build (k_succ_resolve)
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -2019,6 +2020,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "phase_limit" && value >= 0 && value <= 5) { h->phase_limit = (int)value; return DBG_OK; }
     if (n == "estimate_scale_pct" && value >= 1 && value <= 1000) { h->est_scale_pct = (int)value; return DBG_OK; }
     if (n == "target_distinct" && value >= 0 && value <= 4096) { h->target_distinct = (int)value; return DBG_OK; }
+    if (n == "shard_stamp64" && (value == 0 || value == 1)) { h->shard_stamp64 = (int)value; return DBG_OK; }
     if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
@@ -3795,6 +3797,7 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
         if ((sc[0] & 64) && q_cap < n_edge_inst + 1024) { q_cap = n_edge_inst + 1024; again = true; }
         if (!again || attempt == 2) break;
     }
+    if (sc[0] & 1024) { h->err = "two-word count kernel: an LDS slot claim never completed"; return DBG_E_HIP; }
     if (sc[0] & 512) { h->err = "16-bit successor counter overflow"; return DBG_E_CAPACITY; }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }
@@ -4167,32 +4170,24 @@ extern "C" int dbg_shard_record_layout(dbg_t *h, int *w0_words, int *stamp_bytes
     return DBG_OK;
 }
 
-extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0,
-                                 const void **d_w1, const void **d_st) {
-    CHK(shard_args_ok(h, k, n_shards));
-    if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
-    if (h->n_bytes >= (1ull << 31)) { h->err = "a shard's reads must stay below 2 GiB (32-bit local stamps)"; return DBG_E_ARG; }
-    HIPCHK(h, hipSetDevice(h->device));
-    if (k > 31) {
-        if (h->wide_engine == 1) return shard_extract_wsk(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
-        int rcw = shard_extract_wide(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
-        if (rcw == DBG_OK) { shard_of(h).rec_words = 1; shard_of(h).rec_stamp_bytes = 8; }
-        return rcw;
-    }
+// one-word k-mers: records split by the 512 level-1 groups; ST = width of the rank-local stamps
+template <class ST>
+static int shard_extract_sk(dbg *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
+                            const void **d_st) {
     free_build(h);
     h->stats = dbg_stats_t{};
     uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
-    uint32_t *st[2];
+    ST *st[2];
     uint32_t n_seg = 0;
-    CHK(sk_extract<uint32_t>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    CHK(sk_extract<ST>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
     // group by the 9 top bits of the bucket hash: owners are contiguous ranges of those 512 groups
     const int nb1 = 512;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
     Timer t(h->stream);
-    CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
-                                          st[1], 6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2],
-                                          h->ar_misc[3], h->ar_misc[4])));
+    CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
+                                    st[1], 6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2],
+                                    h->ar_misc[3], h->ar_misc[4])));
     std::vector<uint64_t> cnt(nb1);
     HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
     h->stats.ms_partition = t.stop();
@@ -4209,8 +4204,26 @@ extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_c
     sh.n_kmer_inst_local = h->n_kmer_inst;
     sh.l1_counts = cnt;
     sh.rec_words = 1;
-    sh.rec_stamp_bytes = 4;
+    sh.rec_stamp_bytes = (int)sizeof(ST);
     return DBG_OK;
+}
+
+extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0,
+                                 const void **d_w1, const void **d_st) {
+    CHK(shard_args_ok(h, k, n_shards));
+    if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
+    // rank-local stamps: 32 bits while this rank's reads stay below 2 GiB (or "shard_stamp64" asks for the wide ones)
+    const bool st64 = h->n_bytes >= (1ull << 31) || h->shard_stamp64;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (k > 31) {
+        if (h->n_bytes >= (1ull << 31)) { h->err = "a shard's reads must stay below 2 GiB for k > 31 (32-bit local stamps)"; return DBG_E_ARG; }
+        if (h->wide_engine == 1) return shard_extract_wsk(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
+        int rcw = shard_extract_wide(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
+        if (rcw == DBG_OK) { shard_of(h).rec_words = 1; shard_of(h).rec_stamp_bytes = 8; }
+        return rcw;
+    }
+    return st64 ? shard_extract_sk<uint64_t>(h, k, n_shards, send_counts, d_w0, d_w1, d_st)
+                : shard_extract_sk<uint32_t>(h, k, n_shards, send_counts, d_w0, d_w1, d_st);
 }
 
 extern "C" int dbg_shard_bucket_counts(dbg_t *h, uint64_t *counts512) {
@@ -4224,12 +4237,15 @@ extern "C" int dbg_shard_bucket_counts(dbg_t *h, uint64_t *counts512) {
 extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, const void *d_w0, const void *d_w1,
                                const void *d_st32, const uint64_t *recv_counts, const uint64_t *stamp_base,
                                uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys,
-                               const uint64_t *sender_bucket_counts) {
+                               const uint64_t *sender_bucket_counts, int stamp_bytes) {
     CHK(shard_args_ok(h, k, n_shards));
     if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !q_starts || !q_counts || !d_q_keys)
         return DBG_E_ARG;
+    if (stamp_bytes != 0 && stamp_bytes != 4 && stamp_bytes != 8) { h->err = "stamp_bytes must be 0 (the layout's default), 4 or 8"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     if (k > 31) {
+        const bool lds_engine = h->wide_engine == 1 && sender_bucket_counts;
+        if (stamp_bytes && stamp_bytes != (lds_engine ? 4 : 8)) { h->err = "two-word sharded builds: stamps are 4 bytes (records) or 8 (k-mer instances)"; return DBG_E_ARG; }
         if (h->wide_engine == 1 && sender_bucket_counts)
             return shard_build_wsk(h, k, n_shards, my_shard, (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint32_t *)d_st32,
                                    recv_counts, stamp_base, sender_bucket_counts, q_starts, q_counts, d_q_keys);
@@ -4280,12 +4296,18 @@ extern "C" int dbg_shard_build(dbg_t *h, int k, int n_shards, int my_shard, cons
         pre.stamp_add = add.data();
         pre.in_st = d_st32;
         const int w = k - sk_m_for_k(k) + 1;  // a record holds at most w k-mers
-        rc = sk_count_from_segments<uint64_t, 4096, uint32_t>(h, k, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w,
-                                                              n_rec * (uint64_t)w, (const uint64_t *)d_w0, (const uint64_t *)d_w1,
-                                                              (const uint64_t *)nullptr, w0, w1, st, 0, shard_bits, my_shard, &pre);
+        if (stamp_bytes == 8)  // senders that hold 2 GiB of reads or more
+            rc = sk_count_from_segments<uint64_t, 4096, uint64_t>(h, k, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w,
+                                                                  n_rec * (uint64_t)w, (const uint64_t *)d_w0, (const uint64_t *)d_w1,
+                                                                  (const uint64_t *)nullptr, w0, w1, st, 0, shard_bits, my_shard, &pre);
+        else
+            rc = sk_count_from_segments<uint64_t, 4096, uint32_t>(h, k, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w,
+                                                                  n_rec * (uint64_t)w, (const uint64_t *)d_w0, (const uint64_t *)d_w1,
+                                                                  (const uint64_t *)nullptr, w0, w1, st, 0, shard_bits, my_shard, &pre);
         n_inst = h->n_kmer_inst;
         n_edge = h->n_edge_inst;
     } else {
+        if (stamp_bytes == 8) { h->err = "64-bit rank-local stamps need sender_bucket_counts (the receiver starts at level 2)"; return DBG_E_ARG; }
         CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_shards * 16));
         uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_shards;
         HIPCHK(h, hipMemcpyAsync(seg_start, seg.data(), seg.size() * 8, hipMemcpyHostToDevice, h->stream));
@@ -4509,7 +4531,8 @@ extern "C" int dbg_shard_apply(dbg_t *h, const void *d_answers) {
 // part are resolved after the last pass through that part's directories (k_succ_resolve).
 // ==========================================================================================
 struct MultiPass {
-    int n_passes = 0;
+    int n_passes = 0;                  // parts on this handle
+    int n_virtual = 0, v_first = 0;    // part p is virtual shard v_first + p of n_virtual (ranks x passes; one GPU: n_passes, 0)
     std::vector<dbg *> part;
     std::vector<uint8_t *> col_owner;  // per part: [n_edges of the part] owner part of every CSR column
     std::vector<uint64_t> base;        // global id of the part's first node (prefix sums of the part sizes)
@@ -4588,6 +4611,139 @@ __global__ __launch_bounds__(256) void k_apply_part(const uint32_t *__restrict__
     col_owner[qcol[i]] = owner;
 }
 
+// The pass loop of a multi-pass build.  The records (set by the caller: in_w0 / in_w1 / in_st) are split by the 512
+// level-1 groups already -- by this GPU itself (dbg_build_multipass: one "sender") or by every rank of a sharded build
+// before the exchange (dbg_shard_build_multipass: n_senders segments, each in group order).  This handle owns the
+// n_passes * bps groups of the VIRTUAL shards [v_first, v_first + n_passes) out of n_virtual = ranks x passes; pass p
+// builds virtual shard v_first + p exactly as a rank of a sharded build does (level 2 (+3) -> count -> CSR) and parks
+// it as part p.  grp_cnt[r][g]: records of sender r in the g-th group this handle owns; sender_off[r]: where sender r's
+// records start; stamp_add[r]: added to its stamps.  Afterwards successors in another part OF THIS HANDLE are resolved
+// through that part's directory; successors owned by another rank stay listed per part (dbg_part_queries).
+template <class ST, class STI>
+static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_passes, int n_senders, const uint64_t *grp_cnt,
+                           const uint64_t *sender_off, const uint64_t *stamp_add, const uint64_t *in_w0,
+                           const uint64_t *in_w1, const STI *in_st) {
+    int shard_bits = 0;
+    while ((1 << shard_bits) < n_virtual) ++shard_bits;
+    const int bps = 512 / n_virtual;            // level-1 groups per virtual shard
+    const int own_groups = bps * n_passes;      // ... and of this handle
+    MultiPass *mp = new MultiPass();
+    h->multipass = mp;
+    mp->n_passes = n_passes;
+    mp->n_virtual = n_virtual;
+    mp->v_first = v_first;
+    mp->part.assign(n_passes, nullptr);
+    mp->col_owner.assign(n_passes, nullptr);
+    mp->base.assign(n_passes + 1, 0);
+    const int w = k - sk_m_for_k(k) + 1;
+    double ms_count = 0, ms_part = h->stats.ms_partition, ms_succ = 0;
+    uint64_t n_buckets = 0, n_queries = 0;
+    std::vector<uint64_t> p_cnt((size_t)n_senders * bps), p_off(n_senders);
+    for (int p = 0; p < n_passes; ++p) {
+        dbg *sub = new (std::nothrow) dbg();
+        if (!sub) return DBG_E_NOMEM;
+        mp->part[p] = sub;
+        sub->device = h->device;
+        sub->stream = h->stream;
+        sub->borrowed_stream = true;
+        sub->wide_owner = true;
+        sub->bucket_bits = h->bucket_bits;
+        sub->target_distinct = h->target_distinct;
+        sub->est_scale_pct = h->est_scale_pct;
+        HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));
+        sub->k = k;
+        uint64_t n_rec_p = 0;
+        for (int r = 0; r < n_senders; ++r) {
+            uint64_t before = 0;
+            for (int g = 0; g < p * bps; ++g) before += grp_cnt[(size_t)r * own_groups + g];
+            p_off[r] = sender_off[r] + before;
+            for (int b = 0; b < bps; ++b) {
+                p_cnt[(size_t)r * bps + b] = grp_cnt[(size_t)r * own_groups + (size_t)p * bps + b];
+                n_rec_p += p_cnt[(size_t)r * bps + b];
+            }
+        }
+        // level-2 output of this pass (one set: the presplit path writes set 0 only); freed again below
+        uint64_t *pw0[2] = {nullptr, nullptr}, *pw1[2] = {nullptr, nullptr};
+        ST *pst[2] = {nullptr, nullptr};
+        CHK(buf_ensure(sub, sub->ar_rec[0][0], (n_rec_p + 16) * 8));
+        CHK(buf_ensure(sub, sub->ar_rec[0][1], (n_rec_p + 16) * 8));
+        CHK(buf_ensure(sub, sub->ar_rec[0][2], (n_rec_p + 16) * sizeof(ST)));
+        pw0[0] = (uint64_t *)sub->ar_rec[0][0].p; pw1[0] = (uint64_t *)sub->ar_rec[0][1].p; pst[0] = (ST *)sub->ar_rec[0][2].p;
+        ShardState &sh = shard_of(sub);
+        sh.n_shards = n_virtual; sh.my_shard = v_first + p; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
+        sh.q_start.assign(n_virtual, 0);
+        sh.q_cnt.assign(n_virtual, 0);
+        Presplit pre;
+        pre.n_senders = n_senders;
+        pre.counts = p_cnt.data();
+        pre.recv_off = p_off.data();
+        pre.stamp_add = stamp_add;
+        pre.in_st = in_st;
+        int rc = DBG_OK;
+        if (n_rec_p)
+            rc = sk_count_from_segments<ST, 4096, STI>(sub, k, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w,
+                                                       in_w0, in_w1, (const ST *)nullptr, pw0, pw1, pst, 0, shard_bits, v_first + p, &pre);
+        if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
+        if (n_rec_p) {
+            const uint64_t own_cnt = sub->sk_n_buckets >> shard_bits;
+            rc = part_compact(sub, (own_cnt + (sub->sk_n_ranges - sub->sk_n_buckets)) * (4096 / 64));
+            if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
+        }
+        mp->base[p + 1] = mp->base[p] + sub->n_nodes;
+        if (sub->n_edges) {
+            HIPCHK(h, hipMalloc((void **)&mp->col_owner[p], sub->n_edges));
+            HIPCHK(h, hipMemsetAsync(mp->col_owner[p], v_first + p, sub->n_edges, h->stream));
+        }
+        ms_count += sub->stats.ms_count; ms_part += sub->stats.ms_partition; ms_succ += sub->stats.ms_succ;
+        n_buckets += sub->stats.n_buckets >> shard_bits; n_queries += sub->stats.n_queries;
+        h->stats.count_launches += sub->stats.count_launches;
+    }
+    // ---- successors owned by another part of this handle: the asker's queries are grouped by owner (ShardState), the
+    //      owner's directory answers them
+    {
+        Timer t(h->stream);
+        uint64_t max_q = 0;
+        for (int p = 0; p < n_passes; ++p) {
+            ShardState &sh = shard_of(mp->part[p]);
+            for (int q = 0; q < n_passes; ++q) if (q != p) max_q = std::max(max_q, sh.q_cnt[v_first + q]);
+        }
+        CHK(buf_ensure(h, h->ar_shard[2], (max_q + 16) * 4));
+        uint32_t *ans = (uint32_t *)h->ar_shard[2].p;
+        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+        for (int p = 0; p < n_passes; ++p) {
+            dbg *sub = mp->part[p];
+            ShardState &sh = shard_of(sub);
+            const uint64_t *keys = (const uint64_t *)sub->ar_shard[0].p;
+            const uint32_t *qcol = (const uint32_t *)sub->ar_shard[3].p;
+            for (int q = 0; q < n_passes; ++q) {
+                const int vq = v_first + q;
+                if (q == p || !sh.q_cnt[vq]) continue;
+                int rc = dbg_shard_answer(mp->part[q], keys + sh.q_start[vq], sh.q_cnt[vq], ans);
+                if (rc != DBG_OK) { h->err = "part " + std::to_string(q) + ": " + mp->part[q]->err; return rc; }
+                hipLaunchKernelGGL(k_apply_part, dim3(grid_for(sh.q_cnt[vq], 256)), dim3(256), 0, h->stream, qcol + sh.q_start[vq],
+                                   ans, sh.q_cnt[vq], (uint8_t)vq, sub->d_col, mp->col_owner[p], (unsigned long long *)h->d_scalars);
+            }
+            if (n_virtual == n_passes) {  // nothing is owned elsewhere: the query lists are done with
+                buf_free(sub, sub->ar_shard[0]);
+                buf_free(sub, sub->ar_shard[3]);
+            }
+        }
+        HIPCHK(h, hipGetLastError());
+        uint64_t sc0 = 0;
+        HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (sc0 & 256) { h->err = "a successor in another part came back unresolved"; return DBG_E_HIP; }
+        ms_succ += t.stop();
+    }
+    h->n_nodes = mp->base[n_passes];
+    h->n_edges = 0;
+    for (dbg *sub : mp->part) h->n_edges += sub->n_edges;
+    h->stats.ms_count = ms_count; h->stats.ms_partition = ms_part; h->stats.ms_succ = ms_succ;
+    h->stats.n_buckets = n_buckets; h->stats.n_queries = n_queries;
+    h->starts_known = false;
+    return DBG_OK;
+}
+
 template <class ST>
 static int build_multipass_t(dbg *h, int k, int n_passes) {
     uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
@@ -4608,112 +4764,10 @@ static int build_multipass_t(dbg *h, int k, int n_passes) {
         h->stats.ms_partition = t.stop();
         for (auto &b : h->ar_rec[0]) buf_free(h, b);  // the unsplit records; the split ones (set 1) stay parked for the passes
     }
-    int shard_bits = 0;
-    while ((1 << shard_bits) < n_passes) ++shard_bits;
-    const int bps = nb1 / n_passes;
-    MultiPass *mp = new MultiPass();
-    h->multipass = mp;
-    mp->n_passes = n_passes;
-    mp->part.assign(n_passes, nullptr);
-    mp->col_owner.assign(n_passes, nullptr);
-    mp->base.assign(n_passes + 1, 0);
-    const int w = k - sk_m_for_k(k) + 1;
-    double ms_count = 0, ms_part = h->stats.ms_partition, ms_succ = 0;
-    uint64_t n_buckets = 0, n_queries = 0;
-    for (int p = 0; p < n_passes; ++p) {
-        dbg *sub = new (std::nothrow) dbg();
-        if (!sub) return DBG_E_NOMEM;
-        mp->part[p] = sub;
-        sub->device = h->device;
-        sub->stream = h->stream;
-        sub->borrowed_stream = true;
-        sub->wide_owner = true;
-        sub->bucket_bits = h->bucket_bits;
-        sub->target_distinct = h->target_distinct;
-        sub->est_scale_pct = h->est_scale_pct;
-        HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));
-        sub->k = k;
-        uint64_t n_rec_p = 0;
-        for (int b = 0; b < bps; ++b) n_rec_p += cnt[(size_t)p * bps + b];
-        // level-2 output of this pass (one set: the presplit path writes set 0 only); freed again below
-        uint64_t *pw0[2] = {nullptr, nullptr}, *pw1[2] = {nullptr, nullptr};
-        ST *pst[2] = {nullptr, nullptr};
-        CHK(buf_ensure(sub, sub->ar_rec[0][0], (n_rec_p + 16) * 8));
-        CHK(buf_ensure(sub, sub->ar_rec[0][1], (n_rec_p + 16) * 8));
-        CHK(buf_ensure(sub, sub->ar_rec[0][2], (n_rec_p + 16) * sizeof(ST)));
-        pw0[0] = (uint64_t *)sub->ar_rec[0][0].p; pw1[0] = (uint64_t *)sub->ar_rec[0][1].p; pst[0] = (ST *)sub->ar_rec[0][2].p;
-        ShardState &sh = shard_of(sub);
-        sh.n_shards = n_passes; sh.my_shard = p; sh.shard_bits = shard_bits; sh.k = k; sh.n_remote = 0;
-        sh.q_start.assign(n_passes, 0);
-        sh.q_cnt.assign(n_passes, 0);
-        const uint64_t off0 = start[(size_t)p * bps], add0 = 0;
-        Presplit pre;
-        pre.n_senders = 1;
-        pre.counts = &cnt[(size_t)p * bps];
-        pre.recv_off = &off0;
-        pre.stamp_add = &add0;
-        pre.in_st = st[1];
-        int rc = DBG_OK;
-        if (n_rec_p)
-            rc = sk_count_from_segments<ST, 4096, ST>(sub, k, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w,
-                                                      w0[1], w1[1], (const ST *)nullptr, pw0, pw1, pst, 0, shard_bits, p, &pre);
-        if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
-        if (n_rec_p) {
-            const uint64_t own_cnt = sub->sk_n_buckets >> shard_bits;
-            rc = part_compact(sub, (own_cnt + (sub->sk_n_ranges - sub->sk_n_buckets)) * (4096 / 64));
-            if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
-        }
-        mp->base[p + 1] = mp->base[p] + sub->n_nodes;
-        if (sub->n_edges) {
-            HIPCHK(h, hipMalloc((void **)&mp->col_owner[p], sub->n_edges));
-            HIPCHK(h, hipMemsetAsync(mp->col_owner[p], p, sub->n_edges, h->stream));
-        }
-        ms_count += sub->stats.ms_count; ms_part += sub->stats.ms_partition; ms_succ += sub->stats.ms_succ;
-        n_buckets += sub->stats.n_buckets >> shard_bits; n_queries += sub->stats.n_queries;
-        h->stats.count_launches += sub->stats.count_launches;
-    }
-    // ---- successors owned by another part: the asker's queries are grouped by owner (ShardState), the owner's
-    //      directory answers them
-    {
-        Timer t(h->stream);
-        uint64_t max_q = 0;
-        for (int p = 0; p < n_passes; ++p) {
-            ShardState &sh = shard_of(mp->part[p]);
-            for (int q = 0; q < n_passes; ++q) if (q != p) max_q = std::max(max_q, sh.q_cnt[q]);
-        }
-        CHK(buf_ensure(h, h->ar_shard[2], (max_q + 16) * 4));
-        uint32_t *ans = (uint32_t *)h->ar_shard[2].p;
-        HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
-        for (int p = 0; p < n_passes; ++p) {
-            dbg *sub = mp->part[p];
-            ShardState &sh = shard_of(sub);
-            const uint64_t *keys = (const uint64_t *)sub->ar_shard[0].p;
-            const uint32_t *qcol = (const uint32_t *)sub->ar_shard[3].p;
-            for (int q = 0; q < n_passes; ++q) {
-                if (q == p || !sh.q_cnt[q]) continue;
-                int rc = dbg_shard_answer(mp->part[q], keys + sh.q_start[q], sh.q_cnt[q], ans);
-                if (rc != DBG_OK) { h->err = "part " + std::to_string(q) + ": " + mp->part[q]->err; return rc; }
-                hipLaunchKernelGGL(k_apply_part, dim3(grid_for(sh.q_cnt[q], 256)), dim3(256), 0, h->stream, qcol + sh.q_start[q],
-                                   ans, sh.q_cnt[q], (uint8_t)q, sub->d_col, mp->col_owner[p], (unsigned long long *)h->d_scalars);
-            }
-            buf_free(sub, sub->ar_shard[0]);
-            buf_free(sub, sub->ar_shard[3]);
-        }
-        HIPCHK(h, hipGetLastError());
-        uint64_t sc0 = 0;
-        HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (sc0 & 256) { h->err = "a successor in another part came back unresolved"; return DBG_E_HIP; }
-        ms_succ += t.stop();
-    }
+    const uint64_t off0 = start[0], add0 = 0;
+    int rc = multipass_parts<ST, ST>(h, k, n_passes, 0, n_passes, 1, cnt.data(), &off0, &add0, w0[1], w1[1], st[1]);
     for (auto &b : h->ar_rec[1]) buf_free(h, b);  // every pass has read its slice of the parked records
-    h->n_nodes = mp->base[n_passes];
-    h->n_edges = 0;
-    for (dbg *sub : mp->part) h->n_edges += sub->n_edges;
-    h->stats.ms_count = ms_count; h->stats.ms_partition = ms_part; h->stats.ms_succ = ms_succ;
-    h->stats.n_buckets = n_buckets; h->stats.n_queries = n_queries;
-    h->starts_known = false;
-    return DBG_OK;
+    return rc;
 }
 
 extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
@@ -4737,6 +4791,124 @@ extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     h->stats.ms_build_total = t_total.stop();
     h->arena_freed = true;
     pool_trim(h);
+    return DBG_OK;
+}
+
+// configs[3] on several GPUs: ranks x passes.  A rank of a sharded build whose shard outgrows one 32-bit id space (or
+// one piece of memory) builds it as n_passes parts; part p of rank r is VIRTUAL shard r * n_passes + p of
+// n_shards * n_passes, and a CSR column's owner byte holds the virtual shard.  Input as for dbg_shard_build with
+// sender_bucket_counts.  Afterwards the successors owned by other RANKS are still open: dbg_part_queries lists them per
+// part and virtual shard, the owner answers with dbg_part_answer, dbg_part_apply patches them in, dbg_multipass_finish
+// checks that nothing stayed open (multi_gpu.sharded_build_multipass runs the exchange).
+extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_shard, int n_passes, const void *d_w0,
+                                         const void *d_w1, const void *d_st, int stamp_bytes, const uint64_t *recv_counts,
+                                         const uint64_t *stamp_base, const uint64_t *sender_bucket_counts) {
+    CHK(shard_args_ok(h, k, n_shards));
+    if (k > 31) { h->err = "multi-pass builds take k in 1..31 (one-word k-mers)"; return DBG_E_ARG; }
+    if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !sender_bucket_counts) return DBG_E_ARG;
+    if (stamp_bytes != 4 && stamp_bytes != 8) { h->err = "stamp_bytes must be 4 or 8"; return DBG_E_ARG; }
+    if (n_passes < 1 || (n_passes & (n_passes - 1)) || n_shards * n_passes > 64) {
+        h->err = "n_passes must be a power of two with n_shards * n_passes <= 64";
+        return DBG_E_ARG;
+    }
+    if (h->bucket_bits && h->bucket_bits < 9) { h->err = "multi-pass builds split by 9 bits first: bucket_bits must be 0 or >= 9"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    free_build(h);
+    h->arena_freed = true;
+    pool_trim(h);
+    h->stats = dbg_stats_t{};
+    const int own_groups = 512 / n_shards;
+    std::vector<uint64_t> off(n_shards), add(n_shards);
+    uint64_t n_rec = 0;
+    for (int r = 0; r < n_shards; ++r) {
+        uint64_t tot = 0;
+        for (int g = 0; g < own_groups; ++g) tot += sender_bucket_counts[(size_t)r * own_groups + g];
+        if (tot != recv_counts[r]) { h->err = "sender_bucket_counts do not add up to recv_counts"; return DBG_E_ARG; }
+        off[r] = n_rec;
+        add[r] = stamp_base[r] << 1;
+        n_rec += recv_counts[r];
+    }
+    h->k = k;
+    h->stats.n_records = n_rec;
+    Timer t_total(h->stream);
+    int rc = stamp_bytes == 8
+                 ? multipass_parts<uint64_t, uint64_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
+                                                       off.data(), add.data(), (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)d_st)
+                 : multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
+                                                       off.data(), add.data(), (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint32_t *)d_st);
+    if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->arena_freed = true; pool_trim(h); h->err = keep; return rc; }
+    // the instance counters describe this rank's parts
+    MultiPass *mp = (MultiPass *)h->multipass;
+    h->n_kmer_inst = h->n_edge_inst = 0;
+    for (dbg *sub : mp->part) { h->n_kmer_inst += sub->n_kmer_inst; h->n_edge_inst += sub->n_edge_inst; }
+    HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 8, h->stream));
+    h->stats.ms_build_total = t_total.stop();
+    return DBG_OK;
+}
+
+static dbg *part_of(dbg *h, int part) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp || part < 0 || part >= mp->n_passes) { if (h) h->err = "no such part (a multi-pass build must run first)"; return nullptr; }
+    return mp->part[part];
+}
+
+// successor k-mers of `part` grouped by the virtual shard that owns them: group v at [q_starts[v], q_starts[v] + q_counts[v])
+// of *d_q_keys (uint64, device), v in [0, n_shards * n_passes); the groups of this rank's own parts are answered already
+extern "C" int dbg_part_queries(dbg_t *h, int part, uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys) {
+    dbg *sub = part_of(h, part);
+    if (!sub || !q_starts || !q_counts || !d_q_keys) return DBG_E_ARG;
+    MultiPass *mp = (MultiPass *)h->multipass;
+    ShardState &sh = shard_of(sub);
+    for (int v = 0; v < mp->n_virtual; ++v) {
+        const bool mine = v >= mp->v_first && v < mp->v_first + mp->n_passes;
+        q_starts[v] = v < (int)sh.q_start.size() ? sh.q_start[v] : 0;
+        q_counts[v] = (mine || v >= (int)sh.q_cnt.size()) ? 0 : sh.q_cnt[v];
+    }
+    *d_q_keys = sub->ar_shard[0].p;
+    return DBG_OK;
+}
+
+// node ids (uint32, device) of n successor k-mers another rank asked this rank's `part` about
+extern "C" int dbg_part_answer(dbg_t *h, int part, const void *d_q_keys, uint64_t n, void *d_answers) {
+    dbg *sub = part_of(h, part);
+    if (!sub) return DBG_E_ARG;
+    if (n && !sub->n_nodes) { h->err = "part " + std::to_string(part) + " is empty and cannot own a successor"; return DBG_E_ARG; }
+    int rc = dbg_shard_answer(sub, d_q_keys, n, d_answers);
+    if (rc != DBG_OK) h->err = "part " + std::to_string(part) + ": " + sub->err;
+    return rc;
+}
+
+// d_answers (uint32, device): the answers of virtual shard `owner` to this part's group of queries, in query order
+extern "C" int dbg_part_apply(dbg_t *h, int part, int owner, const void *d_answers) {
+    dbg *sub = part_of(h, part);
+    if (!sub) return DBG_E_ARG;
+    MultiPass *mp = (MultiPass *)h->multipass;
+    ShardState &sh = shard_of(sub);
+    if (owner < 0 || owner >= mp->n_virtual || owner >= (int)sh.q_cnt.size()) { h->err = "no such owner"; return DBG_E_ARG; }
+    const uint64_t n = sh.q_cnt[owner];
+    if (!n) return DBG_OK;
+    if (!d_answers || !sub->ar_shard[3].p) { h->err = "no answers / the part's queries are gone (dbg_multipass_finish ran)"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint32_t *qcol = (const uint32_t *)sub->ar_shard[3].p;
+    hipLaunchKernelGGL(k_apply_part, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, qcol + sh.q_start[owner],
+                       (const uint32_t *)d_answers, n, (uint8_t)owner, sub->d_col, mp->col_owner[part],
+                       (unsigned long long *)h->d_scalars);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // d_answers is the caller's
+    return DBG_OK;
+}
+
+extern "C" int dbg_multipass_finish(dbg_t *h) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp) { if (h) h->err = "a multi-pass build must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t sc0 = 0;
+    HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (dbg *sub : mp->part) { buf_free(sub, sub->ar_shard[0]); buf_free(sub, sub->ar_shard[3]); }
+    h->arena_freed = true;
+    pool_trim(h);
+    if (sc0 & 256) { h->err = "a successor owned by another rank came back unresolved"; return DBG_E_HIP; }
     return DBG_OK;
 }
 

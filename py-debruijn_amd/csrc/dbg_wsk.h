@@ -740,7 +740,10 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                             break;
                         }
                         if ((cur & ~W_PEND) == key.hi) {  // this k-mer or one that shares its high word
-                            if (cur & W_PEND) { ++spins; continue; }
+                            if (cur & W_PEND) {
+                                if (++spins >= (1 << 16)) atomicOr(&out.scalars[0], 1024ull);  // a claim that never completes: fail loudly
+                                continue;
+                            }
                             if (wlds_load(&s.klo[slot]) == key.lo) { ok = true; break; }
                         }
                         slot = (slot + 1) & (WCAP - 1);

@@ -181,10 +181,15 @@ def sharded_build(g, k, dist, check=True):
     # holds (stamp bases), the record layout (all ranks must agree) and how its records split over the 512 level-1
     # buckets -- the receive counts are sums of those, and the owner can start its build at the second multisplit level
     presplit = hasattr(g, "shard_bucket_counts") and (k <= 31 or words == 4)
-    meta = [g.sizes()["n_bytes"], words] + (g.shard_bucket_counts() if presplit else list(send_counts))
+    st_bytes = st.element_size()
+    meta = [g.sizes()["n_bytes"], words, st_bytes] + (g.shard_bucket_counts() if presplit else list(send_counts))
     metas = _all_gather_ints(dist, meta, device)
     if any(m_r[1] != words for m_r in metas):
         raise RuntimeError("sharded build: the ranks disagree about the record layout (different engines or input sizes)")
+    # rank-local stamps are 32-bit while a rank's reads stay below 2 GiB: a receiver takes ONE width, the widest any
+    # sender uses (a rank with narrow stamps zero-extends them: they are unsigned positions)
+    if max(m_r[2] for m_r in metas) > st_bytes:
+        st = widen_stamps(st)
     bases, acc = [], 0
     for m_r in metas:
         bases.append(acc)
@@ -192,10 +197,10 @@ def sharded_build(g, k, dist, check=True):
     sender_buckets = None
     if presplit:
         bps = 512 // w
-        sender_buckets = [m_r[2 + me * bps: 2 + (me + 1) * bps] for m_r in metas]
+        sender_buckets = [m_r[3 + me * bps: 3 + (me + 1) * bps] for m_r in metas]
         recv_counts = [sum(row) for row in sender_buckets]
     else:
-        recv_counts = [m_r[2 + me] for m_r in metas]
+        recv_counts = [m_r[3 + me] for m_r in metas]
     r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0")
     r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1")
     r_st = xc.alltoallv(st, send_counts, recv_counts, "records st")
@@ -233,6 +238,89 @@ def sharded_build(g, k, dist, check=True):
         answers = torch.empty(0, dtype=torch.int32, device=device)
     g.shard_apply(answers)
     return g
+
+
+def _exchange_records(g, k, dist, xc):
+    """Steps 1-3 of a sharded build for super-k-mer records split by the 512 level-1 groups: extract, one all-gather
+    of what the ranks must know about each other, all-to-all of the records.  -> (received w0, w1, st, recv_counts,
+    stamp bases, sender_buckets)."""
+    w, me = dist.get_world_size(), dist.get_rank()
+    send_counts, (w0, w1, st) = g.shard_extract(k, w)
+    device = w0.device
+    words = g.shard_record_layout()[0]
+    st_bytes = st.element_size()
+    metas = _all_gather_ints(dist, [g.sizes()["n_bytes"], words, st_bytes] + g.shard_bucket_counts(), device)
+    if any(m_r[1] != words for m_r in metas):
+        raise RuntimeError("sharded build: the ranks disagree about the record layout (different engines or input sizes)")
+    if max(m_r[2] for m_r in metas) > st_bytes:
+        st = widen_stamps(st)
+    bases, acc = [], 0
+    for m_r in metas:
+        bases.append(acc)
+        acc += m_r[0]
+    bps = 512 // w
+    sender_buckets = [m_r[3 + me * bps: 3 + (me + 1) * bps] for m_r in metas]
+    recv_counts = [sum(row) for row in sender_buckets]
+    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0")
+    r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1")
+    r_st = xc.alltoallv(st, send_counts, recv_counts, "records st")
+    xc.verify()
+    if not _is_gloo(dist) and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return r_w0, r_w1, r_st, recv_counts, bases, sender_buckets
+
+
+def sharded_build_multipass(g, k, dist, n_passes, check=True):
+    """Ranks x passes (BASELINE.json configs[3]: shards that outgrow one 32-bit id space): every rank builds its shard
+    as ``n_passes`` parts (dbg_shard_build_multipass); part p of rank r is virtual shard r * n_passes + p.  Successors
+    owned by another rank are resolved pass by pass -- the same p on every rank at a time: keys out, part-local node ids
+    back (two all-to-alls per pass).  Afterwards ``g.export_part(p)`` / ``g.part_tensors(p)`` hold the rank's parts with
+    ``col_part`` = the virtual shard of every successor."""
+    w, me, P = dist.get_world_size(), dist.get_rank(), int(n_passes)
+    xc = ExchangeCheck(dist) if check else _NoCheck(dist)
+    r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records(g, k, dist, xc)
+    device = r_w0.device
+    g.shard_build_multipass(k, w, me, P, r_w0, r_w1, r_st, recv_counts, bases, sender_buckets)
+    cdev = "cpu" if _is_gloo(dist) else device
+    for p in range(P):
+        q_starts, q_counts, q_keys = g.part_queries(p)
+        # what I ask every (rank, part) about; the owner learns the split of my message over its parts
+        mine = torch.tensor(q_counts, dtype=torch.int64, device=cdev)
+        theirs = torch.empty_like(mine)
+        dist.all_to_all_single(theirs, mine)          # theirs[s * P + q]: rank s asks my part q about that many k-mers
+        theirs = [int(x) for x in theirs.tolist()]
+        send = [sum(q_counts[d * P:(d + 1) * P]) for d in range(w)]
+        recv = [sum(theirs[s * P:(s + 1) * P]) for s in range(w)]
+        groups = [q_keys[q_starts[v]:q_starts[v] + q_counts[v]] for v in range(w * P) if q_counts[v]]
+        packed = torch.cat(groups) if groups else q_keys[:0]
+        keys_in = xc.alltoallv(packed, send, recv, "successor queries")
+        if not _is_gloo(dist) and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        out, pos = [], 0
+        for s in range(w):
+            for q in range(P):
+                n = theirs[s * P + q]
+                if n:
+                    out.append(g.part_answer(q, keys_in[pos:pos + n]))
+                pos += n
+        answers_out = torch.cat(out) if out else torch.empty(0, dtype=torch.int32, device=device)
+        back = xc.alltoallv(answers_out, recv, send, "successor answers")
+        xc.verify()
+        if not _is_gloo(dist) and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        pos = 0
+        for v in range(w * P):
+            n = q_counts[v]
+            if n:
+                g.part_apply(p, v, back[pos:pos + n].contiguous())
+            pos += n
+    g.multipass_finish()
+    return g
+
+
+def widen_stamps(st):
+    """32-bit rank-local stamps (unsigned, carried in an int32 tensor) -> the same values as int64."""
+    return st.to(torch.int64) & 0xFFFFFFFF
 
 
 def _all_gather_ints(dist, vals, device):

@@ -35,9 +35,10 @@ def as_i64(vals):
 class NumpyShardGraph:
     """Model of dbg_shard_* with one record per k-mer occurrence (format is opaque to multi_gpu.py)."""
 
-    def __init__(self, reads, k):
+    def __init__(self, reads, k, stamp64=False):
         self.reads, self.k = reads, k
         self.mask = (1 << (2 * k)) - 1
+        self.stamp64 = stamp64  # this rank hands out 64-bit rank-local stamps (a rank that holds 2 GiB of reads or more)
 
     def sizes(self):
         return {"n_bytes": sum(len(r) for r in self.reads)}
@@ -61,12 +62,12 @@ class NumpyShardGraph:
         recs.sort(key=lambda t: t[0])
         counts = [sum(1 for t in recs if t[0] == d) for d in range(n)]
         return counts, (as_i64([t[1] for t in recs]), as_i64([t[2] for t in recs]),
-                        torch.tensor([t[3] for t in recs], dtype=torch.int32))
+                        torch.tensor([t[3] for t in recs], dtype=torch.int64 if self.stamp64 else torch.int32))
 
     def shard_build(self, k, n, me, w0, w1, st, recv_counts, bases):
         keys = w0.numpy().view(np.uint64)
         succ = w1.numpy().view(np.uint64)
-        stl = st.numpy().view(np.uint32)
+        stl = st.numpy().view(np.uint64 if st.dtype == torch.int64 else np.uint32)  # one width for all senders
         table, seg = {}, 0
         for r, c in enumerate(recv_counts):
             for i in range(seg, seg + c):
@@ -125,6 +126,81 @@ class NumpyShardGraph:
         return torch.from_numpy(blob), torch.from_numpy(off)
 
 
+class NumpyMultipassGraph(NumpyShardGraph):
+    """Model of the ranks x passes protocol (dbg_shard_build_multipass, dbg_part_*): records grouped by the 512 level-1
+    groups (top 9 bits of the key hash), part p of rank r = virtual shard r * n_passes + p."""
+
+    def group(self, key):
+        return mix(key) >> (64 - 9)
+
+    def shard_extract(self, k, n):
+        counts, (w0, w1, st) = super().shard_extract(k, n)
+        keys = [int(x) for x in w0.numpy().view(np.uint64)]
+        order = sorted(range(len(keys)), key=lambda i: self.group(keys[i]))  # stable: owner order is kept (owner = group prefix)
+        self.l1 = [0] * 512
+        for key in keys:
+            self.l1[self.group(key)] += 1
+        idx = torch.tensor(order, dtype=torch.int64)
+        return counts, (w0[idx], w1[idx], st[idx])
+
+    def shard_record_layout(self):
+        return 1, 8 if self.stamp64 else 4
+
+    def shard_bucket_counts(self):
+        return list(self.l1)
+
+    def shard_build_multipass(self, k, n, me, n_passes, w0, w1, st, recv_counts, bases, sender_buckets):
+        assert [sum(row) for row in sender_buckets] == list(recv_counts)
+        super().shard_build(k, n, me, w0, w1, st, recv_counts, bases)  # the whole shard's table; the parts cut it by hash
+        nv = n * n_passes
+        bits = nv.bit_length() - 1
+        virt = lambda key: (mix(key) >> (64 - bits)) if bits else 0
+        self.nv, self.P, self.v_first = nv, n_passes, me * n_passes
+        self.parts = []
+        for p in range(n_passes):
+            sel = [i for i, key in enumerate(self.node_keys) if virt(key) == self.v_first + p]
+            keys = [self.node_keys[i] for i in sel]
+            self.parts.append({"keys": keys, "ids": {key: j for j, key in enumerate(keys)},
+                               "stamps": self.stamps[sel], "counts": self.counts[sel],
+                               "succ_part": np.full((len(sel), 4), 255, dtype=np.uint8),
+                               "succ_id": np.full((len(sel), 4), 0xFFFFFFFF, dtype=np.uint32), "queries": None})
+        for p, d in enumerate(self.parts):
+            groups = [[] for _ in range(nv)]
+            for j, key in enumerate(d["keys"]):
+                for code in range(4):
+                    if d["counts"][j, code]:
+                        sk = ((key << 2) | code) & self.mask
+                        v = virt(sk)
+                        if self.v_first <= v < self.v_first + n_passes:  # a part of this rank: resolved here
+                            d["succ_part"][j, code] = v
+                            d["succ_id"][j, code] = self.parts[v - self.v_first]["ids"][sk]
+                        else:
+                            groups[v].append((sk, j * 4 + code))
+            d["queries"] = groups
+
+    def part_queries(self, p):
+        groups = self.parts[p]["queries"]
+        counts = [len(gq) for gq in groups]
+        starts = [sum(counts[:v]) for v in range(self.nv)]
+        return starts, counts, as_i64([sk for gq in groups for sk, _ in gq])
+
+    def part_answer(self, q, keys):
+        ids = self.parts[q]["ids"]
+        return torch.tensor([ids[int(x)] for x in keys.numpy().view(np.uint64)], dtype=torch.int32)
+
+    def part_apply(self, p, owner, answers):
+        d = self.parts[p]
+        slots = [slot for _, slot in d["queries"][owner]]
+        assert len(slots) == answers.numel()
+        for slot, a in zip(slots, answers.tolist()):
+            d["succ_part"].reshape(-1)[slot] = owner
+            d["succ_id"].reshape(-1)[slot] = a
+        d["queries"][owner] = []
+
+    def multipass_finish(self):
+        assert all(not gq for d in self.parts for gq in d["queries"]), "a successor owned by another rank stayed open"
+
+
 class NumpyMergedGraph:
     """Model of dbg_import_graph: concatenated shard arrays, successor ids rewritten to global positions."""
 
@@ -149,6 +225,19 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     per = n_reads // world
     reads = synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01, first_read=rank * per)
+    if mode == "fake_mp":  # ranks x passes over gloo: the parts of this rank, one npz entry per array and part
+        n_passes = int(os.environ.get("SHARD_PASSES", "2"))
+        g = NumpyMultipassGraph([row.tobytes().decode() for row in reads], k, stamp64=(rank == 0))
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        out = {}
+        for p, d in enumerate(g.parts):
+            out[f"keys{p}"] = np.array(d["keys"], dtype=np.uint64)
+            out[f"stamps{p}"], out[f"counts{p}"] = d["stamps"], d["counts"].reshape(-1, 4)
+            out[f"succ_part{p}"], out[f"succ_id{p}"] = d["succ_part"], d["succ_id"]
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **out)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "fake":
         g = NumpyShardGraph([row.tobytes().decode() for row in reads], k)
         multi_gpu.sharded_build(g, k, dist)

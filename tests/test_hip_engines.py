@@ -256,19 +256,20 @@ def test_two_word_engine_counter_overflow_falls_back():
     assert g.stats()["n_records"] == 0  # the fallback engine has no records
 
 
-def test_two_word_engine_ragged_reads():
-    """Variable-length reads (including len <= k, len == k + 1 and empty) packed back to back, k = 40."""
-    rng = np.random.default_rng(6)
+@pytest.mark.parametrize("k", [40, 63])
+def test_two_word_engine_ragged_reads(k):
+    """Variable-length reads (including len < k, len == k, len == k + 1 and empty) packed back to back; k = 40 goes
+    through the doubling-table extraction, k = 63 through the register kernel (k_wsk_extract_w<51>)."""
+    rng = np.random.default_rng(6 + k)
     genome = synth.reads_ascii(10, 6000, 1, 6000, 0.0)[0]
     reads = []
-    for _ in range(2500):
-        L = int(rng.integers(0, 130))
+    for i in range(4000):
+        L = int(rng.integers(0, 130)) if i % 7 else int(rng.choice([0, k - 1, k, k + 1, 2 * k]))
         s = int(rng.integers(0, 6000 - 130))
         reads.append(genome[s:s + L])
     blob = np.concatenate(reads) if reads else np.zeros(0, np.uint8)
     off = np.zeros(len(reads) + 1, dtype=np.uint64)
     np.cumsum([r.size for r in reads], out=off[1:])
-    k = 40
     want = orc_c.build(blob, off, k)
     g = _dbg.Graph()
     g.set_reads(blob, off)

@@ -155,3 +155,68 @@ def test_more_than_two_to_the_32_nodes_on_one_gpu():
         del rp, deg, present, popc, stamps, pos
     assert total_cnt == sz["n_edge_instances"]                               # every (k+1)-mer instance counted once
     assert total_starts == sz["n_starts"]
+
+
+def rank_reads(world, rank, n_reads, read_len, seed=31):
+    per = n_reads // world
+    return synth.reads_ascii(seed, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01, first_read=rank * per)
+
+
+@pytest.mark.parametrize("ranks,n_passes,k,n_reads,read_len,wide_stamp_ranks",
+                         [(2, 4, 31, 8000, 150, ()), (4, 4, 21, 8000, 100, ()), (8, 8, 31, 16000, 150, ()),
+                          (8, 1, 31, 8000, 150, ()), (1, 4, 31, 6000, 150, ()), (4, 2, 31, 8000, 150, (0, 3)),
+                          (2, 2, 21, 6000, 100, (0, 1))])
+def test_ranks_times_passes_equal_the_oracle(ranks, n_passes, k, n_reads, read_len, wide_stamp_ranks):
+    """BASELINE.json configs[3] in miniature: a sharded build whose ranks build their shards in passes
+    (multi_gpu.sharded_build_multipass through the C ABI; `ranks` handles on cuda:0, one thread each, in-process
+    exchange).  The union of all parts of all ranks == the C oracle, and every successor (virtual shard = rank * passes +
+    part, local id) -- resolved inside a part, across the parts of a rank, or across ranks -- is the shifted k-mer."""
+    import inproc_dist
+    import multi_gpu
+
+    def one(dist, rank):
+        reads = rank_reads(ranks, rank, n_reads, read_len)
+        g = _dbg.Graph(device=0)
+        if rank in wide_stamp_ranks:
+            g.set_option("shard_stamp64", 1)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        assert g.part_count() == n_passes
+        parts = gather_parts(g)
+        sz = g.sizes()
+        with pytest.raises(_dbg.DbgError, match="multi-pass"):
+            g.prune(2)
+        g.close()
+        return parts, sz
+
+    got = inproc_dist.run_ranks(ranks, one)
+    parts = [d for rank_parts, _ in got for d in rank_parts]      # index = virtual shard
+    assert len(parts) == ranks * n_passes
+    all_reads = np.concatenate([rank_reads(ranks, r, n_reads, read_len) for r in range(ranks)])
+    want = orc_c.build(all_reads.reshape(-1), np.arange(0, all_reads.size + 1, read_len, dtype=np.uint64), k)
+    keys = np.concatenate([d["keys"] for d in parts])
+    stamps = np.concatenate([d["stamps"] for d in parts])
+    counts = np.concatenate([dense_counts(d) for d in parts])
+    assert keys.size == want["n_nodes"] == sum(sz["n_nodes"] for _, sz in got)
+    assert sum(sz["n_kmer_instances"] for _, sz in got) == want["n_kmer_instances"]
+    assert sum(sz["n_edge_instances"] for _, sz in got) == want["n_edge_instances"]
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(counts[o], want["counts"])
+    mask = np.uint64((1 << (2 * k)) - 1)
+    crossing = 0
+    for v, d in enumerate(parts):
+        e = d["row_ptr"][:-1].astype(np.int64).copy()
+        for code in range(4):
+            has = ((d["flags"] >> (1 + code)) & 1).astype(bool)
+            cols, owners = d["col"][e[has]], d["col_part"][e[has]]
+            assert owners.size == 0 or int(owners.max()) < len(parts)
+            got_keys = np.empty(cols.size, dtype=np.uint64)
+            for q, dq in enumerate(parts):
+                sel = owners == q
+                assert np.all(cols[sel] < dq["keys"].size)
+                got_keys[sel] = dq["keys"][cols[sel]]
+            assert np.array_equal(got_keys, ((d["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+            crossing += int((owners // n_passes != v // n_passes).sum())
+            e[has] += 1
+    assert ranks == 1 or crossing > 0  # the exchange between ranks really carried successors

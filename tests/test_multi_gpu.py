@@ -92,25 +92,89 @@ def test_exchange_logic_on_cpu_gloo(world, max_msg, tmp_path):
         assert np.all(m["succ"][~has, code] == 0xFFFFFFFF)
 
 
+def test_ranks_times_passes_on_cpu_gloo(tmp_path):
+    """multi_gpu.sharded_build_multipass with real torch.distributed (gloo, 2 processes x 2 passes; rank 0 hands out
+    64-bit stamps): same checks as the in-process run below."""
+    world, n_passes, k, n_reads, read_len = 2, 2, 9, 64, 40
+    files = run_ranks("fake_mp", world, tmp_path, k, n_reads, read_len)
+    parts = [{key: f[f"{key}{p}"] for key in ("keys", "stamps", "counts", "succ_part", "succ_id")} for f in files for p in range(n_passes)]
+    reads = np.concatenate([rank_reads(world, r, n_reads, read_len) for r in range(world)])
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
+    keys = np.concatenate([d["keys"] for d in parts])
+    stamps = np.concatenate([d["stamps"] for d in parts])
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(np.concatenate([d["counts"] for d in parts])[o], want["counts"])
+    mask = np.uint64((1 << (2 * k)) - 1)
+    for d in parts:
+        for code in range(4):
+            has = d["counts"][:, code] != 0
+            got = np.array([parts[q]["keys"][i] for q, i in zip(d["succ_part"][has, code], d["succ_id"][has, code])], dtype=np.uint64)
+            assert np.array_equal(got, ((d["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+
+
 def rank_reads(world, rank, n_reads, read_len):
     per = n_reads // world
     return synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01, first_read=rank * per)
 
 
-def test_eight_ranks_in_process_exchange_logic_on_cpu():
+@pytest.mark.parametrize("wide_stamp_ranks", [(), (2, 5), tuple(range(8))])
+def test_eight_ranks_in_process_exchange_logic_on_cpu(wide_stamp_ranks):
     """Three owner bits (8 logical shards, host-side exchange): the real multi_gpu.sharded_build
-    on eight threads of this process around the numpy model of the device steps, checksummed exchanges included."""
+    on eight threads of this process around the numpy model of the device steps, checksummed exchanges included.
+    wide_stamp_ranks: ranks whose rank-local stamps are 64-bit (they hold 2 GiB of reads or more) -- the others widen
+    theirs before the exchange, a receiver sees one width."""
     import multi_gpu
     import shard_worker
     k, n_reads, read_len = 9, 128, 40
 
     def one(dist, rank):
-        g = shard_worker.NumpyShardGraph([row.tobytes().decode() for row in rank_reads(8, rank, n_reads, read_len)], k)
+        g = shard_worker.NumpyShardGraph([row.tobytes().decode() for row in rank_reads(8, rank, n_reads, read_len)], k,
+                                         stamp64=rank in wide_stamp_ranks)
         multi_gpu.sharded_build(g, k, dist)
         keys, stamps, counts, succ = g.export()
         return {"keys": keys, "keys_hi": np.zeros_like(keys), "stamps": stamps, "counts": counts, "succ": succ}
 
     check(inproc_dist.run_ranks(8, one), 8, k, n_reads, read_len)
+
+
+@pytest.mark.parametrize("ranks,n_passes,wide_stamp_ranks", [(4, 2, ()), (2, 4, (1,)), (8, 1, ()), (1, 4, ())])
+def test_ranks_times_passes_exchange_logic_on_cpu(ranks, n_passes, wide_stamp_ranks):
+    """multi_gpu.sharded_build_multipass (BASELINE.json configs[3]: ranks x passes) around the numpy model of
+    dbg_shard_build_multipass / dbg_part_*: the parts of all ranks together hold every k-mer of the reads once, with
+    the counts of a single table, and every successor -- same part, another part of the rank, another rank -- names
+    (virtual shard, local id) of the shifted k-mer."""
+    import multi_gpu
+    import shard_worker
+    k, n_reads, read_len = 9, 96, 40
+
+    def one(dist, rank):
+        g = shard_worker.NumpyMultipassGraph([row.tobytes().decode() for row in rank_reads(ranks, rank, n_reads, read_len)], k,
+                                             stamp64=rank in wide_stamp_ranks)
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        return g.parts
+
+    parts = [d for rank_parts in inproc_dist.run_ranks(ranks, one) for d in rank_parts]  # index = virtual shard
+    assert len(parts) == ranks * n_passes
+    reads = np.concatenate([rank_reads(ranks, r, n_reads, read_len) for r in range(ranks)])
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
+    keys = np.array([key for d in parts for key in d["keys"]], dtype=np.uint64)
+    stamps = np.concatenate([d["stamps"] for d in parts])
+    counts = np.concatenate([d["counts"].reshape(-1, 4) for d in parts])
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(counts[o], want["counts"])
+    mask, crossing = (1 << (2 * k)) - 1, 0
+    for v, d in enumerate(parts):
+        for j, key in enumerate(d["keys"]):
+            for code in range(4):
+                if d["counts"][j, code]:
+                    q, i = int(d["succ_part"][j, code]), int(d["succ_id"][j, code])
+                    assert parts[q]["keys"][i] == ((key << 2) | code) & mask
+                    crossing += q // n_passes != v // n_passes
+                else:
+                    assert d["succ_id"][j, code] == 0xFFFFFFFF
+    assert ranks == 1 or crossing > 0
 
 
 def test_damaged_exchange_is_detected():
@@ -140,11 +204,15 @@ def test_damaged_exchange_is_detected():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,n_reads,read_len,bucket_bits", [(31, 24000, 150, 0), (21, 8000, 100, 0), (63, 8000, 150, 0),
-                                                            (31, 8000, 150, 21)])  # 21 bits: 9 (senders) + 10 + 2, third level
-def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len, bucket_bits):
+@pytest.mark.parametrize("k,n_reads,read_len,bucket_bits,wide_stamp_ranks",
+                         [(31, 24000, 150, 0, ()), (21, 8000, 100, 0, ()), (63, 8000, 150, 0, ()),
+                          (31, 8000, 150, 21, ()),  # 21 bits: 9 (senders) + 10 + 2, third level
+                          (31, 24000, 150, 0, (1, 6)), (21, 8000, 100, 0, tuple(range(8)))])
+def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len, bucket_bits, wide_stamp_ranks):
     """shard_bits = 3 through the C ABI before a real 8-GPU node sees it: eight handles on cuda:0, one thread per rank,
-    the real multi_gpu.sharded_build with an in-process exchange; union of the shards == the C oracle."""
+    the real multi_gpu.sharded_build with an in-process exchange; union of the shards == the C oracle.
+    wide_stamp_ranks: ranks that hand out 64-bit rank-local stamps ("shard_stamp64": what a rank holding 2 GiB of reads or
+    more does by itself)."""
     import _dbg
     import multi_gpu
 
@@ -153,6 +221,8 @@ def test_eight_shards_in_process_on_one_gpu(k, n_reads, read_len, bucket_bits):
         g = _dbg.Graph(device=0)
         if bucket_bits:
             g.set_option("bucket_bits", bucket_bits)
+        if rank in wide_stamp_ranks:
+            g.set_option("shard_stamp64", 1)
         g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
         multi_gpu.sharded_build(g, k, dist)
         keys, stamps, counts, _ = g.export_nodes()
