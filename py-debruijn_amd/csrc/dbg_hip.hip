@@ -3784,8 +3784,12 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
             const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);
             uint32_t split_recs = 0;
             if (est_distinct > 0.0) split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(16.0, (WCAP * 0.80) / (est_distinct / (double)n_rec)));
+            // descriptor in device memory (see fresh_args): words 64.. of the scalar block are reserved for it
+            static_assert(sizeof(WSkCountOut) <= 64 * 8, "descriptor slot");
+            WSkCountOut *d_out = (WSkCountOut *)(h->d_scalars + 64);
+            HIPCHK(h, hipMemcpyAsync(d_out, &out, sizeof(out), hipMemcpyHostToDevice, h->stream));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WCNT_NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where], st[where],
-                               (const uint4 *)rec_b, k, n_buckets, out, split_recs);
+                               (const uint4 *)rec_b, k, n_buckets, (const WSkCountOut *)d_out, split_recs);
             HIPCHK(h, hipGetLastError());
         }
         h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;

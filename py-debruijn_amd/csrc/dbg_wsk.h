@@ -60,7 +60,8 @@ __device__ inline uint32_t wkmer_bucket22(K128 kmer, int k, int m) {
 
 constexpr int WCAP = 4096;                                              // LDS table slots per bucket
 // table slot and hash sub-range of a two-word k-mer: a multiplicative fold of the four 32-bit halves (k128_hash, two
-// 64-bit mixes, cost ~40 instructions per insert and per successor lookup)
+// 64-bit mixes, cost ~40 instructions per insert and per successor lookup).  A cheaper fold -- the halves rotated and
+// xor-ed, two multiplies instead of five -- was measured slower (28.5 vs 27.6 ms at k = 63): its probe runs are longer.
 __device__ inline uint32_t wfold32(K128 a) {
     return (uint32_t)a.lo * 0x9E3779B1u ^ (uint32_t)(a.lo >> 32) * 0x85EBCA77u ^ (uint32_t)a.hi * 0xC2B2AE3Du ^
            (uint32_t)(a.hi >> 32) * 0x27D4EB2Fu;
@@ -515,6 +516,13 @@ struct WSkCountOut {
     unsigned long long *scalars;  // [0] err [4] nodes | edges << 32 [5] queries [6] extra ranges
 };
 
+typedef const WSkCountOut __attribute__((address_space(4))) *WSkOutConstPtr;
+__device__ inline WSkOutConstPtr wfresh_args(const WSkCountOut *p) {  // see fresh_args (dbg_sk.h)
+    unsigned long long v = (unsigned long long)p;
+    asm volatile("" : "+s"(v));
+    return (WSkOutConstPtr)v;
+}
+
 __device__ inline void wcnt_load(const uint32_t *cnt2, uint32_t slot, uint32_t c[4]) {
     const uint2 v = reinterpret_cast<const uint2 *>(cnt2)[slot];
     c[0] = v.x & 0xFFFFu; c[1] = v.x >> 16; c[2] = v.y & 0xFFFFu; c[3] = v.y >> 16;
@@ -547,7 +555,8 @@ template <class ST>
 __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restrict__ b_start, const uint64_t *__restrict__ b_cnt,
                                                       const uint64_t *__restrict__ rec_w0, const uint64_t *__restrict__ rec_w1,
                                                       const ST *__restrict__ rec_st, const uint4 *__restrict__ rec_b /* k_wsk_gather */,
-                                                      int k, uint64_t n_buckets, WSkCountOut out, uint32_t split_recs) {
+                                                      int k, uint64_t n_buckets, const WSkCountOut *__restrict__ outp /* in device memory: see fresh_args, dbg_sk.h */,
+                                                      uint32_t split_recs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wcnt_raw[];
     WCntLds<ST> &s = *reinterpret_cast<WCntLds<ST> *>(wcnt_raw);
     constexpr int NPT = WCAP / WCNT_NT;
@@ -741,7 +750,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                         }
                         if ((cur & ~W_PEND) == key.hi) {  // this k-mer or one that shares its high word
                             if (cur & W_PEND) {
-                                if (++spins >= (1 << 16)) atomicOr(&out.scalars[0], 1024ull);  // a claim that never completes: fail loudly
+                                if (++spins >= (1 << 16)) atomicOr(&wfresh_args(outp)->scalars[0], 1024ull);  // a claim that never completes: fail loudly
                                 continue;
                             }
                             if (wlds_load(&s.klo[slot]) == key.lo) { ok = true; break; }
@@ -756,7 +765,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                             atomicAdd(&s.cnt2[slot * 2 + (b >> 1)], mult << shf);  // and nobody waits for the old value
                         } else {
                             const uint32_t old = atomicAdd(&s.cnt2[slot * 2 + (b >> 1)], mult << shf);
-                            if (((old >> shf) & 0xFFFFu) + mult > 0xFFFFu) atomicOr(&out.scalars[0], 512ull);  // 16-bit counter overflow
+                            if (((old >> shf) & 0xFFFFu) + mult > 0xFFFFu) atomicOr(&wfresh_args(outp)->scalars[0], 512ull);  // 16-bit counter overflow
                         }
                     }
                     atomicMin(&s.stamp[slot], stamp);
@@ -776,7 +785,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
                 const uint32_t bit = cur_mask + 1;
                 if (stk_n + 2 > CNT_STACK || bit >= (1u << 20)) {
-                    if (threadIdx.x == 0) atomicOr(&out.scalars[0], 8ull);
+                    if (threadIdx.x == 0) atomicOr(&wfresh_args(outp)->scalars[0], 8ull);
                     failed = true;
                     break;
                 }
@@ -840,7 +849,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             const uint32_t n_local = s.n_local & 0xFFFFu, n_edges_local = s.n_local >> 16;
             unsigned long long got = 0;
             if (threadIdx.x == 0)
-                got = atomicAdd(&out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
+                got = atomicAdd(&wfresh_args(outp)->scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
             // ---- successor lookups into registers; misses are staged as queries
             unsigned long long nsucc[NPT];
 #pragma unroll
@@ -892,15 +901,16 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             }
             CNT_TICK(8);
             if (threadIdx.x == 0) {
+                const auto &orr = *wfresh_args(outp);
                 const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
                 s.gbase = base;
                 s.ebase = eb;
-                if (base + n_local > out.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
-                if (eb + n_edges_local > out.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 16ull); s.fail = 1; }
+                if (base + n_local > orr.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
+                if (eb + n_edges_local > orr.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
                 uint64_t ri = bucket;
                 if (cur_mask) {
-                    ri = out.n_buckets + atomicAdd(&out.scalars[6], 1ull);
-                    if (ri >= out.range_cap || ri >= 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 32ull); s.fail = 1; }
+                    ri = orr.n_buckets + atomicAdd(&orr.scalars[6], 1ull);
+                    if (ri >= orr.range_cap || ri >= 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
                 }
                 s.ri = ri;
                 if (!s.fail) {
@@ -908,10 +918,10 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                     rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
                     rg.next = 0; rg.pad = 0;
                     if (cur_mask) {
-                        rg.next = out.ranges[bucket].next;
-                        out.ranges[bucket].next = (uint32_t)ri;
+                        rg.next = orr.ranges[bucket].next;
+                        orr.ranges[bucket].next = (uint32_t)ri;
                     }
-                    out.ranges[ri] = rg;
+                    orr.ranges[ri] = rg;
                 }
             }
             CNT_TICK(9);
@@ -919,7 +929,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             CNT_TICK(10);
             const uint32_t nq = s.n_q;
             unsigned long long qgot = 0;
-            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&out.scalars[5], (unsigned long long)nq);
+            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&wfresh_args(outp)->scalars[5], (unsigned long long)nq);
             if (s.fail) break;
             const uint64_t gbase = s.gbase, ebase = s.ebase;
             if (stk_n == 0 && !have_pf) {  // uniform: last pass of this bucket, the registers hold the next one's first round
@@ -927,13 +937,14 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 staged = true;
             }
             // ---- write nodes and their CSR rows; every slot read is cleared for the next bucket
+            const auto &ow = *wfresh_args(outp);  // loaded here, not kept in SGPRs across the whole bucket loop
             if (threadIdx.x < WCAP / 64) {
                 SkDirEnt de;
                 de.mask = s.dir_mask[threadIdx.x];
                 de.base = (uint32_t)(gbase + s.dir_base[threadIdx.x]);
-                de.pad = s.ri < out.n_buckets ? 1u : 0u;
-                const uint64_t di = s.ri < out.n_buckets ? s.ri - out.own_lo : out.own_cnt + (s.ri - out.n_buckets);
-                out.dirs[di * (WCAP / 64) + threadIdx.x] = de;
+                de.pad = s.ri < ow.n_buckets ? 1u : 0u;
+                const uint64_t di = s.ri < ow.n_buckets ? s.ri - ow.own_lo : ow.own_cnt + (s.ri - ow.n_buckets);
+                ow.dirs[di * (WCAP / 64) + threadIdx.x] = de;
             }
 #pragma unroll
             for (int u = 0; u < NPT; ++u) {
@@ -949,27 +960,28 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 s.khi[i] = EMPTY_KEY;
                 s.stamp[i] = (ST)~(ST)0;
                 reinterpret_cast<uint2 *>(s.cnt2)[i] = make_uint2(0, 0);
-                out.keys[node] = klo;
-                out.keys_hi[node] = khi;
-                reinterpret_cast<ST *>(out.stamps)[node] = stamp;
-                out.flags[node] = (uint8_t)((uint32_t)(stamp & 1) | ((c[0] != 0) << 1) | ((c[1] != 0) << 2) | ((c[2] != 0) << 3) |
+                ow.keys[node] = klo;
+                ow.keys_hi[node] = khi;
+                reinterpret_cast<ST *>(ow.stamps)[node] = stamp;
+                ow.flags[node] = (uint8_t)((uint32_t)(stamp & 1) | ((c[0] != 0) << 1) | ((c[1] != 0) << 2) | ((c[2] != 0) << 3) |
                                             ((c[3] != 0) << 4));
                 uint64_t e = ebase + s.eoff[li];
-                out.rowptr[node] = (uint32_t)e;
+                ow.rowptr[node] = (uint32_t)e;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     if (c[b]) {
                         const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
-                        out.col[e] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
-                        out.ecnt[e] = c[b];
+                        ow.col[e] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
+                        ow.ecnt[e] = c[b];
                         ++e;
                     }
                 }
             }
             CNT_TICK(11);
+            const auto &oq = *wfresh_args(outp);
             if (threadIdx.x == 64 && nq) {
                 s.qbase = qgot;
-                if (qgot + nq > out.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&out.scalars[0], 64ull); s.fail = 1; }
+                if (qgot + nq > oq.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&oq.scalars[0], 64ull); s.fail = 1; }
             }
             __syncthreads();
             CNT_TICK(12);
@@ -977,9 +989,9 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
             if (nq) {
                 const uint64_t qbase = s.qbase;
                 for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)WCNT_QBUF); i += WCNT_NT) {
-                    out.q_lo[qbase + i] = s.q_lo[i];
-                    out.q_hi[qbase + i] = s.q_hi[i];
-                    out.q_col[qbase + i] = (uint32_t)(ebase + s.q_off[i]);
+                    oq.q_lo[qbase + i] = s.q_lo[i];
+                    oq.q_hi[qbase + i] = s.q_hi[i];
+                    oq.q_col[qbase + i] = (uint32_t)(ebase + s.q_off[i]);
                 }
                 if (nq > (uint32_t)WCNT_QBUF) {  // rare: queries that did not fit the staging, straight from the registers
 #pragma unroll
@@ -993,10 +1005,10 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                             if (v >= 0x8000u && v < 0xFFFEu) {
                                 const uint64_t qi = (uint64_t)(v & 0x7FFFu) + WCNT_QBUF;
                                 const uint64_t node = gbase + li;
-                                const K128 sk = k128_append(K128{out.keys_hi[node], out.keys[node]}, (uint32_t)b, k);
-                                out.q_lo[qbase + qi] = sk.lo;
-                                out.q_hi[qbase + qi] = sk.hi;
-                                out.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
+                                const K128 sk = k128_append(K128{oq.keys_hi[node], oq.keys[node]}, (uint32_t)b, k);
+                                oq.q_lo[qbase + qi] = sk.lo;
+                                oq.q_hi[qbase + qi] = sk.hi;
+                                oq.q_col[qbase + qi] = (uint32_t)(ebase + s.eoff[li] + rank);
                             }
                             if (v != 0xFFFFu) ++rank;
                         }
