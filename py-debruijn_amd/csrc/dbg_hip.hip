@@ -134,6 +134,7 @@ struct dbg {
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
     int shard_stamp64 = 0;    // option: dbg_shard_extract hands out 64-bit rank-local stamps even below 2 GiB of reads (tests)
+    int extract_generic = 0;  // option: 1 = the window-minimum-through-LDS extraction kernels instead of the per-window register ones (A/B, tests)
     uint64_t sk_n_ranges = 0, sk_n_buckets = 0;
     SkGeom sk_geom{};            // hash -> bucket mapping of the last partitioned build (k_succ_resolve)
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
@@ -2021,6 +2022,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "estimate_scale_pct" && value >= 1 && value <= 1000) { h->est_scale_pct = (int)value; return DBG_OK; }
     if (n == "target_distinct" && value >= 0 && value <= 4096) { h->target_distinct = (int)value; return DBG_OK; }
     if (n == "shard_stamp64" && (value == 0 || value == 1)) { h->shard_stamp64 = (int)value; return DBG_OK; }
+    if (n == "extract_generic" && (value == 0 || value == 1)) { h->extract_generic = (int)value; return DBG_OK; }
     if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
@@ -3096,15 +3098,22 @@ static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2]
         HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
         if (tiles) {
-            if (m == SK_MAX_M && w == 19)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 19>), dim3(n_wg), dim3(256), 0, h->stream,
-                                   h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt,
-                                   seg_nk, seg_ne, sc_dev);
-            else if (m == SK_MAX_M && w == 9)
-                hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, 9>), dim3(n_wg), dim3(256), 0, h->stream,
-                                   h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt,
-                                   seg_nk, seg_ne, sc_dev);
-            else
+            // m = 13 (k >= 13): the register kernel, one instantiation per window w = k - 12 in 1..19 -- the kernel that
+            // looks the w hashes of every position up in LDS takes 12.5-15.6 ms at k = 23..30 where these take 3.3-3.7
+            bool launched = false;
+            if (m == SK_MAX_M && !h->extract_generic) {
+#define DBG_EXW_CASE(W_) case W_: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, W_>), dim3(n_wg), dim3(256), 0, h->stream, \
+                                                      h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, \
+                                                      seg_nk, seg_ne, sc_dev); launched = true; break;
+                switch (w) {
+                    DBG_EXW_CASE(1) DBG_EXW_CASE(2) DBG_EXW_CASE(3) DBG_EXW_CASE(4) DBG_EXW_CASE(5) DBG_EXW_CASE(6) DBG_EXW_CASE(7)
+                    DBG_EXW_CASE(8) DBG_EXW_CASE(9) DBG_EXW_CASE(10) DBG_EXW_CASE(11) DBG_EXW_CASE(12) DBG_EXW_CASE(13)
+                    DBG_EXW_CASE(14) DBG_EXW_CASE(15) DBG_EXW_CASE(16) DBG_EXW_CASE(17) DBG_EXW_CASE(18) DBG_EXW_CASE(19)
+                    default: break;
+                }
+#undef DBG_EXW_CASE
+            }
+            if (!launched)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases,
                                    h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk,
                                    seg_ne, sc_dev);
@@ -3514,7 +3523,7 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
     if (pk_words)
         hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, pk_words, pk);
     const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
-    const bool reg_kernel = (w == 51);  // k = 63: the register kernel (256 threads, several workgroups per CU)
+    const bool reg_kernel = (w >= 20 && w <= 51) && !h->extract_generic;  // k = 32..63: the register kernel (256 threads, several workgroups per CU)
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), reg_kernel ? 2048 : 1024);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
     uint64_t *seg_start = (uint64_t *)h->ar_misc[0].p, *seg_cnt = seg_start + n_wg, *seg_nk = seg_cnt + n_wg, *seg_ne = seg_nk + n_wg;
@@ -3538,9 +3547,20 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
         HIPCHK(h, hipMemcpyAsync(seg_start, hseg.data(), (size_t)n_wg * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemsetAsync(seg_cnt, 0, (size_t)n_wg * 3 * 8, h->stream));
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
-        if (tiles && reg_kernel) {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wsk_extract_w<ST, 51>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases, h->n_bytes,
-                               h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
+        if (tiles && reg_kernel) {  // one instantiation per window w = k - 12 (the doubling-table kernel stays as the generic fallback)
+#define DBG_WEXW_CASE(W_) case W_: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wsk_extract_w<ST, W_>), dim3(n_wg), dim3(256), 0, h->stream, \
+                                                       h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, \
+                                                       seg_nk, seg_ne, sc_dev); break;
+            switch (w) {
+                DBG_WEXW_CASE(20) DBG_WEXW_CASE(21) DBG_WEXW_CASE(22) DBG_WEXW_CASE(23) DBG_WEXW_CASE(24) DBG_WEXW_CASE(25)
+                DBG_WEXW_CASE(26) DBG_WEXW_CASE(27) DBG_WEXW_CASE(28) DBG_WEXW_CASE(29) DBG_WEXW_CASE(30) DBG_WEXW_CASE(31)
+                DBG_WEXW_CASE(32) DBG_WEXW_CASE(33) DBG_WEXW_CASE(34) DBG_WEXW_CASE(35) DBG_WEXW_CASE(36) DBG_WEXW_CASE(37)
+                DBG_WEXW_CASE(38) DBG_WEXW_CASE(39) DBG_WEXW_CASE(40) DBG_WEXW_CASE(41) DBG_WEXW_CASE(42) DBG_WEXW_CASE(43)
+                DBG_WEXW_CASE(44) DBG_WEXW_CASE(45) DBG_WEXW_CASE(46) DBG_WEXW_CASE(47) DBG_WEXW_CASE(48) DBG_WEXW_CASE(49)
+                DBG_WEXW_CASE(50) DBG_WEXW_CASE(51)
+                default: break;
+            }
+#undef DBG_WEXW_CASE
         } else if (tiles) {
             auto ekern = k_wsk_extract<ST>;
             HIPCHK(h, hipFuncSetAttribute((const void *)ekern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WSkLds)));

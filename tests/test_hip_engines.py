@@ -279,3 +279,41 @@ def test_two_word_engine_ragged_reads(k):
     o = np.argsort(stamps, kind="stable")
     assert np.array_equal(keys[o], want["keys"]) and np.array_equal(g.export_keys_hi()[o], want["keys_hi"])
     assert np.array_equal(counts[o], want["counts"]) and np.array_equal(stamps[o], want["stamps"])
+
+
+@pytest.mark.parametrize("k", list(range(13, 64)))
+def test_every_window_width_both_extraction_kernels(k):
+    """One register extraction kernel per window w = k - 12 (k_sk_extract_w<1..19>, k_wsk_extract_w<20..51>) and the
+    generic kernels that take the window minimum through LDS ("extract_generic"): both against the C oracle, on ragged
+    reads (empty, shorter than k, exactly k, k + 1) so that read borders fall everywhere in a lane's 32 positions."""
+    rng = np.random.default_rng(100 + k)
+    genome = synth.reads_ascii(20 + k, 9000, 1, 9000, 0.0)[0]
+    reads = []
+    for i in range(1500):
+        L = int(rng.integers(0, 160)) if i % 5 else int(rng.choice([0, k - 1, k, k + 1, 3 * k]))
+        s = int(rng.integers(0, 9000 - 200))
+        r = genome[s:s + L].copy()
+        if L > 3 and i % 3 == 0:
+            r[int(rng.integers(0, L))] = b"ACGT"[int(rng.integers(0, 4))]
+        reads.append(r)
+    blob = np.concatenate(reads)
+    off = np.zeros(len(reads) + 1, dtype=np.uint64)
+    np.cumsum([r.size for r in reads], out=off[1:])
+    want = orc_c.build(blob, off, k)
+    n_rec = []
+    for generic in (0, 1):
+        g = _dbg.Graph()
+        g.set_option("extract_generic", generic)
+        g.set_reads(blob, off)
+        g.build(k)
+        assert g.sizes()["n_nodes"] == want["n_nodes"] and g.sizes()["n_kmer_instances"] == want["n_kmer_instances"]
+        assert g.sizes()["n_edge_instances"] == want["n_edge_instances"]
+        keys, stamps, counts, flags = g.export_nodes()
+        o = np.argsort(stamps, kind="stable")
+        assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+        assert np.array_equal(counts[o], want["counts"])
+        if k > 32:
+            assert np.array_equal(g.export_keys_hi()[o], want["keys_hi"])
+        n_rec.append(g.stats()["n_records"])
+        g.close()
+    assert n_rec[0] == n_rec[1] and n_rec[0] > 0  # the same super-k-mers either way
