@@ -1354,8 +1354,21 @@ struct PredSplitter {
     __device__ bool operator()(uint64_t v) const { return jump_is_splitter((uint32_t)v, J0[v]); }
 };
 
-// R[s] = (next splitter on s's chain, hops and score up to it), unresolved; a splitter whose own chain ends in itself
-// keeps its resolved entry.  A chain that cycles without a splitter leaves R[s] pointing at s: never resolved.
+// position of node x in the ascending splitter list (x is a splitter)
+__device__ inline uint32_t jump_rank(const uint32_t *__restrict__ list, uint64_t n, uint32_t x) {
+    uint64_t lo = 0, hi = n;  // list[lo] <= x < list[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (list[mid] <= x) lo = mid; else hi = mid;
+    }
+    return (uint32_t)lo;
+}
+
+// R[i] for splitter i = list[i]: (RANK of the next splitter on its chain, hops and score up to it), unresolved; a
+// splitter whose own chain ends in itself keeps its resolved entry (target unused).  A chain that cycles without a
+// splitter points at itself: never resolved.  R is DENSE over the splitters -- 1/30 of the nodes, 190 MB at the
+// BASELINE size: the doubling rounds below then run inside the last-level cache instead of touching one 64-byte line
+// of a per-node table per splitter (17 rounds x 0.8 ms before, x 0.1 ms now).
 __global__ __launch_bounds__(256) void k_jump_walk(const uint32_t *__restrict__ list, uint64_t n_list, const Jump *__restrict__ J0,
                                                    Jump *R) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1366,53 +1379,63 @@ __global__ __launch_bounds__(256) void k_jump_walk(const uint32_t *__restrict__ 
     if (!(acc.score & JUMP_TERM)) {
         uint32_t x = acc.target, tortoise = s;
         uint32_t power = 1, lam = 1;
+        bool cycle = false;
         for (;;) {
             const Jump jx = J0[x];
             if (jump_is_splitter(x, jx)) break;
-            if (x == tortoise) { acc = Jump{s, 0u, 0ull}; x = s; break; }  // closed on itself: a cycle
+            if (x == tortoise) { cycle = true; break; }  // closed on itself: a cycle
             if (lam == power) { tortoise = x; power <<= 1; lam = 0; }
             ++lam;
             acc.hops += jx.hops;  // not a start: the flag bit is clear
             acc.score += jx.score;
             x = jx.target;
         }
-        acc.target = x;
+        if (cycle) acc = Jump{(uint32_t)i, 0u, 0ull};
+        else acc.target = jump_rank(list, n_list, x);
     }
-    R[s] = acc;
+    R[i] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_jump_step_list(const uint32_t *__restrict__ list, uint64_t n_list,
-                                                        const Jump *__restrict__ in, Jump *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_jump_step_dense(uint64_t n, const Jump *__restrict__ in, Jump *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_list) return;
-    const uint32_t v = list[i];
-    Jump a = in[v];
+    if (i >= n) return;
+    Jump a = in[i];
     if (!(a.score & JUMP_TERM)) {
         const Jump b = in[a.target];
         a.target = b.target;
         a.hops += b.hops;
         a.score += b.score;
     }
-    out[v] = a;
+    out[i] = a;
+}
+
+// every start is a splitter: its position in the splitter list
+__global__ __launch_bounds__(256) void k_jump_start_ranks(const uint32_t *__restrict__ starts, uint64_t n_starts,
+                                                          const uint32_t *__restrict__ list, uint64_t n_list, uint32_t *rank,
+                                                          unsigned long long *scalars) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_starts) return;
+    const uint32_t r = n_list ? jump_rank(list, n_list, starts[i]) : 0u;
+    if (!n_list || list[r] != starts[i]) atomicOr(&scalars[0], 1ull);
+    rank[i] = r;
 }
 
 struct UnresolvedStart {
-    const uint32_t *starts;
-    const Jump *J;
+    const uint32_t *starts, *rank;
+    const Jump *R;
     const uint8_t *flags;
     __device__ uint64_t operator()(uint64_t i) const {
-        const uint32_t s = starts[i];
-        return !(flags[s] & DBG_F_PULLED) && !(J[s].score & JUMP_TERM);
+        return !(flags[starts[i]] & DBG_F_PULLED) && !(R[rank[i]].score & JUMP_TERM);
     }
 };
 
-__global__ __launch_bounds__(256) void k_jump_starts(const uint32_t *starts, uint64_t n_starts, const Jump *J,
+__global__ __launch_bounds__(256) void k_jump_starts(const uint32_t *starts, const uint32_t *rank, uint64_t n_starts, const Jump *R,
                                                      const uint8_t *flags, int k, uint64_t *per_ctg, uint64_t *per_chr,
                                                      uint64_t *per_score) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_starts) return;
     const uint32_t s = starts[i];
-    const Jump a = J[s];
+    const Jump a = R[rank[i]];
     const bool emit = !(flags[s] & DBG_F_PULLED) && (a.score & JUMP_TERM);
     per_ctg[i] = emit;
     per_chr[i] = emit ? (uint64_t)k + a.hops : 0;
@@ -2667,34 +2690,46 @@ static int walk_impl(dbg *h, const G &g, int final_mode, uint64_t max_chars) {
         };
         if (use_jump) {
             if ((rc = dev_alloc(h, &per_score, ns)) != DBG_OK) break;
-            // 16 B per node each: kept in the arena (a fresh 12 GB hipMalloc costs ~0.4 s at the BASELINE size)
+            // the one-step table, 16 B per node: kept in the arena (a fresh 6 GB hipMalloc costs ~0.2 s at the BASELINE size)
             if ((rc = buf_ensure(h, h->ar_walk[0], h->n_nodes * sizeof(Jump))) != DBG_OK) break;
-            if ((rc = buf_ensure(h, h->ar_walk[1], h->n_nodes * sizeof(Jump))) != DBG_OK) break;
             jump[0] = (Jump *)h->ar_walk[0].p;
-            jump[1] = (Jump *)h->ar_walk[1].p;
             const dim3 grid(grid_for(h->n_nodes, 256));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_jump_init<G>), grid, dim3(256), 0, h->stream, h->n_nodes, g, jump[0]);
-            // splitters (see k_jump_walk): their list, their walks into jump[1], then doubling over the list only;
-            // jump[0] (the one-step table) becomes the second buffer once the walks are done
+            // splitters (see k_jump_walk): their list, their walks into a table that is dense over the splitters,
+            // then doubling over that table
             if ((rc = buf_ensure(h, h->ar_walk[2], h->n_nodes * 4)) != DBG_OK) break;
             uint32_t *slist = (uint32_t *)h->ar_walk[2].p;
             uint64_t n_split = 0;
             if ((rc = compact_ids(h, h->n_nodes, PredSplitter{jump[0]}, slist, &n_split)) != DBG_OK) break;
+            if ((rc = buf_ensure(h, h->ar_walk[1], (2 * n_split + 1) * sizeof(Jump) + (ns + 4) * 4)) != DBG_OK) break;
+            Jump *dense[2] = {(Jump *)h->ar_walk[1].p, (Jump *)h->ar_walk[1].p + n_split};
+            uint32_t *start_rank = (uint32_t *)((Jump *)h->ar_walk[1].p + 2 * n_split);
             const dim3 sgrid(grid_for(n_split, 256));
             if (n_split)
-                hipLaunchKernelGGL(k_jump_walk, sgrid, dim3(256), 0, h->stream, slist, n_split, jump[0], jump[1]);
-            int cur = 1, max_rounds = 2;
+                hipLaunchKernelGGL(k_jump_walk, sgrid, dim3(256), 0, h->stream, slist, n_split, jump[0], dense[0]);
+            (void)hipMemsetAsync(h->d_scalars, 0, 8, h->stream);
+            hipLaunchKernelGGL(k_jump_start_ranks, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, slist, n_split,
+                               start_rank, (unsigned long long *)h->d_scalars);
+            int cur = 0, max_rounds = 2;
             while ((1ull << (max_rounds - 1)) < n_split) ++max_rounds;  // a chain holds fewer splitters than there are
             for (int round = 0; round < max_rounds; ++round) {
                 uint64_t open = 0;
-                if ((rc = reduce_sum(h, ns, UnresolvedStart{starts, jump[cur], h->d_flags}, &open)) != DBG_OK) break;
-                if (!open) break;
-                hipLaunchKernelGGL(k_jump_step_list, sgrid, dim3(256), 0, h->stream, slist, n_split, jump[cur], jump[cur ^ 1]);
+                if ((round & 1) == 0) {  // every other round: the test costs as much as a round
+                    if ((rc = reduce_sum(h, ns, UnresolvedStart{starts, start_rank, dense[cur], h->d_flags}, &open)) != DBG_OK) break;
+                    if (!open) break;
+                }
+                hipLaunchKernelGGL(k_jump_step_dense, sgrid, dim3(256), 0, h->stream, n_split, dense[cur], dense[cur ^ 1]);
                 cur ^= 1;
             }
             if (rc != DBG_OK) break;
-            hipLaunchKernelGGL(k_jump_starts, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, ns, jump[cur],
+            hipLaunchKernelGGL(k_jump_starts, dim3(grid_for(ns, 256)), dim3(256), 0, h->stream, starts, start_rank, ns, dense[cur],
                                h->d_flags, h->k, per_ctg, per_chr, per_score);
+            {
+                uint64_t sc0 = 0;
+                if (hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                    hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "walk: list ranking failed on the device"; rc = DBG_E_HIP; break; }
+                if (sc0 & 1) { h->err = "internal: a start node is not a splitter"; rc = DBG_E_HIP; break; }
+            }
             jump[0] = jump[1] = nullptr;  // arena-owned
         } else {
             launch(0);
