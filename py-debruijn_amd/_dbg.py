@@ -473,6 +473,13 @@ class Graph:
                                                   C.byref(p[3]), C.byref(p[4]), C.byref(p[5]), C.byref(p[6])))
         sz, dev = self.part_sizes(part), self.sizes_device()
         n, ne = sz["n_nodes"], sz["n_edges"]
+        if n == 0:  # a part whose level-1 groups hold no record has no arrays on the device
+            import torch
+            d = torch.device("cuda", dev) if isinstance(dev, int) else torch.device(dev)
+            e = lambda dt: torch.empty(0, dtype=dt, device=d)  # noqa: E731
+            return {"keys": e(torch.int64), "stamps": e(torch.int64), "flags": e(torch.uint8),
+                    "row_ptr": torch.zeros(1, dtype=torch.int32, device=d), "col": e(torch.int32), "col_part": e(torch.uint8),
+                    "cnt": e(torch.int32)}
         return {"keys": device_tensor(p[0].value, n, "int64", dev),
                 "stamps": device_tensor(p[1].value, n, "int32" if sb.value == 4 else "int64", dev),
                 "flags": device_tensor(p[2].value, n, "uint8", dev), "row_ptr": device_tensor(p[3].value, n + 1, "int32", dev),

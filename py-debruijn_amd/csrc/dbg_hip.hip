@@ -5016,6 +5016,10 @@ extern "C" int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *sta
     HIPCHK(h, hipSetDevice(h->device));
     dbg *sub = mp->part[part];
     const uint64_t n = sub->n_nodes, ne = sub->n_edges;
+    if (n == 0) {  // a part whose level-1 groups hold no record has no arrays at all
+        if (row_ptr) row_ptr[0] = 0;
+        return DBG_OK;
+    }
     D2H(h, keys, sub->d_keys, n * 8);
     D2H(h, flags, sub->d_flags, n);
     D2H(h, col, sub->d_col, ne * 4);

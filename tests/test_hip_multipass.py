@@ -220,3 +220,52 @@ def test_ranks_times_passes_equal_the_oracle(ranks, n_passes, k, n_reads, read_l
             crossing += int((owners // n_passes != v // n_passes).sum())
             e[has] += 1
     assert ranks == 1 or crossing > 0  # the exchange between ranks really carried successors
+
+
+@pytest.mark.parametrize("n_reads,n_passes", [(3, 64), (40, 64), (1, 8), (0, 4)])
+def test_multipass_with_empty_parts(n_reads, n_passes):
+    """Fewer records than level-1 groups: most parts hold nothing (no arrays at all) -- exports, sizes and the device
+    views must cope, and the non-empty parts still equal the oracle."""
+    reads = synth.reads_ascii(13, 2000, max(n_reads, 1), 60, 0.0)[:n_reads]
+    g = _dbg.Graph()
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 60, dtype=np.uint64))
+    g.build_multipass(31, n_passes)
+    assert g.part_count() == n_passes
+    empty = [p for p in range(n_passes) if g.part_sizes(p)["n_nodes"] == 0]
+    assert len(empty) > 0
+    for p in empty:
+        d = g.export_part(p)
+        assert d["keys"].size == 0 and d["row_ptr"].tolist() == [0] and d["col"].size == 0
+        t = g.part_tensors(p)
+        assert t["keys"].numel() == 0 and t["row_ptr"].tolist() == [0]
+    if n_reads:
+        check_against_oracle(g, reads, 60, 31)
+    else:
+        assert g.sizes()["n_nodes"] == 0
+
+
+def test_ranks_times_passes_with_empty_parts():
+    """4 ranks x 8 passes over 160 short reads: 32 virtual shards, some without a single record."""
+    import inproc_dist
+    import multi_gpu
+    k, read_len, per, ranks, n_passes = 31, 34, 40, 4, 8
+
+    def one(dist, rank):
+        reads = synth.reads_ascii(862236413, 272, per, read_len, 0.01, first_read=rank * per)
+        g = _dbg.Graph(device=0)
+        if rank == 0:
+            g.set_option("shard_stamp64", 1)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        parts = gather_parts(g)
+        g.close()
+        return parts
+
+    parts = [d for rp in inproc_dist.run_ranks(ranks, one) for d in rp]
+    allr = np.concatenate([synth.reads_ascii(862236413, 272, per, read_len, 0.01, first_read=r * per) for r in range(ranks)])
+    want = orc_c.build(allr.reshape(-1), np.arange(0, allr.size + 1, read_len, dtype=np.uint64), k)
+    keys = np.concatenate([d["keys"] for d in parts])
+    stamps = np.concatenate([d["stamps"] for d in parts])
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(np.concatenate([dense_counts(d) for d in parts])[o], want["counts"])
