@@ -294,3 +294,34 @@ def test_a_shard_that_outgrows_its_id_space_fails_loudly():
     # both ranks fail at the same step (each owns half of ~60 000 nodes), so neither waits for the other
     got = inproc_dist.run_ranks(2, one)
     assert all(x is not None and x[0] == _dbg.DBG_E_CAPACITY and "capacity" in x[1] for x in got), got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n_passes", [(31, 0), (63, 0), (21, 4)])
+def test_a_rank_without_reads(k, n_passes):
+    """An uneven split can leave a rank with no reads at all: it still takes part in every exchange and owns its share
+    of the k-mers of the others (sharded build, two-word records, ranks x passes)."""
+    import _dbg
+    import multi_gpu
+    L = 100
+
+    def reads_of(r):
+        return synth.reads_ascii(5, 4000, 300, L, 0.01) if r != 1 else np.zeros((0, L), dtype=np.uint8)
+
+    def one(dist, rank):
+        g = _dbg.Graph(device=0)
+        rd = reads_of(rank)
+        g.set_reads(rd.reshape(-1), np.arange(0, rd.size + 1, L, dtype=np.uint64))
+        if n_passes:
+            multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+            n = sum(g.part_sizes(p)["n_nodes"] for p in range(n_passes))
+        else:
+            multi_gpu.sharded_build(g, k, dist)
+            n = g.sizes()["n_nodes"]
+        g.close()
+        return n
+
+    got = inproc_dist.run_ranks(4, one)
+    allr = np.concatenate([reads_of(r) for r in range(4)])
+    want = orc_c.build(allr.reshape(-1), np.arange(0, allr.size + 1, L, dtype=np.uint64), k, export=False)
+    assert sum(got) == want["n_nodes"] and min(got) > 0
