@@ -155,4 +155,42 @@ __device__ inline uint32_t startwin32(const T &t, int j) {
 }
 
 
+// Sliding-window OR over a bit mask: bit q of the result = OR of bits q .. q + WIDTH - 1 of x (bits beyond the word read
+// as 0), by doubling -- about ten operations for all 64 positions.  The extraction kernels use it for "a read starts
+// inside the k-mer at position q", which they used to test position by position (a third of their instructions).
+template <int WIDTH>
+__device__ inline uint64_t window_or64(uint64_t x) {
+    static_assert(WIDTH >= 1 && WIDTH <= 64, "window width");
+    uint64_t y = x;
+    int have = 1;
+    if (WIDTH >= 2) { y |= y >> 1; have = 2; }
+    if (WIDTH >= 4) { y |= y >> 2; have = 4; }
+    if (WIDTH >= 8) { y |= y >> 4; have = 8; }
+    if (WIDTH >= 16) { y |= y >> 8; have = 16; }
+    if (WIDTH >= 32) { y |= y >> 16; have = 32; }
+    if (WIDTH > have) y |= y >> (WIDTH - have);
+    return y;
+}
+
+// the same over a 128-bit mask (lo, hi): only the low word of the result is returned (positions 0..63), WIDTH <= 64
+struct Bits128 { uint64_t lo, hi; };
+__device__ inline Bits128 shr128(Bits128 a, int s) {  // 0 < s < 64
+    return Bits128{(a.lo >> s) | (a.hi << (64 - s)), a.hi >> s};
+}
+template <int WIDTH>
+__device__ inline uint64_t window_or128_lo(Bits128 x) {
+    static_assert(WIDTH >= 1 && WIDTH <= 64, "window width");
+    Bits128 y = x;
+    int have = 1;
+    auto step = [&](int s) { const Bits128 t = shr128(y, s); y.lo |= t.lo; y.hi |= t.hi; };
+    if (WIDTH >= 2) { step(1); have = 2; }
+    if (WIDTH >= 4) { step(2); have = 4; }
+    if (WIDTH >= 8) { step(4); have = 8; }
+    if (WIDTH >= 16) { step(8); have = 16; }
+    if (WIDTH >= 32) { step(16); have = 32; }
+    if (WIDTH >= 64) { step(32); have = 64; }
+    if (WIDTH > have) step(WIDTH - have);
+    return y.lo;
+}
+
 }  // namespace dbgk

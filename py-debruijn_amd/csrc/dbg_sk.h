@@ -251,15 +251,14 @@ __global__ __launch_bounds__(256, DBG_EXW_WAVES) void k_sk_extract_w(const char 
             P[i] = (i % W == 0) ? pv[i] : min(P[i - 1], pv[i]);
         }
         const uint64_t sb64 = ((uint64_t)s.t.sb[(j0 >> 5) + 1] << 32) | s.t.sb[j0 >> 5];
-        uint32_t vmask = 0, skmask = 0;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const uint32_t sw = (uint32_t)(sb64 >> q);
-            const uint32_t s0 = sw & 1u, sk = (sw >> K) & 1u;
-            const bool v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0) && (tile0 + j0 + q < n_bytes);
-            vmask |= (uint32_t)v << q;
-            skmask |= sk << q;
-        }
+        // a k-mer at position q is valid iff no read starts at q + 1 .. q + K - 1, not both at q and q + K (a read of
+        // exactly K bases has no successor but is a k-mer ... of a read with len == K: excluded, debruijn.py:123), and q
+        // lies inside the reads -- all 32 positions of the lane at once, on the bit masks
+        const uint32_t skmask = (uint32_t)(sb64 >> K);
+        const uint64_t left = n_bytes > tile0 + (uint64_t)j0 ? n_bytes - (tile0 + (uint64_t)j0) : 0;
+        const uint32_t inside = left >= 32 ? 0xFFFFFFFFu : ((1u << (uint32_t)left) - 1u);
+        const uint32_t vmask = ~(uint32_t)window_or64<K - 1>(sb64 >> 1) & ~(skmask & (uint32_t)sb64) & inside;
+        (void)mid_mask;
         n_k += __popc(vmask);
         n_e += __popc(vmask & ~skmask);
         uint32_t off[32];
@@ -377,7 +376,10 @@ __global__ __launch_bounds__(256, DBG_EXW_WAVES) void k_sk_extract_w(const char 
 #ifndef DBG_MS_CH
 #define DBG_MS_CH 4096
 #endif
-constexpr int MS_CH = DBG_MS_CH;      // records sorted per LDS round
+constexpr int MS_CH = DBG_MS_CH;      // records sorted per LDS round with 64-bit stamps (24 B per record)
+// ... and with 32-bit stamps (20 B per record: 6144 fit): a child gets chunk / fan-out records per round in one piece --
+// 12 instead of 8 at a fan-out of 512, 96-byte instead of 64-byte pieces of w0 / w1 (partition 4.82 -> 4.57 ms)
+template <class ST> struct MsChunk { static constexpr int CH = sizeof(ST) == 8 ? MS_CH : MS_CH + MS_CH / 2; };
 constexpr int MS_SC = 32768;          // records per super-chunk
 constexpr int MS_MAX_NB = 1024;
 #ifndef DBG_MS_NT
@@ -490,9 +492,9 @@ __global__ __launch_bounds__(256) void k_ms_children(MsParents P, const uint64_t
 
 template <class ST>
 struct MsLds {
-    uint64_t w0[MS_CH];
-    uint64_t w1[MS_CH];
-    ST st[MS_CH];
+    uint64_t w0[MsChunk<ST>::CH];
+    uint64_t w1[MsChunk<ST>::CH];
+    ST st[MsChunk<ST>::CH];
     uint32_t hist[MS_MAX_NB];    // count in this chunk
     uint32_t start[MS_MAX_NB];   // exclusive prefix inside the chunk
     uint64_t run[MS_MAX_NB];     // global cursor of the super-chunk per child bucket
@@ -515,6 +517,8 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
                                                     uint64_t *out_w0, uint64_t *out_w1, ST *out_st) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ms_raw[];
     MsLds<ST> &s = *reinterpret_cast<MsLds<ST> *>(ms_raw);
+    constexpr int CH = MsChunk<ST>::CH;
+    static_assert(CH % MS_NT == 0 && sizeof(MsLds<ST>) <= 160 * 1024, "multisplit chunk");
 #ifdef DBG_MS_PROF
     unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
 #endif
@@ -531,16 +535,16 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
     for (int b = threadIdx.x; b < nb; b += MS_NT) s.run[b] = offs[lbase + (uint64_t)b * nsc + gidx];
     const uint64_t beg = P.start[seg] + sidx * MS_SC;
     const uint64_t end = min(P.start[seg] + P.cnt[seg], beg + (uint64_t)MS_SC);
-    for (uint64_t c0 = beg; c0 < end; c0 += MS_CH) {
-        const int n = (int)min((uint64_t)MS_CH, end - c0);
+    for (uint64_t c0 = beg; c0 < end; c0 += CH) {
+        const int n = (int)min((uint64_t)CH, end - c0);
         for (int b = threadIdx.x; b < nb; b += MS_NT) s.hist[b] = 0;
         __syncthreads();
         MS_TICK(1);
-        uint64_t r0[MS_CH / MS_NT], r1[MS_CH / MS_NT];
-        ST rs[MS_CH / MS_NT];
-        uint32_t rk[MS_CH / MS_NT];
+        uint64_t r0[CH / MS_NT], r1[CH / MS_NT];
+        ST rs[CH / MS_NT];
+        uint32_t rk[CH / MS_NT];
 #pragma unroll
-        for (int i = 0; i < MS_CH / MS_NT; ++i) {
+        for (int i = 0; i < CH / MS_NT; ++i) {
             const int q = i * MS_NT + threadIdx.x;
             if (q < n) {
                 r0[i] = in_w0[c0 + q];
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(MS_NT) void k_ms_scatter(MsParents P, const uint64_
         __syncthreads();
         MS_TICK(3);
 #pragma unroll
-        for (int i = 0; i < MS_CH / MS_NT; ++i) {
+        for (int i = 0; i < CH / MS_NT; ++i) {
             const int q = i * MS_NT + threadIdx.x;
             if (q < n) {
                 const uint32_t b = ms_child(r1[i], shift, nb, fbits);

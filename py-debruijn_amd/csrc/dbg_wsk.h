@@ -311,15 +311,15 @@ __global__ __launch_bounds__(256, 2) void k_wsk_extract_w(const char *__restrict
         }
         const uint64_t sb_lo = ((uint64_t)s.t.sb[(j0 >> 5) + 1] << 32) | s.t.sb[j0 >> 5];
         const uint64_t sb_hi = s.t.sb[(j0 >> 5) + 2];
-        uint32_t vmask = 0, skmask = 0;
-#pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const uint64_t sw = q ? (sb_lo >> q) | (sb_hi << (64 - q)) : sb_lo;  // start bits of positions j0 + q ...
-            const uint32_t s0 = (uint32_t)(sw & 1ull), sk = (uint32_t)(sw >> K) & 1u;
-            const bool v = (((sw >> 1) & mid_mask) == 0) && !(sk && s0) && (tile0 + j0 + q + (uint64_t)K <= n_bytes);
-            vmask |= (uint32_t)v << q;
-            skmask |= sk << q;
-        }
+        // validity of the lane's 32 positions at once, on the 96 start bits (see k_sk_extract_w): no read start at
+        // q + 1 .. q + K - 1, not both at q and q + K, and the k-mer ends inside the reads
+        const Bits128 sbits{sb_lo, sb_hi};
+        const uint32_t skmask = (uint32_t)shr128(sbits, K).lo;
+        const uint64_t pos0 = tile0 + (uint64_t)j0;
+        const uint64_t fit = n_bytes >= pos0 + (uint64_t)K ? n_bytes - (pos0 + (uint64_t)K) + 1 : 0;  // positions q < fit end inside
+        const uint32_t inside = fit >= 32 ? 0xFFFFFFFFu : ((1u << (uint32_t)fit) - 1u);
+        const uint32_t vmask = ~(uint32_t)window_or128_lo<K - 1>(shr128(sbits, 1)) & ~(skmask & (uint32_t)sb_lo) & inside;
+        (void)mid_mask;
         n_k += __popc(vmask);
         n_e += __popc(vmask & ~skmask);
         uint32_t off[32];
