@@ -269,3 +269,45 @@ def test_ranks_times_passes_with_empty_parts():
     o = np.argsort(stamps, kind="stable")
     assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
     assert np.array_equal(np.concatenate([dense_counts(d) for d in parts])[o], want["counts"])
+
+
+def test_part_entry_points_refuse_bad_arguments():
+    """dbg_part_* / dbg_multipass_finish / dbg_shard_build_multipass on handles and arguments that cannot be served:
+    an error code and text, never a crash."""
+    import torch
+    reads = synth.reads_ascii(14, 3000, 200, 80, 0.01)
+    g = _dbg.Graph()
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 80, dtype=np.uint64))
+    with pytest.raises(_dbg.DbgError):
+        g.multipass_finish()                      # no multi-pass build yet
+    g._mp_virtual = 4
+    with pytest.raises(_dbg.DbgError):
+        g.part_queries(0)
+    g.build(31)                                   # a single-pass graph has no parts either
+    assert g.part_count() == 0
+    with pytest.raises(_dbg.DbgError):
+        g.export_part(0)
+    g.build_multipass(31, 4)
+    for bad in (-1, 4, 1000):
+        with pytest.raises(_dbg.DbgError):
+            g.part_sizes(bad)
+        with pytest.raises(_dbg.DbgError):
+            g.part_queries(bad)
+        with pytest.raises(_dbg.DbgError):
+            g.part_answer(bad, torch.zeros(4, dtype=torch.int64, device="cuda"))
+    with pytest.raises(_dbg.DbgError):
+        g.part_apply(0, 99, torch.zeros(0, dtype=torch.int32, device="cuda"))   # no such owner
+    g.multipass_finish()                          # nothing open on one GPU: fine, and twice as well
+    g.multipass_finish()
+    # ranks x passes with impossible shapes
+    dummy = torch.zeros(16, dtype=torch.int64, device="cuda")
+    st = torch.zeros(16, dtype=torch.int32, device="cuda")
+    rows = [[0] * 256, [0] * 256]
+    for n_shards, me, passes in ((2, 0, 3), (2, 0, 64), (2, 5, 2), (3, 0, 2)):
+        with pytest.raises(_dbg.DbgError):
+            g.shard_build_multipass(31, n_shards, me, passes, dummy, dummy, st, [0] * n_shards, [0] * n_shards,
+                                    rows if n_shards == 2 else [[0] * 170] * 3 + [[0] * 2])
+    with pytest.raises(_dbg.DbgError, match="one-word"):
+        g.shard_build_multipass(40, 2, 0, 2, dummy, dummy, st, [0, 0], [0, 0], rows)
+    g.build(31)                                   # the handle still works
+    assert g.sizes()["n_nodes"] > 0
