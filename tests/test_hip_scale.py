@@ -302,3 +302,31 @@ def test_bench_digest_on_the_device_equals_the_oracle_digest():
     d = bench.node_digest_gpu(g)
     assert d == orc_c.digest(want["keys"], want["stamps"], want["counts"]) == mt["digest"]
     assert g.sizes()["n_edges"] == mt["n_edges"] and g.sizes()["n_nodes"] == mt["n_nodes"]
+
+
+def test_bench_line_contract_at_a_small_size(tmp_path):
+    """bench.py end to end in a child process (200 k reads): ONE JSON line with the driver's contract fields, the
+    roofline and cpu_baseline blocks, the CPU/GPU digest comparison and the FASTA-ingest extra."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "200000", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "k-mers/s" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert abs(d["value"] - 200000 * 120 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None  # the committed PMC profile describes the full-size workload only
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["same_graph_as_gpu"] is True and c["value"] > 0
+    assert d["extras"]["fasta_ingest"]["same_reads_and_graph"] is True
