@@ -330,3 +330,31 @@ def test_bench_line_contract_at_a_small_size(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["same_graph_as_gpu"] is True and c["value"] > 0
     assert d["extras"]["fasta_ingest"]["same_reads_and_graph"] is True
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rehearsal(scaling):
+    """The N > 1 leg of bench.py as the driver launches it (torch.distributed.run, one process per rank), rehearsed on
+    this box's one GPU: both ranks on cuda:0, gloo instead of RCCL (RCCL refuses two ranks on one device).  Checks the
+    line's fields, not its speed."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SAME_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--scaling", scaling] + (["--total-reads", "200000"] if scaling == "strong" else ["--reads", "100000"])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["reads_total"] == 200000
+    assert "shard x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 200000 * 120 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]  # whole-job k-mers / max-over-ranks time
