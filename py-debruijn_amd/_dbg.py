@@ -401,6 +401,7 @@ class Graph:
     def build_multipass(self, k, n_passes):
         self.generation += 1
         self._chk(self._lib.dbg_build_multipass(self._h, int(k), int(n_passes)))
+        self._mp_virtual = int(n_passes)  # virtual shards = parts on one GPU
 
     # ---- ranks x passes: a rank of a sharded build that builds its shard in parts (multi_gpu.sharded_build_multipass)
     def shard_build_multipass(self, k, n_shards, my_shard, n_passes, w0, w1, st, recv_counts, stamp_base, sender_bucket_counts):
@@ -421,7 +422,9 @@ class Graph:
 
     def part_queries(self, part):
         """-> (q_starts, q_counts, keys tensor): the part's open successor k-mers grouped by owning virtual shard."""
-        nv = self._mp_virtual
+        nv = getattr(self, "_mp_virtual", 0)
+        if not nv:
+            raise DbgError(-1, "part_queries: a multi-pass build must run first")
         qs, qc = (C.c_uint64 * nv)(), (C.c_uint64 * nv)()
         pk = C.c_void_p()
         self._chk(self._lib.dbg_part_queries(self._h, int(part), qs, qc, C.byref(pk)))

@@ -280,7 +280,6 @@ def test_part_entry_points_refuse_bad_arguments():
     g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 80, dtype=np.uint64))
     with pytest.raises(_dbg.DbgError):
         g.multipass_finish()                      # no multi-pass build yet
-    g._mp_virtual = 4
     with pytest.raises(_dbg.DbgError):
         g.part_queries(0)
     g.build(31)                                   # a single-pass graph has no parts either
