@@ -229,6 +229,12 @@ int dbg_export_csr(dbg_t *h, uint64_t *row_ptr, uint32_t *col, uint32_t *cnt);
 /* ranks[n_nodes]: pull order key of pulled nodes (ascending == append order of
  * already_pull_out, debruijn.py:253), UINT64_MAX for the rest */
 int dbg_export_pull_ranks(dbg_t *h, uint64_t *ranks);
+/* The two short label lists of construct_graph without anything of size n_nodes leaving the device: the nodes that
+ * carry `flag` -- DBG_F_PULLED in pull order (already_pull_out, debruijn.py:253) or DBG_F_BRANCH in dict order
+ * (branch_kmer, debruijn.py:230-236) -- as rows[*n_out] (node ids), keys[*n_out], keys_hi[*n_out] (zeros for
+ * k <= 32).  *n_out is always set (rows == NULL: count only); DBG_E_CAPACITY if capacity < *n_out. */
+int dbg_export_marked(dbg_t *h, uint32_t flag, uint64_t capacity, uint64_t *n_out, uint32_t *rows, uint64_t *keys,
+                      uint64_t *keys_hi);
 int dbg_export_pull_reads(dbg_t *h, uint8_t *read_flags /* [n_reads] */);
 /* contigs in emission order grouped by start: offsets[n_contigs+1] into chars[contig_chars],
  * scores[n_contigs], start_stamp[n_contigs] (stamp of the start node: sort key for dict order),

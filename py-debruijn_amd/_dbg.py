@@ -33,6 +33,7 @@ SYMBOLS = (
     "dbg_import_graph", "dbg_device_keys_hi",
     "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
     "dbg_shard_build_multipass", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
+    "dbg_export_marked",
 )
 
 
@@ -137,6 +138,7 @@ def load_library():
         "dbg_part_answer": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp]),
         "dbg_part_apply": (C.c_int, [H, C.c_int, C.c_int, vp]),
         "dbg_multipass_finish": (C.c_int, [H]),
+        "dbg_export_marked": (C.c_int, [H, C.c_uint32, C.c_uint64, u64p, vp, vp, vp]),
         "dbg_part_sizes": (C.c_int, [H, C.c_int, u64p, u64p, u64p]),
         "dbg_export_part": (C.c_int, [H, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "dbg_part_device_views": (C.c_int, [H, C.c_int] + [C.POINTER(vp)] * 2 + [C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5),
@@ -341,6 +343,19 @@ class Graph:
         r = np.empty(self.sizes()["n_nodes"], dtype=np.uint64)
         self._chk(self._lib.dbg_export_pull_ranks(self._h, _ptr(r)))
         return r
+
+    def export_marked(self, flag, keys=True):
+        """Rows, keys, keys_hi of the nodes carrying ``flag`` (F_PULLED: pull order; F_BRANCH: dict order), selected
+        and sorted on the device.  keys=False: rows only (graphs keyed by reference hold no packed k-mers)."""
+        n = C.c_uint64()
+        self._chk(self._lib.dbg_export_marked(self._h, int(flag), 0, C.byref(n), None, None, None))
+        m = int(n.value)
+        rows = np.empty(m, np.uint32)
+        kk, hi = (np.empty(m, np.uint64), np.empty(m, np.uint64)) if keys else (None, None)
+        if m:
+            self._chk(self._lib.dbg_export_marked(self._h, int(flag), m, C.byref(n), _ptr(rows), _ptr(kk) if keys else None,
+                                                  _ptr(hi) if keys else None))
+        return rows, kk, hi
 
     def export_pull_reads(self):
         f = np.empty(self.sizes()["n_reads"], dtype=np.uint8)

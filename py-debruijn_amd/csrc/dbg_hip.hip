@@ -2427,6 +2427,77 @@ extern "C" int dbg_export_dict_order(dbg_t *h, uint32_t *order) {
     return rc;
 }
 
+// rows of the nodes that carry `flag`, in the reference's list order, with their k-mers: the pulled nodes in pull order
+// (already_pull_out, debruijn.py:253) or the branch nodes in dict order (branch_kmer, debruijn.py:230-236) -- compacted,
+// sorted and gathered on the device, so a caller that only needs these two short lists moves nothing of size n_nodes
+__global__ __launch_bounds__(256) void k_gather_u64(const uint32_t *__restrict__ ids, uint64_t n, const uint64_t *__restrict__ src,
+                                                    uint64_t *dst) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[ids[i]];
+}
+
+extern "C" int dbg_export_marked(dbg_t *h, uint32_t flag, uint64_t capacity, uint64_t *n_out, uint32_t *rows, uint64_t *keys,
+                                 uint64_t *keys_hi) {
+    if (!h || !h->k || !n_out) { if (h) h->err = "dbg_build must run first"; return DBG_E_ARG; }
+    if (flag != DBG_F_PULLED && flag != DBG_F_BRANCH) { h->err = "flag must be DBG_F_PULLED or DBG_F_BRANCH"; return DBG_E_ARG; }
+    if (flag == DBG_F_PULLED && !h->tipped) { h->err = "dbg_remove_tips must run first"; return DBG_E_ARG; }
+    if (flag == DBG_F_BRANCH && !h->pruned) { h->err = "dbg_prune must run first"; return DBG_E_ARG; }
+    if (h->partial_graph) { h->err = kPartialGraph; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
+    *n_out = 0;
+    const uint64_t n = h->n_nodes;
+    if (!n) return DBG_OK;
+    if ((keys || keys_hi) && !h->d_keys) {  // tables keyed by reference into the reads (generic alphabet, k >= 12) hold no packed k-mers
+        h->err = "dbg_export_marked: this graph has no packed keys (pass NULL for keys and spell the rows from the reads)";
+        return DBG_E_ARG;
+    }
+    if (!h->d_flags || !h->d_stamps || (flag == DBG_F_PULLED && !h->d_pull_rank)) { h->err = "dbg_export_marked: node arrays missing"; return DBG_E_ARG; }
+    uint32_t *ids = nullptr, *ids_sorted = nullptr;
+    uint64_t *skey = nullptr, *skey_sorted = nullptr, *gathered = nullptr;
+    void *tmp = nullptr;
+    int rc = DBG_OK;
+    do {
+        uint64_t found = 0;
+        if ((rc = compact_ids(h, n, PredFlags{h->d_flags, (uint8_t)flag, (uint8_t)flag}, (uint32_t *)nullptr, &found)) != DBG_OK) break;
+        *n_out = found;
+        if (!found || !rows) break;
+        if (found > capacity) { h->err = "dbg_export_marked: capacity too small"; rc = DBG_E_CAPACITY; break; }
+        if ((rc = dev_alloc(h, &ids, found)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &ids_sorted, found)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &skey, found)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &skey_sorted, found)) != DBG_OK) break;
+        if ((rc = dev_alloc(h, &gathered, found)) != DBG_OK) break;
+        uint64_t again = 0;
+        if ((rc = compact_ids(h, n, PredFlags{h->d_flags, (uint8_t)flag, (uint8_t)flag}, ids, &again)) != DBG_OK) break;
+        const dim3 grid(grid_for(found, 256));
+        hipLaunchKernelGGL(k_gather_u64, grid, dim3(256), 0, h->stream, ids, found, flag == DBG_F_PULLED ? h->d_pull_rank : h->d_stamps, skey);
+        size_t tmp_bytes = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, skey, skey_sorted, ids, ids_sorted, (size_t)found, 0u, 64u, h->stream);
+        if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, skey, skey_sorted, ids, ids_sorted, (size_t)found, 0u, 64u, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(rows, ids_sorted, found * 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && keys) {
+            hipLaunchKernelGGL(k_gather_u64, grid, dim3(256), 0, h->stream, ids_sorted, found, h->d_keys, gathered);
+            e = hipMemcpyAsync(keys, gathered, found * 8, hipMemcpyDeviceToHost, h->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess && keys_hi) {
+            if (h->d_keys_hi) {
+                hipLaunchKernelGGL(k_gather_u64, grid, dim3(256), 0, h->stream, ids_sorted, found, h->d_keys_hi, gathered);
+                e = hipMemcpyAsync(keys_hi, gathered, found * 8, hipMemcpyDeviceToHost, h->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            } else {
+                memset(keys_hi, 0, found * 8);
+            }
+        }
+        if (e != hipSuccess) { h->err = std::string("dbg_export_marked: ") + hipGetErrorString(e); rc = DBG_E_HIP; }
+    } while (0);
+    if (tmp) (void)hipFree(tmp);
+    dev_free(ids); dev_free(ids_sorted); dev_free(skey); dev_free(skey_sorted); dev_free(gathered);
+    return rc;
+}
+
 __global__ __launch_bounds__(256) void k_keepmask_from_flags(uint64_t n, const uint8_t *flags, uint32_t *out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t)(flags[i] & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT;

@@ -115,17 +115,33 @@ class _NodeStore:
     conversion.  Indices of this class's methods are positions in dict (first-occurrence) order; ``order[i]`` is the
     row of node i in the arrays, so nothing of size n_nodes is gathered or sorted on the host up front."""
 
-    def __init__(self, k, alphabet, bits, order, keys, keys_hi, counts, rank_mc, rank_fs, flags, keep):
+    def __init__(self, k, alphabet, bits, n, loader):
         self.k, self.alphabet, self.bits = k, alphabet, bits
         self.chars = alphabet.decode("latin-1")
         self.code_of = {ch: i for i, ch in enumerate(self.chars)}  # alphabet[code] = character
-        self.order = order
-        self.keys, self.keys_hi, self.counts = keys, keys_hi, counts
-        self.rank_mc, self.rank_fs = rank_mc, rank_fs
-        self.flags, self.keep = flags, keep
-        self.n = int(keys.size)
+        self.n = int(n)
+        # The arrays leave the device when something first asks for them: the reference's driver
+        # (II_assembleFromReads.py:56-75) never reads vertices / edges / edge_count_table, and their export is most of
+        # construct_graph's time at scale (37 bytes per node + the dict-order sort).
+        self._loader = loader
+        self._arrays = None
         self._sorted = None
         self._inverse = None
+
+    def _get(self, name):
+        if self._arrays is None:
+            self._arrays = self._loader()
+            self._loader = None
+        return self._arrays[name]
+
+    order = property(lambda self: self._get("order"))
+    keys = property(lambda self: self._get("keys"))
+    keys_hi = property(lambda self: self._get("keys_hi"))
+    counts = property(lambda self: self._get("counts"))
+    rank_mc = property(lambda self: self._get("rank_mc"))
+    rank_fs = property(lambda self: self._get("rank_fs"))
+    flags = property(lambda self: self._get("flags"))
+    keep = property(lambda self: self._get("keep"))
 
     def rows(self, idx):
         return self.order[np.asarray(idx, dtype=np.int64)]
@@ -433,22 +449,36 @@ def construct_graph(reads, k, threshold=3, final=False):
     if not final:
         g.mark_pull_reads()
 
-    keys, stamps, counts, flags = g.export_nodes()
-    rank_mc, rank_fs = g.export_orders()          # (n, D): successor codes by rank
     alphabet, bits = g.alphabet()                 # code -> character
     chars = alphabet.decode("latin-1")
-    order = g.export_dict_order().astype(np.int64)  # dict order == first-occurrence order (sorted on the device)
-    keys_hi = g.export_keys_hi() if bits == 2 and bits * k > 64 else None
-    keep = g.export_keepmask()
-    n_ranks = rank_mc.shape[1]
+    n_nodes = sz["n_nodes"]
+    two_words = bits == 2 and bits * k > 64
+
+    def load_arrays():
+        keys, stamps, counts, flags = g.export_nodes()
+        rank_mc, rank_fs = g.export_orders()      # (n, D): successor codes by rank
+        return {"keys": keys, "stamps": stamps, "counts": counts, "flags": flags, "rank_mc": rank_mc, "rank_fs": rank_fs,
+                "order": g.export_dict_order().astype(np.int64),  # dict order == first-occurrence order (sorted on the device)
+                "keys_hi": g.export_keys_hi() if two_words else None, "keep": g.export_keepmask()}
 
     byref = bits == 5 and bits * (k + 1) > 64  # generic alphabet, k >= 12: a node's k-mer is the text at its first occurrence
-    lazy = len(order) >= LAZY_MIN_NODES and not byref
-    if lazy:  # the arrays stay in table order; the views go through `order` when they are asked for something
-        store = _NodeStore(k, alphabet, bits, order, keys, keys_hi, counts, rank_mc, rank_fs, flags, keep)
+    lazy = n_nodes >= LAZY_MIN_NODES and not byref
+    if lazy:  # the arrays stay on the device until a view is asked for something; then in table order, through `order`
+        generation = g.generation
+
+        def load_later():
+            if g.generation != generation:
+                raise RuntimeError("these views belong to a graph that a later build on the same reads replaced: read them "
+                                   "(or dict() them) before the next construct_graph")
+            return load_arrays()
+
+        store = _NodeStore(k, alphabet, bits, n_nodes, load_later)
         vertices, edges, ect = _LazyVertices(store), _LazyEdges(store), _LazyEdgeCounts(store)
-        row_labels = store.row_labels
     else:
+        a = load_arrays()
+        keys, stamps, counts, flags, rank_mc, rank_fs = a["keys"], a["stamps"], a["counts"], a["flags"], a["rank_mc"], a["rank_fs"]
+        order, keys_hi, keep = a["order"], a["keys_hi"], a["keep"]
+        n_ranks = rank_mc.shape[1]
         if byref:
             text = reads._pull()[0] if isinstance(reads, DeviceReads) else bases.tobytes().decode("latin-1")
             labels = [text[p:p + k] for p in (stamps[order] >> np.uint64(1)).tolist()]
@@ -494,11 +524,14 @@ def construct_graph(reads, k, threshold=3, final=False):
                 kp = keep_l[i]
                 edges[lab] = [tail + chars[code] for code in ranked if (kp >> code) & 1]
 
-    # the two label lists: rows of the table, put into the reference's order by a sort of the (few) selected rows
-    pulled_rows = np.nonzero(flags & _dbg.F_PULLED)[0]
-    ranks = g.export_pull_ranks()
-    pulled_rows = pulled_rows[np.argsort(ranks[pulled_rows], kind="stable")]
-    already_pull_out = _Tracked(row_labels(pulled_rows))
+    # the two label lists: the (few) marked rows, selected, put into the reference's order and spelled on the device side
+    def marked_labels(flag):
+        rows, mk, mhi = g.export_marked(flag, keys=not byref)
+        if byref:
+            return row_labels(rows.astype(np.int64))
+        return _dbg.decode_keys(mk, k, alphabet, bits, mhi if two_words else None)
+
+    already_pull_out = _Tracked(marked_labels(_dbg.F_PULLED))
 
     if final:  # debruijn.py:281-283
         pull_out_read = []
@@ -506,8 +539,7 @@ def construct_graph(reads, k, threshold=3, final=False):
     else:
         rf = g.export_pull_reads()
         pull_out_read = [reads[i] for i in np.nonzero(rf)[0]]
-        branch_rows = np.nonzero(flags & _dbg.F_BRANCH)[0]
-        branch_kmer = _Tracked(row_labels(branch_rows[np.argsort(stamps[branch_rows], kind="stable")]))
+        branch_kmer = _Tracked(marked_labels(_dbg.F_BRANCH))
 
     token = object()
     vertices._graph = g

@@ -163,3 +163,75 @@ def test_sorted_fasta_from_the_device_equals_the_host_formatting():
         order = sorted(range(len(contigs)), key=lambda i: scores[i], reverse=True)
         want = "".join('>SEQUENCE_{}_{}mer\n{}\n'.format(i, k, contigs[j]) for i, j in enumerate(order))
         assert len(contigs) > 10 and contigs.sorted_fasta() == want
+
+
+def test_lazy_views_load_on_first_use_and_refuse_a_replaced_graph(tmp_path, monkeypatch):
+    """At scale vertices / edges / edge_count_table are views whose arrays leave the device when first asked for (the
+    reference's driver never asks).  A view read later equals the dict built eagerly; a view whose graph a later
+    construct_graph on the same resident reads replaced raises instead of showing the new graph."""
+    import debruijn as prod
+    import synth
+    reads = synth.reads_list(71, 4000, 400, 80, 0.01)
+    with contextlib.redirect_stdout(io.StringIO()):
+        (V, E), pull, branch, pulled, ect = prod.construct_graph(reads, 15, threshold=2)   # dicts (small graph)
+        monkeypatch.setattr(prod, "LAZY_MIN_NODES", 0)
+        (Vl, El), pull_l, branch_l, pulled_l, ect_l = prod.construct_graph(reads, 15, threshold=2)
+    assert Vl._s._arrays is None and len(Vl) == len(V)            # nothing exported yet, the size is known
+    assert list(branch_l) == list(branch) and list(pulled_l) == list(pulled) and pull_l == pull
+    contigs = prod.output_contigs((Vl, El), branch_l, pulled_l)
+    assert Vl._s._arrays is None and len(contigs) > 0             # the walk does not need them either
+    assert dict(El) == E and list(Vl) == list(V) and dict(ect_l.items()) == ect
+    assert Vl._s._arrays is not None
+    p = tmp_path / "input_reads.fasta"
+    synth.write_fasta(str(p), reads)
+    dev = prod.read_reads_device(str(p))
+    with contextlib.redirect_stdout(io.StringIO()):
+        first = prod.construct_graph(dev, 15, threshold=2)
+        prod.construct_graph(dev, 17, threshold=2)
+    with pytest.raises(RuntimeError, match="replaced"):
+        len(first[0][1])      # edges needs the arrays of a graph that is gone
+    assert len(first[0][0]) == len(V)   # the vertex count was known at construction
+
+
+def test_export_marked_equals_the_host_selection():
+    """dbg_export_marked (pulled nodes in pull order, branch nodes in dict order, selected and sorted on the device)
+    against the same selection from the full exports; graphs keyed by reference refuse keys instead of faulting."""
+    import _dbg
+    import synth
+    reads = synth.reads_ascii(81, 6000, 1500, 100, 0.02)
+    for k in (21, 40):
+        g = _dbg.Graph()
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64))
+        g.build(k); g.refine_edge_order(); g.prune(2); g.remove_tips(); g.mark_pull_reads()
+        keys, stamps, counts, flags = g.export_nodes()
+        hi = g.export_keys_hi()
+        ranks = g.export_pull_ranks()
+        rows = np.nonzero(flags & _dbg.F_PULLED)[0]
+        rows = rows[np.argsort(ranks[rows], kind="stable")]
+        got = g.export_marked(_dbg.F_PULLED)
+        assert rows.size > 0 and np.array_equal(got[0], rows) and np.array_equal(got[1], keys[rows])
+        assert np.array_equal(got[2], hi[rows] if k > 32 else np.zeros(rows.size, np.uint64))
+        rows = np.nonzero(flags & _dbg.F_BRANCH)[0]
+        rows = rows[np.argsort(stamps[rows], kind="stable")]
+        got = g.export_marked(_dbg.F_BRANCH)
+        assert rows.size > 0 and np.array_equal(got[0], rows) and np.array_equal(got[1], keys[rows])
+        g.close()
+    rng = np.random.default_rng(9)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    protein = rng.choice(aa, size=300)
+    pep = []
+    for _ in range(120):
+        s0 = int(rng.integers(0, 300 - 60))
+        r = protein[s0:s0 + 60].copy()
+        m = rng.random(60) < 0.03
+        r[m] = rng.choice(aa, size=int(m.sum()))
+        pep.append(r)
+    blob = np.concatenate(pep)
+    g = _dbg.Graph()
+    g.set_reads(blob, np.arange(0, blob.size + 1, 60, dtype=np.uint64))
+    g.build(14); g.refine_edge_order(); g.prune(2); g.remove_tips()   # k = 14 peptides: tables keyed by reference
+    assert g.sizes()["n_branch"] > 0
+    with pytest.raises(_dbg.DbgError, match="no packed keys"):
+        g.export_marked(_dbg.F_BRANCH)
+    rows, kk, hh = g.export_marked(_dbg.F_BRANCH, keys=False)
+    assert rows.size == g.sizes()["n_branch"] and kk is None

@@ -60,8 +60,16 @@ def test_views_over_table_order_arrays_equal_the_oracle_dicts(name):
     perm = rng.permutation(n)                                               # table row r holds dict-order node perm[r]
     order = np.argsort(res["stamps"][perm], kind="stable").astype(np.int64)  # == dbg_export_dict_order
     wide = 2 * k > 64
-    store = prod._NodeStore(k, CODE_CHAR.encode(), 2, order, res["keys"][perm], res["keys_hi"][perm] if wide else None,
-                            res["counts"][perm], rank_mc[perm], rank_fs[perm], flags[perm], keep[perm])
+    loads = []
+
+    def loader():  # what construct_graph hands the store: the arrays leave the device on first use, once
+        loads.append(1)
+        return {"order": order, "keys": res["keys"][perm], "keys_hi": res["keys_hi"][perm] if wide else None,
+                "counts": res["counts"][perm], "rank_mc": rank_mc[perm], "rank_fs": rank_fs[perm], "flags": flags[perm],
+                "keep": keep[perm]}
+
+    store = prod._NodeStore(k, CODE_CHAR.encode(), 2, n, loader)
+    assert len(prod._LazyVertices(store)) == n and not loads  # the size is known without the arrays
     Vv, Ev, Cv = prod._LazyVertices(store), prod._LazyEdges(store), prod._LazyEdgeCounts(store)
     assert list(Vv) == labels and len(Vv) == n
     assert [(Vv[v].indegree, Vv[v].outdegree) for v in labels] == [(V[v].indegree, V[v].outdegree) for v in labels]
@@ -73,6 +81,7 @@ def test_views_over_table_order_arrays_equal_the_oracle_dicts(name):
         assert bogus not in Vv and bogus not in Ev and bogus not in Cv
     some_edge = next(iter(ect))
     assert Cv[some_edge] == ect[some_edge] and (some_edge[:-1] + "N") not in Cv
+    assert loads == [1]  # one load, however much was asked
 
 
 def test_lazy_contigs_sequence_protocol():
@@ -166,8 +175,9 @@ def test_views_for_a_generic_alphabet(name):
                 keep[i] |= 1 << code[s[-1]]
     take = np.random.default_rng(5).permutation(n)  # table row r holds dict-order node take[r]
     order = np.argsort(take).astype(np.int64)        # row of dict-order node i (what dbg_export_dict_order returns)
-    store = prod._NodeStore(k, alphabet.encode(), 5, order, keys[take], None, counts[take], rank_mc[take], rank_fs[take],
-                            flags[take], keep[take])
+    store = prod._NodeStore(k, alphabet.encode(), 5, n, lambda: {"order": order, "keys": keys[take], "keys_hi": None,
+                                                                "counts": counts[take], "rank_mc": rank_mc[take],
+                                                                "rank_fs": rank_fs[take], "flags": flags[take], "keep": keep[take]})
     Vv, Ev, Cv = prod._LazyVertices(store), prod._LazyEdges(store), prod._LazyEdgeCounts(store)
     assert list(Vv) == labels
     assert [(Vv[v].indegree, Vv[v].outdegree) for v in labels] == [(V[v].indegree, V[v].outdegree) for v in labels]
