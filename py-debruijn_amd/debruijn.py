@@ -93,6 +93,24 @@ class DeviceReads:
         for i in range(self._n):
             yield text[int(off[i]):int(off[i + 1])]
 
+    def take(self, indices):
+        """``[self[i] for i in indices]`` without bringing every read to the host: the selected reads are gathered on
+        the device (pull_out_read of construct_graph is 3 % of the reads at the BASELINE size)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        if self._host is not None or idx.size == 0 or idx.size > self._n // 4:
+            return [self[int(i)] for i in idx]
+        import torch
+        bases, offs = self._graph.reads_tensors()
+        ix = torch.as_tensor(idx, device=bases.device)
+        beg = offs[ix]
+        length = offs[ix + 1] - beg
+        out_beg = torch.cumsum(length, 0) - length
+        total = int(length.sum().item())
+        row = torch.repeat_interleave(torch.arange(idx.size, device=bases.device), length)
+        src = torch.arange(total, device=bases.device) - out_beg[row] + beg[row]
+        text = bases[src].cpu().numpy().tobytes().decode("latin-1")
+        return [text[a:a + b] for a, b in zip(out_beg.cpu().tolist(), length.cpu().tolist())]
+
 
 def read_reads_device(fname):
     """``read_reads`` (debruijn.py:22-32) without leaving the GPU; see DeviceReads."""
@@ -538,7 +556,8 @@ def construct_graph(reads, k, threshold=3, final=False):
         branch_kmer = _Tracked()
     else:
         rf = g.export_pull_reads()
-        pull_out_read = [reads[i] for i in np.nonzero(rf)[0]]
+        pulled_idx = np.nonzero(rf)[0]
+        pull_out_read = reads.take(pulled_idx) if isinstance(reads, DeviceReads) else [reads[i] for i in pulled_idx]
         branch_kmer = _Tracked(marked_labels(_dbg.F_BRANCH))
 
     token = object()

@@ -235,3 +235,23 @@ def test_export_marked_equals_the_host_selection():
         g.export_marked(_dbg.F_BRANCH)
     rows, kk, hh = g.export_marked(_dbg.F_BRANCH, keys=False)
     assert rows.size == g.sizes()["n_branch"] and kk is None
+
+
+def test_device_reads_take_gathers_on_the_device(tmp_path):
+    """DeviceReads.take == indexing one by one, for ragged reads, without the host copy of all reads."""
+    import debruijn as prod
+    rng = np.random.default_rng(17)
+    reads = ["".join(rng.choice(list("ACGT"), size=int(rng.integers(1, 90)))) for _ in range(400)]
+    p = tmp_path / "r.fasta"
+    with open(p, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f">r{i}\n{r}\n")
+    dev = prod.read_reads_device(str(p))
+    idx = np.sort(rng.choice(400, size=37, replace=False))
+    got = dev.take(idx)
+    assert dev._host is None and got == [reads[i] for i in idx]
+    assert dev.take([]) == [] and dev.take(np.arange(400)) == reads   # large selections go through the host copy
+    with contextlib.redirect_stdout(io.StringIO()):
+        a = prod.construct_graph(prod.read_reads_device(str(p)), 9, threshold=2)
+        b = prod.construct_graph(reads, 9, threshold=2)
+    assert a[1] == b[1] and list(a[2]) == list(b[2]) and list(a[3]) == list(b[3])
