@@ -17,15 +17,17 @@
  *     stream-synchronous on return.
  *   - k-mers travel as 2-bit packed keys: base code = (ascii >> 1) & 3
  *     (A=0, C=1, T=2, G=3), first base in the most significant used bits,
- *     key = sum(code[i] << 2*(k-1-i)), 1 <= k <= 31.
+ *     key = sum(code[i] << 2*(k-1-i)); 1 <= k <= 31 is one 64-bit word, 32 <= k <= 63 two (the upper word:
+ *     dbg_export_keys_hi / dbg_device_keys_hi / dbg_part_keys_hi).
  *   - "stamp" of a node = (byte offset of its first occurrence in the
  *     concatenated read buffer << 1) | (1 if that occurrence is NOT at position
  *     0 of its read).  Ascending stamp == the reference's dict insertion order
  *     (debruijn.py:121-147); stamp & 1 == the reference's Node.indegree.
- *   - reads made of upper-case A/C/G/T only take the 2-bit path above (k <= 31).  Any other
+ *   - reads made of upper-case A/C/G/T only take the 2-bit path above (k <= 63).  Any other
  *     alphabet (the reference is alphabet-agnostic; its real inputs are peptides) takes the
- *     generic path: up to 32 distinct bytes, 5 bits per character, codes in byte order
- *     (dbg_get_alphabet), k <= 11, 32 successor slots per node; DBG_E_ALPHABET beyond that.
+ *     generic path: up to 32 distinct bytes, codes in byte order (dbg_get_alphabet), 32 successor
+ *     slots per node, k <= 63 (5 bits per character in one word up to k = 11, tables keyed by
+ *     reference into the reads above); DBG_E_ALPHABET for more symbols or k >= 64.
  */
 #ifndef DBG_H
 #define DBG_H
@@ -45,7 +47,7 @@ typedef struct dbg dbg_t;
 #define DBG_E_CAPACITY (-4) /* hash table or an output limit was exceeded */
 #define DBG_E_NOMEM (-5)    /* host or device allocation failed */
 
-#define DBG_ABI_VERSION 3
+#define DBG_ABI_VERSION 4
 
 /* node flag bits (dbg_export_nodes: flags[]) */
 #define DBG_F_INDEG 0x01u    /* Node.indegree (0 or 1), debruijn.py:134,141-142 */
@@ -130,6 +132,12 @@ int dbg_synth_reads(dbg_t *h, uint64_t seed, uint64_t genome_len, uint64_t first
                     uint32_t read_len, uint32_t err_thr24);
 int dbg_reads_checksum(dbg_t *h, uint64_t *out);              /* synth.checksum twin */
 int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets); /* D2H of the current read set */
+/* [self[i] for i in indices] of the reference's `reads` list without bringing every read to the host (pull_out_read,
+ * debruijn.py:274-278, is a few per cent of the reads): the selected reads, concatenated, gathered on the device.
+ * out_offsets[n + 1] (may be NULL) and *n_chars are always set; out_chars may be NULL (first call: sizes only),
+ * else capacity >= *n_chars. */
+int dbg_take_reads(dbg_t *h, const uint64_t *indices, uint64_t n, uint64_t *out_offsets, char *out_chars, uint64_t capacity,
+                   uint64_t *n_chars);
 /* device pointers of the current read set (bases: n_bytes chars; offsets: u64[n_reads + 1]); valid until the reads change */
 int dbg_reads_device(dbg_t *h, const void **d_bases, uint64_t *n_bytes, const void **d_offsets, uint64_t *n_reads);
 
@@ -163,6 +171,9 @@ int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *stamps, uint8_
 int dbg_part_device_views(dbg_t *h, int part, const void **d_keys, const void **d_stamps, int *stamp_bytes,
                           const void **d_flags, const void **d_row_ptr32, const void **d_col, const void **d_col_part,
                           const void **d_cnt);
+/* upper key words of a part's nodes (k > 31: the k-mer is keys_hi * 2^64 + keys; all zero for k <= 31): keys_hi[n_nodes]
+ * on the host and / or the device pointer (NULL for k <= 31); either output may be NULL */
+int dbg_part_keys_hi(dbg_t *h, int part, uint64_t *keys_hi, const void **d_keys_hi);
 /* ---- ranks x passes (BASELINE.json configs[3] on several GPUs): a rank of a sharded build that builds its shard as
  *      n_passes parts.  Input as for dbg_shard_build with sender_bucket_counts (stamp_bytes 4 or 8); part p of rank r is
  *      VIRTUAL shard r * n_passes + p of n_shards * n_passes (<= 64), and col_part of a column holds the virtual shard

@@ -19,6 +19,12 @@ import debruijn as db
 from debruijn import read_reads, read_reads_device
 
 
+def getScore(edge_count_table, contig, k):
+    """II_assembleFromReads.py:14-18: the counts of all (k+1)-mers of a contig, added up.  Host version of the score the
+    walk kernels attach to every contig (``ContigList.scores`` / ``get_score_device``); kept for callers that import it."""
+    return sum(edge_count_table[contig[i:i + k + 1]] for i in range(len(contig) - k))
+
+
 def get_args():
     parser = argparse.ArgumentParser()
     parser.add_argument('-froot', type=str)
@@ -32,19 +38,26 @@ def assemble(sequences, k_lowerlimit, k_upperlimit, threshold, out_path=None):
         g, pull_out_read, branch_kmer, already_pull_out, edge_count_table = db.construct_graph(
             sequences, k, threshold=threshold, final=final)
         contigs = db.output_contigs(g, branch_kmer, already_pull_out)
-        scores = db.get_score_device(contigs)  # == getScore(edge_count_table, x, k) for every contig
-        order = sorted(range(len(contigs)), key=lambda i: scores[i], reverse=True)  # stable, like list.sort
-        sequences = [contigs[i] for i in order]
+        if isinstance(contigs, db.LazyContigs):
+            # more text than fits the host: the index is sorted (device scores == getScore), no contig text moves
+            contigs.sort(reverse=True)
+            sequences = contigs
+            max_len = max(contigs.lengths, default=0)
+        else:
+            scores = db.get_score_device(contigs)  # == getScore(edge_count_table, x, k) for every contig
+            order = sorted(range(len(contigs)), key=lambda i: scores[i], reverse=True)  # stable, like list.sort
+            sequences = [contigs[i] for i in order]
+            max_len = max((len(x) for x in sequences), default=0)
         if k == k_upperlimit:
             if out_path is not None:
                 with open(out_path, mode='a+') as out_file:  # append mode, as in the reference
                     if hasattr(contigs, "sorted_fasta"):
                         out_file.write(contigs.sorted_fasta())  # the same records, sorted and formatted on the device
-                    else:
+                    else:  # record by record: a LazyContigs fetches each text from the device as it is written
                         for i in range(len(sequences)):
-                            out_file.writelines('>SEQUENCE_{}_{}mer\n{}\n'.format(i, k, sequences[i]))
+                            out_file.write('>SEQUENCE_{}_{}mer\n{}\n'.format(i, k, sequences[i]))
             break
-        print('max length: ', len(max(sequences, key=lambda x: len(x))))
+        print('max length: ', max_len)
         print('number of output for k={}: '.format(k), len(sequences))
         if k <= k_upperlimit - 1:
             sequences.extend(pull_out_read)

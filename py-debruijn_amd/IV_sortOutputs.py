@@ -6,21 +6,20 @@
 in dict order); ``support_read_scores(contigs, score_table)`` scores a whole list in one device call, which is what a
 caller with more than a handful of contigs wants: the reference tests reads x contigs substrings on the host, the
 device indexes the reads once and looks every contig position up (csrc/dbg_support.h).  No CPU path: both raise
-without the library and a GPU.  The CLI below is the reference's (``-froot``, ``setting.json``, the PSM score tables
-under ``source``, ``{froot}/{froot}_sorted.fasta`` in append mode); the tables are proprietary inputs of the reference's
-pipeline, so only the scoring and sorting it feeds are covered by tests.
+without the library and a GPU.  The rest of the reference's script -- the loader of the proprietary PSM score tables and
+its CLI -- is outside the hot path and not mirrored here.
 """
-import argparse
-import json
-import os
-
 import numpy as np
 
 import _dbg
-from debruijn import _pack_reads, read_reads
+from debruijn import _pack_reads
 
 _handle = None
-_packed = {}  # id(score_table) -> (len, packed arrays): the reference calls the function once per contig with one table
+# The last packed table: (the dict itself, a digest of its items, the packed arrays).  The reference calls
+# findSupportReadScore once per contig with one table, so the packing is worth keeping -- but only for THAT dict with
+# THAT content: the entry holds a reference to the dict (an id() alone is reused by CPython once a temporary dict is
+# freed) and a digest of its items (the same dict may have been updated in place).
+_packed = None
 
 
 def _graph():
@@ -30,11 +29,17 @@ def _graph():
     return _handle
 
 
+def _table_digest(score_table):
+    """Order- and type-sensitive digest of the items: the dict order is the order the scores are added in, and an int
+    score and the equal float give results of different types (1 == 1.0 and they hash alike, hence the type name)."""
+    return hash(tuple((read, score, type(score).__name__) for read, score in score_table.items()))
+
+
 def _pack_table(score_table):
-    key = id(score_table)
-    hit = _packed.get(key)
-    if hit is not None and hit[0] == len(score_table):
-        return hit[1]
+    global _packed
+    digest = _table_digest(score_table)
+    if _packed is not None and _packed[0] is score_table and _packed[1] == digest:
+        return _packed[2]
     reads = list(score_table.keys())
     values = list(score_table.values())
     for v in values:
@@ -43,8 +48,7 @@ def _pack_table(score_table):
     chars, off = _pack_reads(reads)
     packed = (chars, off, np.asarray(values, dtype=np.float64),
               np.fromiter((isinstance(v, (float, np.floating)) for v in values), dtype=np.uint8, count=len(values)))
-    _packed.clear()
-    _packed[key] = (len(score_table), packed)
+    _packed = (score_table, digest, packed)
     return packed
 
 
@@ -63,46 +67,8 @@ def findSupportReadScore(contig, score_table):
     return support_read_scores([contig], score_table)[0]
 
 
-def get_args():
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-froot', type=str)
-    return parser.parse_args()
-
-
-def load_score_table(file_path, score_cut):
-    """IV_sortOutputs.py:34-49: DENOVO sequence -> summed Score of the PSM rows that pass the cuts."""
-    import pandas as pd
-    sequences_scores = dict()
-    for root, _dirs, files in os.walk(file_path):
-        root = root + '/'
-        for file in files:
-            data = pd.read_csv(root + file, delimiter='\t')
-            temp = data[data['Score'] >= score_cut]
-            temp = temp[-50 < temp['PPM Difference']]
-            temp = temp[temp['PPM Difference'] < 50]
-            temp.reset_index(inplace=True)
-            for i in range(len(temp)):
-                seq = temp['DENOVO'][i]
-                sequences_scores[seq] = temp['Score'][i] + sequences_scores[seq] if seq in sequences_scores else temp['Score'][i]
-    return sequences_scores
-
-
 def sort_contigs(contigs, score_table):
     """IV_sortOutputs.py:55: contigs by support score, descending, stable.  Returns (contigs, scores)."""
     scores = support_read_scores(contigs, score_table)
     order = sorted(range(len(contigs)), key=lambda i: scores[i], reverse=True)
     return [contigs[i] for i in order], [scores[i] for i in order]
-
-
-if __name__ == '__main__':
-    args = get_args()
-    froot = args.froot
-    with open(f'{froot}/setting.json') as f:
-        setting = json.load(f)
-    print(setting)
-    table = load_score_table(setting['source'], setting['score_cut'])
-    contigs, scores = sort_contigs(read_reads(f'{froot}/{froot}.fasta'), table)
-    k = setting['k_upperlimit']
-    with open(f'{froot}/{froot}_sorted.fasta', mode='a+') as out_file:  # append mode, as in the reference
-        for i in range(len(contigs)):
-            out_file.writelines('>SEQUENCE_{}_{}mer_{}\n{}\n'.format(i, k, round(scores[i], 2), contigs[i]))

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DBG_LIB") or os.path.join(_HERE, "libdbg_hip.so")  # 
 DBG_OK, DBG_E_ARG, DBG_E_HIP, DBG_E_ALPHABET, DBG_E_CAPACITY, DBG_E_NOMEM = 0, -1, -2, -3, -4, -5
 F_INDEG, F_KEEP_MASK, F_KEEP_SHIFT, F_BRANCH, F_PULLED = 0x01, 0x1E, 1, 0x20, 0x40
 NO_NODE = 0xFFFFFFFF
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
@@ -33,7 +33,7 @@ SYMBOLS = (
     "dbg_import_graph", "dbg_device_keys_hi",
     "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
     "dbg_shard_build_multipass", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
-    "dbg_export_marked",
+    "dbg_export_marked", "dbg_part_keys_hi", "dbg_take_reads",
 )
 
 
@@ -142,6 +142,8 @@ def load_library():
         "dbg_part_sizes": (C.c_int, [H, C.c_int, u64p, u64p, u64p]),
         "dbg_export_part": (C.c_int, [H, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
         "dbg_part_device_views": (C.c_int, [H, C.c_int] + [C.POINTER(vp)] * 2 + [C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5),
+        "dbg_part_keys_hi": (C.c_int, [H, C.c_int, vp, C.POINTER(vp)]),
+        "dbg_take_reads": (C.c_int, [H, vp, C.c_uint64, vp, vp, C.c_uint64, u64p]),
         "dbg_shard_apply": (C.c_int, [H, vp]),
         "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp, vp]),
         "dbg_device_keys_hi": (C.c_int, [H, C.POINTER(vp)]),
@@ -180,7 +182,8 @@ class Graph:
             self._h = None
             raise DbgError(rc, "dbg_create failed: no usable MI355X visible (the device path has no CPU fallback)")
         self._keep = []  # buffers the device borrows
-        self.generation = 0  # bumped whenever the handle's graph is replaced (debruijn.output_contigs checks it)
+        self.generation = 0  # bumped whenever the handle's graph or reads are replaced (debruijn.output_contigs checks it)
+        self.walks = 0       # bumped by every walk: the device contigs of an earlier walk are gone (ContigList.sorted_fasta checks it)
         for var, opt in (("DBG_ENGINE", "engine"), ("DBG_BUCKET_BITS", "bucket_bits"), ("DBG_LDS_SLOTS", "lds_slots"),
                          ("DBG_WALK_JUMP_MIN", "walk_jump_min_nodes")):
             if os.environ.get(var, "") != "":
@@ -212,6 +215,7 @@ class Graph:
         b = np.ascontiguousarray(b, dtype=np.uint8)
         o = np.ascontiguousarray(offsets, dtype=np.uint64)
         assert o.ndim == 1 and o.size >= 1 and int(o[-1]) == b.size
+        self.generation += 1
         self._chk(self._lib.dbg_set_reads(self._h, _ptr(b), _ptr(o), o.size - 1))
 
     def set_reads_fasta(self, path_or_bytes):
@@ -222,21 +226,35 @@ class Graph:
             raw = np.frombuffer(path_or_bytes, dtype=np.uint8)
         else:
             raw = np.fromfile(path_or_bytes, dtype=np.uint8)
+        self.generation += 1
         self._chk(self._lib.dbg_set_reads_fasta(self._h, _ptr(raw) if raw.size else None, raw.size))
 
     def set_reads_device(self, bases_ptr, n_bytes, offsets_ptr, n_reads, keepalive=()):
         self._keep = list(keepalive)
+        self.generation += 1
         self._chk(self._lib.dbg_set_reads_device(self._h, C.c_void_p(bases_ptr), n_bytes, C.c_void_p(offsets_ptr),
                                                  n_reads))
 
     def synth_reads(self, seed, genome_len, n_reads, read_len, err_rate=0.0, first_read=0):
         thr = int(round(float(err_rate) * (1 << 24)))
+        self.generation += 1
         self._chk(self._lib.dbg_synth_reads(self._h, seed, genome_len, first_read, n_reads, read_len, thr))
 
     def reads_checksum(self):
         out = C.c_uint64()
         self._chk(self._lib.dbg_reads_checksum(self._h, C.byref(out)))
         return out.value
+
+    def take_reads(self, indices):
+        """-> (chars uint8, offsets uint64[n + 1]): the selected reads, concatenated, gathered on the device."""
+        idx = np.ascontiguousarray(indices, dtype=np.uint64)
+        off = np.zeros(idx.size + 1, dtype=np.uint64)
+        total = C.c_uint64()
+        self._chk(self._lib.dbg_take_reads(self._h, _ptr(idx) if idx.size else None, idx.size, _ptr(off), None, 0, C.byref(total)))
+        chars = np.empty(total.value, dtype=np.uint8)
+        if total.value:
+            self._chk(self._lib.dbg_take_reads(self._h, _ptr(idx), idx.size, None, _ptr(chars), chars.size, C.byref(total)))
+        return chars, off
 
     def copy_reads(self):
         s = self.sizes()
@@ -277,6 +295,7 @@ class Graph:
         self._chk(self._lib.dbg_mark_pull_reads(self._h))
 
     def walk(self, final_mode, max_chars=0):
+        self.walks += 1
         self._chk(self._lib.dbg_walk(self._h, 1 if final_mode else 0, int(max_chars)))
 
     def sizes(self):
@@ -445,14 +464,15 @@ class Graph:
         self._chk(self._lib.dbg_part_queries(self._h, int(part), qs, qc, C.byref(pk)))
         qs, qc = [int(x) for x in qs], [int(x) for x in qc]
         total = max([a + b for a, b in zip(qs, qc) if b] + [0])
-        return qs, qc, device_tensor(pk.value, total, "int64", self.sizes_device())
+        self._q_words = 2 if self.sizes()["k"] > 31 else 1  # two-word k-mers: a query is a (lo, hi) pair
+        return qs, qc, device_tensor(pk.value, total * self._q_words, "int64", self.sizes_device())
 
     def part_answer(self, part, keys):
         import torch
-        ans = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
-        if keys.numel():
-            self._chk(self._lib.dbg_part_answer(self._h, int(part), C.c_void_p(keys.data_ptr()), keys.numel(),
-                                                C.c_void_p(ans.data_ptr())))
+        n = keys.numel() // self.query_words()
+        ans = torch.empty(n, dtype=torch.int32, device=keys.device)
+        if n:
+            self._chk(self._lib.dbg_part_answer(self._h, int(part), C.c_void_p(keys.data_ptr()), n, C.c_void_p(ans.data_ptr())))
         return ans
 
     def part_apply(self, part, owner, answers):
@@ -477,9 +497,10 @@ class Graph:
         n, ne = sz["n_nodes"], sz["n_edges"]
         out = {"keys": np.empty(n, np.uint64), "stamps": np.empty(n, np.uint64), "flags": np.empty(n, np.uint8),
                "row_ptr": np.empty(n + 1, np.uint64), "col": np.empty(ne, np.uint32), "col_part": np.empty(ne, np.uint8),
-               "cnt": np.empty(ne, np.uint32)}
+               "cnt": np.empty(ne, np.uint32), "keys_hi": np.zeros(n, np.uint64)}
         self._chk(self._lib.dbg_export_part(self._h, int(part), *[_ptr(out[x]) for x in
                                                                    ("keys", "stamps", "flags", "row_ptr", "col", "col_part", "cnt")]))
+        self._chk(self._lib.dbg_part_keys_hi(self._h, int(part), _ptr(out["keys_hi"]) if n else None, None))
         return out
 
     def part_tensors(self, part):
@@ -498,7 +519,10 @@ class Graph:
             return {"keys": e(torch.int64), "stamps": e(torch.int64), "flags": e(torch.uint8),
                     "row_ptr": torch.zeros(1, dtype=torch.int32, device=d), "col": e(torch.int32), "col_part": e(torch.uint8),
                     "cnt": e(torch.int32)}
-        return {"keys": device_tensor(p[0].value, n, "int64", dev),
+        hi = C.c_void_p()
+        self._chk(self._lib.dbg_part_keys_hi(self._h, int(part), None, C.byref(hi)))
+        extra = {"keys_hi": device_tensor(hi.value, n, "int64", dev)} if hi.value else {}
+        return {**extra, "keys": device_tensor(p[0].value, n, "int64", dev),
                 "stamps": device_tensor(p[1].value, n, "int32" if sb.value == 4 else "int64", dev),
                 "flags": device_tensor(p[2].value, n, "uint8", dev), "row_ptr": device_tensor(p[3].value, n + 1, "int32", dev),
                 "col": device_tensor(p[4].value, ne, "int32", dev), "col_part": device_tensor(p[5].value, ne, "uint8", dev),
@@ -510,6 +534,7 @@ class Graph:
         w0 holds ``shard_record_layout()[0]`` words per record (1, or 4 for the two-word k-mers' records by value)."""
         counts = (C.c_uint64 * n_shards)()
         p0, p1, p2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.generation += 1  # the extraction frees the graph of an earlier build
         self._chk(self._lib.dbg_shard_extract(self._h, int(k), int(n_shards), counts, C.byref(p0), C.byref(p1),
                                               C.byref(p2)))
         counts = [int(c) for c in counts]
@@ -550,22 +575,30 @@ class Graph:
             assert len(flat) == 512, "one count per (sender, owned level-1 bucket)"
             sbc = (C.c_uint64 * 512)(*flat)
         self._keep = [w0, w1, st]
+        self.generation += 1
         self._chk(self._lib.dbg_shard_build(self._h, int(k), int(n_shards), int(my_shard), C.c_void_p(w0.data_ptr()),
                                             C.c_void_p(w1.data_ptr()), C.c_void_p(st.data_ptr()), rc, sb, qs, qc,
                                             C.byref(pk), sbc, int(st.element_size())))
         self._keep = []
         qs, qc = [int(x) for x in qs], [int(x) for x in qc]
         total = max([a + b for a, b in zip(qs, qc)] + [0])
-        return qs, qc, device_tensor(pk.value, total, "int64", self.sizes_device())
+        # two-word k-mers (records by value): a query is a (lo, hi) pair -- query_words() 64-bit words per query
+        self._q_words = 2 if (int(k) > 31 and self.shard_record_layout()[0] == 4) else 1
+        return qs, qc, device_tensor(pk.value, total * self._q_words, "int64", self.sizes_device())
+
+    def query_words(self):
+        """64-bit words per successor query of the last shard_build / part_queries (2 for two-word k-mers)."""
+        return getattr(self, "_q_words", 1)
 
     def shard_answer(self, keys):
         import torch
-        ans = torch.empty(keys.numel(), dtype=torch.int32, device=keys.device)
-        self._chk(self._lib.dbg_shard_answer(self._h, C.c_void_p(keys.data_ptr()), keys.numel(),
-                                             C.c_void_p(ans.data_ptr())))
+        n = keys.numel() // self.query_words()
+        ans = torch.empty(n, dtype=torch.int32, device=keys.device)
+        self._chk(self._lib.dbg_shard_answer(self._h, C.c_void_p(keys.data_ptr()), n, C.c_void_p(ans.data_ptr())))
         return ans
 
     def shard_apply(self, answers):
+        self.generation += 1
         self._chk(self._lib.dbg_shard_apply(self._h, C.c_void_p(answers.data_ptr()) if answers.numel() else None))
 
     # ---- gather for traversal (multi_gpu.gather_graph)

@@ -17,11 +17,12 @@
 #include <string>
 #include <vector>
 
-#include <rocprim/device/device_radix_sort.hpp>  // dbg_export_dict_order only
+#include <rocprim/device/device_radix_sort.hpp>  // library sorts off the timed path: dbg_export_dict_order, dbg_export_marked, dbg_support_read_scores, dbg_export_sorted_fasta
 
 #include "../../include/dbg.h"
 #include "dbg_device.h"
 #include "dbg_sk.h"
+#include "dbg_sk2.h"
 #include "dbg_generic.h"
 #include "dbg_genref.h"
 #include "dbg_wide.h"
@@ -122,6 +123,7 @@ struct dbg {
     int phase_limit = 0;     // ablation of k_sk_count (timing only; the build then fails on purpose)
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
     int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
+    int count_kernel = 2;    // k <= 31, 4096 slots: 2 = k_sk_count2 (successor hints, 16-bit counters; falls back to 1 on counter overflow), 1 = k_sk_count
 
     // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
     // so buffers survive across dbg_build calls on the same handle
@@ -129,7 +131,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_l2, ar_scan, ar_shard[4], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_l2, ar_scan, ar_shard[6], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
@@ -1758,6 +1760,63 @@ extern "C" int dbg_copy_reads(dbg_t *h, char *bases, uint64_t *offsets) {
     return DBG_OK;
 }
 
+// ---- a selection of the resident reads, gathered on the device (pull_out_read of construct_graph, debruijn.py:274-278:
+//      a few per cent of the reads -- the others never leave the GPU)
+struct TakeLen {
+    const uint64_t *idx, *offsets;
+    uint64_t n_reads;
+    __device__ uint64_t operator()(uint64_t i) const { const uint64_t r = idx[i]; return r < n_reads ? offsets[r + 1] - offsets[r] : 0; }
+};
+__global__ __launch_bounds__(256) void k_take_copy(const uint64_t *__restrict__ idx, uint64_t n, const uint64_t *__restrict__ offsets,
+                                                   uint64_t n_reads, const char *__restrict__ bases, const uint64_t *__restrict__ out_off,
+                                                   char *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per selected read
+    if (i >= n) return;
+    const uint64_t r = idx[i];
+    if (r >= n_reads) return;
+    const uint64_t beg = offsets[r], len = offsets[r + 1] - beg, o = out_off[i];
+    for (uint64_t j = threadIdx.x & 63; j < len; j += 64) out[o + j] = bases[beg + j];
+}
+
+extern "C" int dbg_take_reads(dbg_t *h, const uint64_t *indices, uint64_t n, uint64_t *out_offsets, char *out_chars,
+                              uint64_t capacity, uint64_t *n_chars) {
+    if (!h || (n && !indices) || !n_chars) return DBG_E_ARG;
+    if (!h->d_offsets) { h->err = "no reads set"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    *n_chars = 0;
+    if (out_offsets) out_offsets[0] = 0;
+    if (!n) return DBG_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (indices[i] >= h->n_reads) { h->err = "read index out of range"; return DBG_E_ARG; }
+    uint64_t *d_idx = nullptr, *d_off = nullptr;
+    char *d_out = nullptr;
+    CHK(dev_alloc(h, &d_idx, n));
+    int rc = dev_alloc(h, &d_off, n + 1);
+    if (rc != DBG_OK) { dev_free(d_idx); return rc; }
+    auto done = [&](int code) { dev_free(d_idx); dev_free(d_off); dev_free(d_out); return code; };
+    if (hipMemcpyAsync(d_idx, indices, n * 8, hipMemcpyHostToDevice, h->stream) != hipSuccess) { h->err = "dbg_take_reads: copy of the indices failed"; return done(DBG_E_HIP); }
+    uint64_t total = 0;
+    rc = exclusive_scan(h, n, TakeLen{d_idx, h->d_offsets, h->n_reads}, d_off, &total);
+    if (rc != DBG_OK) return done(rc);
+    *n_chars = total;
+    if (out_offsets) {
+        if (hipMemcpyAsync(out_offsets, d_off, n * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "dbg_take_reads: copy of the offsets failed"; return done(DBG_E_HIP); }
+        out_offsets[n] = total;
+    }
+    if (!out_chars) return done(DBG_OK);  // first call of the two-call pattern: sizes only
+    if (capacity < total) { h->err = "dbg_take_reads: capacity below the selected reads' total length"; return done(DBG_E_CAPACITY); }
+    if (total) {
+        rc = dev_alloc(h, &d_out, total);
+        if (rc != DBG_OK) return done(rc);
+        hipLaunchKernelGGL(k_take_copy, dim3(grid_for(n, 4)), dim3(256), 0, h->stream, d_idx, n, h->d_offsets, h->n_reads,
+                           h->d_bases, d_off, d_out);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(out_chars, d_out, total, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) { h->err = "dbg_take_reads: gather failed"; return done(DBG_E_HIP); }
+    }
+    return done(DBG_OK);
+}
+
 // ------------------------------------------------------------------------------------------
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint);
 static int build_wsk(dbg *h, int k, bool *fallback);
@@ -2049,6 +2108,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
+    if (n == "count_kernel" && (value == 1 || value == 2)) { h->count_kernel = (int)value; return DBG_OK; }
     if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -3477,7 +3537,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     const uint64_t own_cnt = n_buckets >> shard_bits, own_lo = (uint64_t)my_shard * own_cnt;
     CHK(buf_ensure(h, h->ar_dir, (own_cnt + (range_cap - n_buckets)) * (CAP / 64) * sizeof(SkDirEnt)));
     SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    bool use_count2 = CAP == 4096 && h->count_kernel == 2 && !h->phase_limit;
+    int extra_attempts = 0;
+    for (int attempt = 0; attempt < 3 + extra_attempts; ++attempt) {
         CHK(ensure_node_arrays());
         for (int set = 0; set < 2; ++set) {
             CHK(buf_ensure(h, h->ar_q[set][0], q_cap * 8));
@@ -3496,10 +3558,28 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         HIPCHK(h, hipMemsetAsync(dirs, 0, own_cnt * (CAP / 64) * sizeof(SkDirEnt), h->stream));
         SkCountOut out{h->d_keys, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
                        qk[0], qc[0], q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, id_tag, sc_dev};
+        // split_recs: records beyond which a bucket starts in hash sub-ranges: ~3300 distinct k-mers (80 % of the table: the
+        // mean is 36 %, so this is the far tail -- a bucket counted in sub-ranges turns in-bucket successors into queries)
+        uint32_t split_recs = 0;
+        if (est_distinct > 0.0 && n_rec)
+            split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(64.0, (CAP * 0.80) / (est_distinct / (double)n_rec)));
+        if (use_count2 && n_rec) {
+            auto kern2 = k_sk_count2<ST>;
+            const size_t lds2 = sizeof(Cnt2Lds<ST>);
+            HIPCHK(h, hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
+            const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);  // persistent, one workgroup per CU
+            SkCount2Args a2{out, b_start, b_cnt, w0[where], w1[where], (const void *)st[where], n_buckets, split_recs, k};
+            SkCount2Args *d_a2 = (SkCount2Args *)(h->d_scalars + 64);
+            HIPCHK(h, hipMemcpyAsync(d_a2, &a2, sizeof(a2), hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(kern2, dim3(grid), dim3(Cnt2Cfg<ST>::NT), lds2, h->stream, (const SkCount2Args *)d_a2);
+            HIPCHK(h, hipGetLastError());
+        }
         auto kern = k_sk_count<ST, CAP>;
         const size_t lds = sizeof(CntLds<ST, CAP>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (n_rec) {
+        if (n_rec && !use_count2) {
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
             constexpr int NT = CntCfg<ST, CAP>::NT;
@@ -3509,11 +3589,6 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             static_assert(sizeof(SkCountOut) <= 64 * 8, "descriptor slot");
             SkCountOut *d_out = (SkCountOut *)(h->d_scalars + 64);
             HIPCHK(h, hipMemcpyAsync(d_out, &out, sizeof(out), hipMemcpyHostToDevice, h->stream));
-            // records beyond which a bucket starts in hash sub-ranges: ~3300 distinct k-mers (80 % of the table: the
-            // mean is 36 %, so this is the far tail -- a bucket counted in sub-ranges turns in-bucket successors into queries)
-            uint32_t split_recs = 0;
-            if (est_distinct > 0.0 && n_rec)
-                split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(64.0, (CAP * 0.80) / (est_distinct / (double)n_rec)));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, h->stream, b_start, b_cnt, w0[where], w1[where],
                                st[where], k, m, n_buckets, (const SkCountOut *)d_out, split_recs, h->phase_limit);
             HIPCHK(h, hipGetLastError());
@@ -3526,13 +3601,19 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         // the usual bound (one query per record) no longer holds, retry with the safe one
         if (sc[0] & (8 | 32)) break;  // not a sizing problem
         bool again = false;
+        if (use_count2 && (sc[0] & (512 | 2048))) {
+            if (sc[0] & 2048) { h->err = "internal: k_sk_count2 counted a bucket's nodes, edges or queries inconsistently"; return DBG_E_HIP; }
+            use_count2 = false;  // an edge seen more than 65 535 times: the kernel with 32-bit counters
+            ++extra_attempts;
+            again = true;
+        }
         if ((sc[0] & 16) && (node_cap < node_cap_max || edge_cap < edge_cap_max) && !node_capacity_hint) {
             node_cap = node_cap_max;  // the estimate was low
             edge_cap = edge_cap_max;
             again = true;
         }
         if ((sc[0] & 64) && q_cap < n_edge_inst + 1024) { q_cap = n_edge_inst + 1024; again = true; }
-        if (!again || attempt == 2) break;
+        if (!again || attempt == 2 + extra_attempts) break;
     }
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }
@@ -3825,6 +3906,12 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
         }
         where = 0;
         if (nb3 > 1) {
+            if (!w0[1]) {  // callers that start at level 2 may bring one record set only
+                CHK(buf_ensure(h, h->ar_rec[1][0], (n_rec + 16) * 8));
+                CHK(buf_ensure(h, h->ar_rec[1][1], (n_rec + 16) * 8));
+                CHK(buf_ensure(h, h->ar_rec[1][2], (n_rec + 16) * sizeof(ST)));
+                w0[1] = (uint64_t *)h->ar_rec[1][0].p; w1[1] = (uint64_t *)h->ar_rec[1][1].p; st[1] = (ST *)h->ar_rec[1][2].p;
+            }
             const uint64_t p_lo = pre ? b_lo * nb2 : 0, p_n = pre ? (uint64_t)bps * nb2 : n_l2;
             CHK((multisplit_level<ST, true>(h, l2_start + p_lo, l2_cnt + p_lo, (uint32_t)p_n, 1, n_rec, w0[0], w1[0], st[0], w0[1], w1[1],
                                             st[1], top - SK_BUCKET_BITS, nb3, b_start + p_lo * nb3, b_cnt + p_lo * nb3, h->ar_misc[2],
@@ -3857,7 +3944,11 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
         h->n_edge_inst = n_edge_inst;
     }
     // ---- per-bucket counting
-    const uint64_t node_cap_max = std::min<uint64_t>(n_inst, 0xFFFFFFF0ull);
+    // sharded ids carry the owner in bits 31:29; the parts of a multi-pass build keep it in a byte of its own
+    const uint64_t id_limit = (shard_bits && !h->wide_owner) ? (h->shard_node_limit ? h->shard_node_limit : (1ull << 29) - 16)
+                                                             : 0xFFFFFFF0ull;
+    const uint32_t id_tag = (shard_bits && !h->wide_owner) ? ((uint32_t)my_shard << 29) : 0u;
+    const uint64_t node_cap_max = std::min<uint64_t>(n_inst, id_limit);
     const uint64_t edge_cap_max = std::min<uint64_t>(n_edge_inst + 16, 0xFFFFFFF0ull);
     uint64_t node_cap = node_cap_max;
     if (est_distinct > 0.0)
@@ -3900,7 +3991,7 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
         HIPCHK(h, hipMemsetAsync(ranges, 0, n_buckets * sizeof(SkRange), h->stream));
         HIPCHK(h, hipMemsetAsync(dirs, 0, own_cnt * (WCAP / 64) * sizeof(SkDirEnt), h->stream));
         WSkCountOut out{h->d_keys, h->d_keys_hi, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
-                        q_lo, q_hi, q_col, q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, sc_dev};
+                        q_lo, q_hi, q_col, q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, sc_dev, id_tag};
         auto kern = k_wsk_count<ST>;
         const size_t lds = sizeof(WCntLds<ST>);
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3940,14 +4031,60 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
     }
     h->csr_built = true;
     h->dense_pending = true;
-    const uint64_t n_q = sc[5], n_ranges = n_buckets + sc[6];
+    uint64_t n_q = sc[5];
+    const uint64_t n_ranges = n_buckets + sc[6];
     h->stats.n_queries = n_q;
     SkGeom geom{k, m, l1, l2 > 0 ? nb2 : 1, fb2, l2_pow, nb3, fb3, shard_bits, my_shard, own_lo, own_cnt};
     {
+        // successors in another bucket.  Of this shard: through the target range's directory.  Of another shard: grouped
+        // by owner and parked as (lo, hi) pairs for the exchange (dbg_shard_answer / dbg_shard_apply), as for k <= 31.
         Timer t(h->stream);
+        const uint64_t *r_lo = q_lo, *r_hi = q_hi;
+        const uint32_t *r_col = q_col;
+        int stride = 1;
+        if (shard_bits && n_q) {
+            CHK(buf_ensure(h, h->ar_shard[4], n_q * 8));
+            CHK(buf_ensure(h, h->ar_q[1][0], n_q * 8));
+            CHK(buf_ensure(h, h->ar_q[1][1], n_q * 8));
+            CHK(buf_ensure(h, h->ar_q[1][2], n_q * 4));
+            uint64_t *q_meta = (uint64_t *)h->ar_shard[4].p;
+            uint64_t *s_lo = (uint64_t *)h->ar_q[1][0].p, *s_meta = (uint64_t *)h->ar_q[1][1].p;
+            uint32_t *s_col = (uint32_t *)h->ar_q[1][2].p;
+            hipLaunchKernelGGL(k_wq_bucket, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, q_lo, q_hi, q_meta, n_q, k, m);
+            HIPCHK(h, hipGetLastError());
+            CHK(buf_ensure(h, h->ar_misc[7], 512 * 16 + 16));
+            uint64_t *q_seg = (uint64_t *)h->ar_misc[7].p;
+            const int nsh = 1 << shard_bits;
+            const uint64_t root[2] = {0, n_q};
+            HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
+            uint64_t *o_start = q_seg + 2, *o_cnt = o_start + nsh;
+            CHK((multisplit_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, 1, n_q, q_lo, q_meta, q_col, s_lo, s_meta, s_col,
+                                                  40 + SK_BUCKET_BITS - shard_bits, nsh, o_start, o_cnt, h->ar_misc[2],
+                                                  h->ar_misc[3], h->ar_misc[4])));
+            ShardState &sh = shard_of(h);
+            sh.q_start.assign(nsh, 0);
+            sh.q_cnt.assign(nsh, 0);
+            HIPCHK(h, hipMemcpyAsync(sh.q_start.data(), o_start, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipMemcpyAsync(sh.q_cnt.data(), o_cnt, (size_t)nsh * 8, hipMemcpyDeviceToHost, h->stream));
+            CHK(buf_ensure(h, h->ar_shard[0], n_q * 16));
+            CHK(buf_ensure(h, h->ar_shard[3], n_q * 4));
+            uint64_t *pairs = (uint64_t *)h->ar_shard[0].p;
+            hipLaunchKernelGGL(k_wq_park, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, n_q, s_lo, s_meta, q_hi, pairs);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(h->ar_shard[3].p, s_col, n_q * 4, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            const uint64_t mine_at = sh.q_start[my_shard], mine_n = sh.q_cnt[my_shard];
+            sh.n_remote = n_q - mine_n;
+            sh.q_cnt[my_shard] = 0;  // what is left in the lists is remote
+            r_lo = pairs + 2 * mine_at;
+            r_hi = r_lo + 1;
+            r_col = (const uint32_t *)h->ar_shard[3].p + mine_at;
+            stride = 2;
+            n_q = mine_n;
+        }
         if (n_q) {
-            hipLaunchKernelGGL(k_wsucc_resolve, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, q_lo, q_hi, q_col, n_q, geom, ranges,
-                               n_buckets, n_ranges, dirs, h->d_keys, h->d_keys_hi, h->n_nodes, h->d_col, shard_bits ? 1 : 0, sc_dev);
+            hipLaunchKernelGGL(k_wsucc_resolve, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, r_lo, r_hi, stride, r_col, n_q, geom,
+                               ranges, n_buckets, n_ranges, dirs, h->d_keys, h->d_keys_hi, h->n_nodes, h->d_col, id_tag, sc_dev);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -4285,8 +4422,9 @@ static int shard_build_wsk(dbg *h, int k, int n_shards, int my_shard, const uint
     int rc = wsk_count<uint64_t, uint32_t>(h, k, d_rb, nullptr, nullptr, 0, n_rec, n_rec * (uint64_t)w, n_rec * (uint64_t)w, in_w0, d_w1,
                                            (const uint64_t *)nullptr, w0, w1, st, shard_bits, my_shard, &pre);
     if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
-    for (int d = 0; d < n_shards; ++d) { q_starts[d] = 0; q_counts[d] = 0; }
-    *d_q_keys = nullptr;
+    // successors owned by other shards: (lo, hi) pairs grouped by owner (two words per query)
+    for (int d = 0; d < n_shards; ++d) { q_starts[d] = sh.q_start[d]; q_counts[d] = sh.q_cnt[d]; }
+    *d_q_keys = h->ar_shard[0].p;
     h->partial_graph = n_shards > 1;
     h->stats.ms_build_total = t_total.stop();
     return DBG_OK;
@@ -4483,6 +4621,12 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     const SkRange *ranges = (const SkRange *)h->ar_misc[6].p;
     const SkDirEnt *dirs = (const SkDirEnt *)h->ar_dir.p;
     if (!ranges || !dirs || h->sk_cap != 4096) { h->err = "dbg_shard_build must run first"; return DBG_E_ARG; }
+    if (h->k > 31) {  // two-word k-mers: the keys come as (lo, hi) pairs
+        if (!h->d_keys_hi) { h->err = "dbg_shard_build (LDS engine) must run first"; return DBG_E_ARG; }
+        hipLaunchKernelGGL(k_wsucc_resolve, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const uint64_t *)d_q_keys,
+                           (const uint64_t *)d_q_keys + 1, 2, (const uint32_t *)nullptr, n, h->sk_geom, ranges, h->sk_n_buckets,
+                           h->sk_n_ranges, dirs, h->d_keys, h->d_keys_hi, h->n_nodes, (uint32_t *)d_answers, 0u, sc_dev);
+    } else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_succ_resolve<4096>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream,
                        (const uint64_t *)d_q_keys, (const uint32_t *)nullptr, n, h->sk_geom, ranges, h->sk_n_buckets,
                        h->sk_n_ranges, dirs, h->d_keys, h->n_nodes, (uint32_t *)d_answers, 0u, sc_dev);
@@ -4688,6 +4832,12 @@ static int part_compact(dbg *sub, uint64_t n_dir_entries) {
     const uint64_t n = sub->n_nodes, ne = sub->n_edges;
     const int st_slot = sub->stamps_st_bytes == 8 ? 1 : 7;
     CHK(buf_shrink(sub, sub->ar_node[0], n * 8));
+    if (sub->k > 31) {  // two-word k-mers: the high key words stay, the gathered record bases go
+        CHK(buf_shrink(sub, sub->ar_wide[5], n * 8));
+        sub->d_keys_hi = (uint64_t *)sub->ar_wide[5].p;
+        for (int i : {0, 1, 2, 3, 4}) buf_free(sub, sub->ar_wide[i]);
+        buf_free(sub, sub->ar_shard[4]);
+    }
     CHK(buf_shrink(sub, sub->ar_node[st_slot], n * (uint64_t)sub->stamps_st_bytes));
     CHK(buf_shrink(sub, sub->ar_node[3], n));
     CHK(buf_shrink(sub, sub->ar_csr[3], (n + 1) * 4));
@@ -4752,7 +4902,9 @@ __global__ __launch_bounds__(256) void k_apply_part(const uint32_t *__restrict__
 template <class ST, class STI>
 static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_passes, int n_senders, const uint64_t *grp_cnt,
                            const uint64_t *sender_off, const uint64_t *stamp_add, const uint64_t *in_w0,
-                           const uint64_t *in_w1, const STI *in_st) {
+                           const uint64_t *in_w1, const STI *in_st, const uint64_t *pk = nullptr) {
+    // pk: two-word k-mers (k > 31): the packed bases the records' positions (in_w0) point into -- the packed reads of a
+    // single-GPU build, or the bases received with the records (record i at position 128 i); the passes then run wsk_count
     int shard_bits = 0;
     while ((1 << shard_bits) < n_virtual) ++shard_bits;
     const int bps = 512 / n_virtual;            // level-1 groups per virtual shard
@@ -4810,7 +4962,12 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
         pre.stamp_add = stamp_add;
         pre.in_st = in_st;
         int rc = DBG_OK;
-        if (n_rec_p)
+        if (n_rec_p && pk) {
+            if constexpr (sizeof(STI) == 4)
+                rc = wsk_count<ST, uint32_t>(sub, k, pk, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w, in_w0,
+                                             in_w1, (const ST *)nullptr, pw0, pw1, pst, shard_bits, v_first + p, &pre);
+            else { sub->err = "two-word records carry 32-bit rank-local stamps"; rc = DBG_E_ARG; }
+        } else if (n_rec_p)
             rc = sk_count_from_segments<ST, 4096, STI>(sub, k, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w,
                                                        in_w0, in_w1, (const ST *)nullptr, pw0, pw1, pst, 0, shard_bits, v_first + p, &pre);
         if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
@@ -4845,10 +5002,12 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
             ShardState &sh = shard_of(sub);
             const uint64_t *keys = (const uint64_t *)sub->ar_shard[0].p;
             const uint32_t *qcol = (const uint32_t *)sub->ar_shard[3].p;
+            const uint64_t qw = pk ? 2 : 1;  // two-word k-mers: a query is a (lo, hi) pair
             for (int q = 0; q < n_passes; ++q) {
                 const int vq = v_first + q;
                 if (q == p || !sh.q_cnt[vq]) continue;
-                int rc = dbg_shard_answer(mp->part[q], keys + sh.q_start[vq], sh.q_cnt[vq], ans);
+                if (!mp->part[q]->n_nodes) { h->err = "part " + std::to_string(q) + " is empty and cannot own a successor"; return DBG_E_HIP; }
+                int rc = dbg_shard_answer(mp->part[q], keys + qw * sh.q_start[vq], sh.q_cnt[vq], ans);
                 if (rc != DBG_OK) { h->err = "part " + std::to_string(q) + ": " + mp->part[q]->err; return rc; }
                 hipLaunchKernelGGL(k_apply_part, dim3(grid_for(sh.q_cnt[vq], 256)), dim3(256), 0, h->stream, qcol + sh.q_start[vq],
                                    ans, sh.q_cnt[vq], (uint8_t)vq, sub->d_col, mp->col_owner[p], (unsigned long long *)h->d_scalars);
@@ -4900,9 +5059,40 @@ static int build_multipass_t(dbg *h, int k, int n_passes) {
     return rc;
 }
 
+// two-word k-mers (k = 32..63, reads below 2 GiB): records by position into the packed reads, split by the 512 level-1 groups
+static int build_multipass_wsk(dbg *h, int k, int n_passes) {
+    uint64_t *pk = nullptr, *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
+    uint32_t *st[2];
+    uint32_t n_seg = 0;
+    CHK(wsk_extract<uint32_t>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    const int nb1 = 512;
+    CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
+    uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
+    std::vector<uint64_t> cnt(nb1), start(nb1);
+    {
+        Timer t(h->stream);
+        CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+                                              6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3],
+                                              h->ar_misc[4], 0, nullptr, nullptr, h->host_seg_cnt.data())));
+        HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(start.data(), c1_start, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
+        h->stats.ms_partition = t.stop();
+        for (auto &b : h->ar_rec[0]) buf_free(h, b);
+    }
+    const uint64_t off0 = start[0], add0 = 0;
+    int rc = multipass_parts<uint32_t, uint32_t>(h, k, n_passes, 0, n_passes, 1, cnt.data(), &off0, &add0, w0[1], w1[1], st[1], pk);
+    for (auto &b : h->ar_rec[1]) buf_free(h, b);
+    buf_free(h, h->ar_wide[0]);
+    return rc;
+}
+
 extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     if (!h) return DBG_E_ARG;
-    if (k < 1 || k > 31) { h->err = "multi-pass builds take k in 1..31 (one-word k-mers)"; return DBG_E_ARG; }
+    if (k < 1 || k > 63) { h->err = "multi-pass builds take k in 1..63"; return DBG_E_ARG; }
+    if (k > 31 && (h->wide_engine != 1 || h->n_bytes >= (1ull << 31))) {
+        h->err = "multi-pass builds of two-word k-mers use the LDS engine (\"wide_engine\" 1) on reads below 2 GiB";
+        return DBG_E_ARG;
+    }
     if (n_passes < 1 || n_passes > 64 || (n_passes & (n_passes - 1))) { h->err = "n_passes must be a power of two up to 64"; return DBG_E_ARG; }
     if (!h->d_offsets) { h->err = "no reads set"; return DBG_E_ARG; }
     if (h->engine != 0) { h->err = "multi-pass builds use the super-k-mer engine"; return DBG_E_ARG; }
@@ -4916,7 +5106,8 @@ extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     if (!h->is_dna) { h->err = "multi-pass builds take ACGT reads"; return DBG_E_ALPHABET; }
     h->k = k;
     Timer t_total(h->stream);
-    int rc = (h->n_bytes < (1ull << 31)) ? build_multipass_t<uint32_t>(h, k, n_passes) : build_multipass_t<uint64_t>(h, k, n_passes);
+    int rc = k > 31 ? build_multipass_wsk(h, k, n_passes)
+                    : (h->n_bytes < (1ull << 31)) ? build_multipass_t<uint32_t>(h, k, n_passes) : build_multipass_t<uint64_t>(h, k, n_passes);
     if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->arena_freed = true; pool_trim(h); h->err = keep; return rc; }
     h->stats.ms_build_total = t_total.stop();
     h->arena_freed = true;
@@ -4934,7 +5125,10 @@ extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_s
                                          const void *d_w1, const void *d_st, int stamp_bytes, const uint64_t *recv_counts,
                                          const uint64_t *stamp_base, const uint64_t *sender_bucket_counts) {
     CHK(shard_args_ok(h, k, n_shards));
-    if (k > 31) { h->err = "multi-pass builds take k in 1..31 (one-word k-mers)"; return DBG_E_ARG; }
+    if (k > 31 && (h->wide_engine != 1 || stamp_bytes != 4)) {
+        h->err = "ranks x passes of two-word k-mers: the LDS engine's records by value (\"wide_engine\" 1), 4-byte stamps";
+        return DBG_E_ARG;
+    }
     if (my_shard < 0 || my_shard >= n_shards || !recv_counts || !stamp_base || !sender_bucket_counts) return DBG_E_ARG;
     if (stamp_bytes != 4 && stamp_bytes != 8) { h->err = "stamp_bytes must be 4 or 8"; return DBG_E_ARG; }
     if (n_passes < 1 || (n_passes & (n_passes - 1)) || n_shards * n_passes > 64) {
@@ -4961,7 +5155,17 @@ extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_s
     h->k = k;
     h->stats.n_records = n_rec;
     Timer t_total(h->stream);
-    int rc = stamp_bytes == 8
+    int rc;
+    if (k > 31) {  // d_w0 holds the received bases, four words per record: the receiver's "packed reads", record i at position 128 i
+        CHK(buf_ensure(h, h->ar_shard[2], (n_rec + 16) * 8));
+        uint64_t *pos = (uint64_t *)h->ar_shard[2].p;
+        if (n_rec) hipLaunchKernelGGL(k_wsk_iota128, dim3(grid_for(n_rec, 256)), dim3(256), 0, h->stream, n_rec, pos);
+        HIPCHK(h, hipGetLastError());
+        rc = multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
+                                                 off.data(), add.data(), pos, (const uint64_t *)d_w1, (const uint32_t *)d_st,
+                                                 (const uint64_t *)d_w0);
+    } else
+    rc = stamp_bytes == 8
                  ? multipass_parts<uint64_t, uint64_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
                                                        off.data(), add.data(), (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)d_st)
                  : multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
@@ -5077,6 +5281,22 @@ extern "C" int dbg_part_device_views(dbg_t *h, int part, const void **d_keys, co
     if (d_col) *d_col = sub->d_col;
     if (d_col_part) *d_col_part = mp->col_owner[part];
     if (d_cnt) *d_cnt = sub->d_ecnt;
+    return DBG_OK;
+}
+
+// upper key words of a part's nodes (two-word k-mers, k > 31; all zero below): keys_hi[n] to the host and / or the
+// device pointer (valid until the next build; NULL for one-word k-mers).  Either output may be NULL.
+extern "C" int dbg_part_keys_hi(dbg_t *h, int part, uint64_t *keys_hi, const void **d_keys_hi) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp || part < 0 || part >= mp->n_passes) { if (h) h->err = "no such part (dbg_build_multipass must run first)"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    dbg *sub = mp->part[part];
+    const bool wide = sub->k > 31 && sub->d_keys_hi && sub->n_nodes;
+    if (d_keys_hi) *d_keys_hi = wide ? sub->d_keys_hi : nullptr;
+    if (keys_hi && sub->n_nodes) {
+        if (wide) { D2H(h, keys_hi, sub->d_keys_hi, sub->n_nodes * 8); HIPCHK(h, hipStreamSynchronize(h->stream)); }
+        else memset(keys_hi, 0, sub->n_nodes * 8);
+    }
     return DBG_OK;
 }
 

@@ -514,6 +514,7 @@ struct WSkCountOut {
     SkDirEnt *dirs;
     uint64_t own_lo, own_cnt;
     unsigned long long *scalars;  // [0] err [4] nodes | edges << 32 [5] queries [6] extra ranges
+    uint32_t id_tag;           // OR-ed into every successor id written (sharded builds with tagged ids: owner << 29)
 };
 
 typedef const WSkCountOut __attribute__((address_space(4))) *WSkOutConstPtr;
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count(const uint64_t *__restric
                 for (int b = 0; b < 4; ++b) {
                     if (c[b]) {
                         const uint32_t v = (uint32_t)(nsucc[u] >> (16 * b)) & 0xFFFFu;
-                        ow.col[e] = v < 0x8000u ? (uint32_t)(gbase + v) : NO_NODE;
+                        ow.col[e] = v < 0x8000u ? ((uint32_t)(gbase + v) | ow.id_tag) : NO_NODE;
                         ow.ecnt[e] = c[b];
                         ++e;
                     }
@@ -1053,16 +1054,33 @@ __device__ inline uint32_t wdir_find(const SkDirEnt *__restrict__ dirs, uint64_t
     return NO_NODE;
 }
 
+// sort key of the owner split of a sharded build: bucket hash of every query in bits 40.. of q_meta, its index below
+__global__ __launch_bounds__(256) void k_wq_bucket(const uint64_t *__restrict__ q_lo, const uint64_t *__restrict__ q_hi,
+                                                   uint64_t *q_meta, uint64_t n, int k, int m) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) q_meta[i] = ((uint64_t)wkmer_bucket22(K128{q_hi[i], q_lo[i]}, k, m) << 40) | i;
+}
+
+// the queries grouped by owner, as they travel: (lo, hi) pairs; the high words come through the index the sort kept
+__global__ __launch_bounds__(256) void k_wq_park(uint64_t n, const uint64_t *__restrict__ lo_sorted,
+                                                 const uint64_t *__restrict__ meta_sorted, const uint64_t *__restrict__ hi_src,
+                                                 uint64_t *pairs) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pairs[2 * i] = lo_sorted[i];
+    pairs[2 * i + 1] = hi_src[meta_sorted[i] & ((1ull << 40) - 1)];
+}
+
+// q_lo / q_hi: query i at [i * stride] (1: two arrays; 2: (lo, hi) pairs, q_hi = q_lo + 1).  id_tag is OR-ed into the ids.
 __global__ __launch_bounds__(256) void k_wsucc_resolve(const uint64_t *__restrict__ q_lo, const uint64_t *__restrict__ q_hi,
-                                                       const uint32_t *__restrict__ q_col, uint64_t n, SkGeom g,
+                                                       int stride, const uint32_t *__restrict__ q_col, uint64_t n, SkGeom g,
                                                        const SkRange *__restrict__ ranges, uint64_t n_buckets, uint64_t n_ranges,
                                                        const SkDirEnt *__restrict__ dirs, const uint64_t *__restrict__ keys,
                                                        const uint64_t *__restrict__ keys_hi, uint64_t n_nodes, uint32_t *out,
-                                                       int allow_foreign /* a shard: successors owned elsewhere stay unresolved */,
-                                                       unsigned long long *scalars) {
+                                                       uint32_t id_tag, unsigned long long *scalars) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const K128 key{q_hi[i], q_lo[i]};
+    const K128 key{q_hi[i * stride], q_lo[i * stride]};
     const uint64_t bucket = sk_bucket_of(wkmer_bucket22(key, g.k, g.m), g);
     uint32_t id = NO_NODE;
     if (bucket >= g.own_lo && bucket < g.own_lo + g.own_cnt) {
@@ -1081,9 +1099,8 @@ __global__ __launch_bounds__(256) void k_wsucc_resolve(const uint64_t *__restric
             if (have) id = wdir_find(dirs, g.own_cnt + (ri - n_buckets), keys, keys_hi, n_nodes, key);
         }
     }
-    else if (allow_foreign) return;
-    if (id == NO_NODE) { atomicOr(&scalars[0], 128ull); return; }
-    out[q_col ? q_col[i] : i] = id;
+    if (id == NO_NODE) { atomicOr(&scalars[0], 128ull); return; }  // every successor k-mer exists as a node of its owner
+    out[q_col ? q_col[i] : i] = id | id_tag;
 }
 
 static_assert(sizeof(WCntLds<uint64_t>) <= 160 * 1024 && sizeof(WCntLds<uint32_t>) <= 160 * 1024, "LDS of the two-word count kernel");

@@ -97,19 +97,14 @@ class DeviceReads:
         """``[self[i] for i in indices]`` without bringing every read to the host: the selected reads are gathered on
         the device (pull_out_read of construct_graph is 3 % of the reads at the BASELINE size)."""
         idx = np.asarray(indices, dtype=np.int64)
+        idx = np.where(idx < 0, idx + self._n, idx)
+        if idx.size and (int(idx.min()) < 0 or int(idx.max()) >= self._n):
+            raise IndexError("read index out of range")
         if self._host is not None or idx.size == 0 or idx.size > self._n // 4:
             return [self[int(i)] for i in idx]
-        import torch
-        bases, offs = self._graph.reads_tensors()
-        ix = torch.as_tensor(idx, device=bases.device)
-        beg = offs[ix]
-        length = offs[ix + 1] - beg
-        out_beg = torch.cumsum(length, 0) - length
-        total = int(length.sum().item())
-        row = torch.repeat_interleave(torch.arange(idx.size, device=bases.device), length)
-        src = torch.arange(total, device=bases.device) - out_beg[row] + beg[row]
-        text = bases[src].cpu().numpy().tobytes().decode("latin-1")
-        return [text[a:a + b] for a, b in zip(out_beg.cpu().tolist(), length.cpu().tolist())]
+        chars, off = self._graph.take_reads(idx)  # dbg_take_reads: gathered on the device, one copy of the selection
+        text = chars.tobytes().decode("latin-1")
+        return [text[int(a):int(b)] for a, b in zip(off[:-1], off[1:])]
 
 
 def read_reads_device(fname):
@@ -356,10 +351,11 @@ class ContigList(list):
     scores = None
     _graph = None
     _generation = None
+    _walk = None
 
     def sorted_fasta(self):
-        if self._graph is None or self._generation != self._graph.generation:
-            raise ValueError("the device contigs of this list are gone (the handle built another graph)")
+        if self._graph is None or self._generation != self._graph.generation or self._walk != self._graph.walks:
+            raise ValueError("the device contigs of this list are gone (the handle built another graph or walked again)")
         return self._graph.export_sorted_fasta()[0].decode("latin-1")
 
 
@@ -600,7 +596,7 @@ def output_contigs(g, branch_kmer, already_pull_out):
     text = chars.tobytes().decode("latin-1")
     out = ContigList(text[int(off[i]):int(off[i + 1])] for i in order)
     out.scores = [int(score[i]) for i in order]
-    out._graph, out._generation = graph, graph.generation
+    out._graph, out._generation, out._walk = graph, graph.generation, graph.walks
     return out
 
 

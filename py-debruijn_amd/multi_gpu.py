@@ -14,9 +14,9 @@ link of a rank at once (a ring collective would be bound by one link):
   5. all-to-all of the answers (uint32 node ids) back                 -- dbg_shard_apply
 
 After step 5 every rank holds its shard: node ids are (owner << 29) | local id, stamps are global.
-Two-word k-mers (k > 31) go through the same five calls: their records are the k-mer instances themselves
-(owner = top bits of the k-mer hash), steps 4-5 carry nothing, and the successors are resolved by
-``gather_graph`` / dbg_import_graph on the gathered node set.
+Two-word k-mers (k > 31) go through the same five calls: a record travels by value (four words of bases, the meta
+word, the rank-local stamp: dbg_wsk.h), owner = top bits of the minimizer-bucket hash as for k <= 31, and a
+successor query is a (lo, hi) pair of words.
 Traversal (prune / tips / pull-out reads / contig walk) crosses ranks; ``gather_graph`` moves the shards
 and the reads to one rank, whose handle then behaves like a single-GPU build (gather first).
 The graph object may be an ``_dbg.Graph`` or anything with the same four shard_* methods
@@ -149,12 +149,31 @@ class ExchangeCheck:
         return out
 
     def verify(self):
-        for what, flags in self.bad:
+        """Collective: every rank calls it at the same point.  A rank that received a damaged message must not be the only
+        one to leave the protocol -- the others would block in the next collective until the watchdog fires -- so the
+        per-rank findings travel in one small all-gather and EVERY rank raises, naming (receiver, senders, array)."""
+        dist = self.dist
+        w = dist.get_world_size()
+        mine = torch.zeros(max(1, len(self.bad)), dtype=torch.int64)
+        for i, (what, flags) in enumerate(self.bad):
             if flags.numel() and bool(flags.any().item()):
-                ranks = [r for r, f in enumerate(flags.tolist()) if f]
-                raise RuntimeError(f"sharded build: rank {self.dist.get_rank()} received damaged '{what}' messages from "
-                                   f"ranks {ranks} (digest of the received bytes != digest the sender computed)")
+                mine[i] = sum(1 << r for r, f in enumerate(flags.tolist()) if f)  # bit r: the message from rank r
+        names = [what for what, _ in self.bad]
         self.bad = []
+        if w > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
+            send = mine.to(dev)
+            got = [torch.empty_like(send) for _ in range(w)]
+            dist.all_gather(got, send)
+            table = [t.cpu().tolist() for t in got]
+        else:
+            table = [mine.tolist()]
+        found = [(recv, names[i] if i < len(names) else "?", [r for r in range(w) if (mask >> r) & 1])
+                 for recv, row in enumerate(table) for i, mask in enumerate(row) if mask]
+        if found:
+            text = "; ".join(f"rank {recv} received damaged '{what}' messages from ranks {senders}" for recv, what, senders in found)
+            raise RuntimeError(f"sharded build (seen from rank {dist.get_rank()}): {text} "
+                               f"(digest of the received bytes != digest the sender computed)")
 
 
 class _NoCheck:
@@ -219,22 +238,23 @@ def sharded_build(g, k, dist, check=True):
     total_q = torch.tensor([sum(q_counts)], dtype=torch.int64, device="cpu" if _is_gloo(dist) else device)
     dist.all_reduce(total_q, op=dist.ReduceOp.SUM)
     if int(total_q.item()):
-        groups = [q_keys[s:s + c] for s, c in zip(q_starts, q_counts)]
+        qw = g.query_words() if hasattr(g, "query_words") else 1  # two-word k-mers: a query is a (lo, hi) pair
+        groups = [q_keys[qw * s:qw * (s + c)] for s, c in zip(q_starts, q_counts)]
         packed = torch.cat(groups) if groups else q_keys[:0]
-        keys_in = xc.alltoallv(packed, q_counts, q_recv, "successor queries")
+        keys_in = xc.alltoallv(packed, [qw * c for c in q_counts], [qw * c for c in q_recv], "successor queries")
         if not _is_gloo(dist) and device.type == "cuda":
             torch.cuda.synchronize(device)
         answers_out = g.shard_answer(keys_in)
         back = xc.alltoallv(answers_out, q_recv, q_counts, "successor answers")
         xc.verify()
-        answers = torch.empty(q_keys.numel(), dtype=torch.int32, device=device)
+        answers = torch.empty(q_keys.numel() // qw, dtype=torch.int32, device=device)
         off = 0
         for s, c in zip(q_starts, q_counts):
             answers[s:s + c] = back[off:off + c]
             off += c
         if not _is_gloo(dist) and device.type == "cuda":
             torch.cuda.synchronize(device)
-    else:  # one rank, or two-word k-mers: nothing to ask
+    else:  # one rank (or the global-table engine of two-word k-mers): nothing to ask
         answers = torch.empty(0, dtype=torch.int32, device=device)
     g.shard_apply(answers)
     return g
@@ -284,6 +304,7 @@ def sharded_build_multipass(g, k, dist, n_passes, check=True):
     cdev = "cpu" if _is_gloo(dist) else device
     for p in range(P):
         q_starts, q_counts, q_keys = g.part_queries(p)
+        qw = g.query_words() if hasattr(g, "query_words") else 1  # two-word k-mers: a query is a (lo, hi) pair
         # what I ask every (rank, part) about; the owner learns the split of my message over its parts
         mine = torch.tensor(q_counts, dtype=torch.int64, device=cdev)
         theirs = torch.empty_like(mine)
@@ -291,9 +312,9 @@ def sharded_build_multipass(g, k, dist, n_passes, check=True):
         theirs = [int(x) for x in theirs.tolist()]
         send = [sum(q_counts[d * P:(d + 1) * P]) for d in range(w)]
         recv = [sum(theirs[s * P:(s + 1) * P]) for s in range(w)]
-        groups = [q_keys[q_starts[v]:q_starts[v] + q_counts[v]] for v in range(w * P) if q_counts[v]]
+        groups = [q_keys[qw * q_starts[v]:qw * (q_starts[v] + q_counts[v])] for v in range(w * P) if q_counts[v]]
         packed = torch.cat(groups) if groups else q_keys[:0]
-        keys_in = xc.alltoallv(packed, send, recv, "successor queries")
+        keys_in = xc.alltoallv(packed, [qw * c for c in send], [qw * c for c in recv], "successor queries")
         if not _is_gloo(dist) and device.type == "cuda":
             torch.cuda.synchronize(device)
         out, pos = [], 0
@@ -301,7 +322,7 @@ def sharded_build_multipass(g, k, dist, n_passes, check=True):
             for q in range(P):
                 n = theirs[s * P + q]
                 if n:
-                    out.append(g.part_answer(q, keys_in[pos:pos + n]))
+                    out.append(g.part_answer(q, keys_in[qw * pos:qw * (pos + n)]))
                 pos += n
         answers_out = torch.cat(out) if out else torch.empty(0, dtype=torch.int32, device=device)
         back = xc.alltoallv(answers_out, recv, send, "successor answers")

@@ -33,6 +33,14 @@ def dense_counts(d):
     return counts
 
 
+def shifted(keys, keys_hi, code, k):
+    """(lo, hi) of the successor k-mers: the k-mer shifted by one base `code` (two words for k > 31)."""
+    u64 = np.uint64
+    lo_mask = u64((1 << (2 * k)) - 1) if 2 * k < 64 else u64(0xFFFFFFFFFFFFFFFF)
+    hi_mask = u64((1 << (2 * k - 64)) - 1) if 2 * k > 64 else u64(0)
+    return ((keys << u64(2)) | u64(code)) & lo_mask, ((keys_hi << u64(2)) | (keys >> u64(62))) & hi_mask
+
+
 def check_against_oracle(g, reads, read_len, k):
     want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
     parts = gather_parts(g)
@@ -44,29 +52,40 @@ def check_against_oracle(g, reads, read_len, k):
     assert keys.size == want["n_nodes"] == sz["n_nodes"] and sz["n_edges"] == int((want["counts"] != 0).sum())
     assert sz["n_kmer_instances"] == want["n_kmer_instances"] and sz["n_edge_instances"] == want["n_edge_instances"]
     o = np.argsort(stamps, kind="stable")
+    keys_hi = np.concatenate([d["keys_hi"] for d in parts])
     assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(keys_hi[o], want["keys_hi"])
     assert np.array_equal(counts[o], want["counts"])
     assert np.array_equal(flags & 1, (stamps & np.uint64(1)).astype(np.uint8))
     assert sz["n_starts"] == int(((want["stamps"] & np.uint64(1)) == 0).sum())
-    # successors: (part, local id) -> the shifted k-mer
-    mask = np.uint64((1 << (2 * k)) - 1)
-    for d in parts:
+    check_successors(parts, k)
+
+
+def check_successors(parts, k, n_passes=None):
+    """every successor (part, local id) -> the shifted k-mer; returns how many cross a rank (parts // n_passes differ)"""
+    crossing = 0
+    for v, d in enumerate(parts):
         e = d["row_ptr"][:-1].astype(np.int64).copy()
         for code in range(4):
             has = ((d["flags"] >> (1 + code)) & 1).astype(bool)
             cols, owners = d["col"][e[has]], d["col_part"][e[has]]
-            got = np.empty(cols.size, dtype=np.uint64)
+            got, got_hi = np.empty(cols.size, dtype=np.uint64), np.empty(cols.size, dtype=np.uint64)
             for q, dq in enumerate(parts):
                 sel = owners == q
                 assert np.all(cols[sel] < dq["keys"].size)
                 got[sel] = dq["keys"][cols[sel]]
+                got_hi[sel] = dq["keys_hi"][cols[sel]]
             assert owners.size == 0 or int(owners.max()) < len(parts)
-            assert np.array_equal(got, ((d["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+            lo, hi = shifted(d["keys"][has], d["keys_hi"][has], code, k)
+            assert np.array_equal(got, lo) and np.array_equal(got_hi, hi)
+            if n_passes:
+                crossing += int((owners // n_passes != v // n_passes).sum())
             e[has] += 1
+    return crossing
 
 
 @pytest.mark.parametrize("n_passes", [1, 2, 4, 8, 64])
-@pytest.mark.parametrize("k,n_reads,read_len", [(31, 6000, 150), (21, 6000, 100)])
+@pytest.mark.parametrize("k,n_reads,read_len", [(31, 6000, 150), (21, 6000, 100), (63, 6000, 150), (40, 4000, 120)])
 def test_multipass_equals_the_oracle(n_passes, k, n_reads, read_len):
     reads = synth.reads_ascii(11, n_reads * read_len // 20, n_reads, read_len, 0.01)
     g = _dbg.Graph()
@@ -165,7 +184,9 @@ def rank_reads(world, rank, n_reads, read_len, seed=31):
 @pytest.mark.parametrize("ranks,n_passes,k,n_reads,read_len,wide_stamp_ranks",
                          [(2, 4, 31, 8000, 150, ()), (4, 4, 21, 8000, 100, ()), (8, 8, 31, 16000, 150, ()),
                           (8, 1, 31, 8000, 150, ()), (1, 4, 31, 6000, 150, ()), (4, 2, 31, 8000, 150, (0, 3)),
-                          (2, 2, 21, 6000, 100, (0, 1))])
+                          (2, 2, 21, 6000, 100, (0, 1)),
+                          # two-word k-mers (BASELINE.json configs[4]): records by value, (lo, hi) queries, owner bytes
+                          (8, 1, 63, 8000, 150, ()), (4, 2, 63, 8000, 150, ()), (2, 4, 40, 6000, 120, ())])
 def test_ranks_times_passes_equal_the_oracle(ranks, n_passes, k, n_reads, read_len, wide_stamp_ranks):
     """BASELINE.json configs[3] in miniature: a sharded build whose ranks build their shards in passes
     (multi_gpu.sharded_build_multipass through the C ABI; `ranks` handles on cuda:0, one thread each, in-process
@@ -202,23 +223,9 @@ def test_ranks_times_passes_equal_the_oracle(ranks, n_passes, k, n_reads, read_l
     assert sum(sz["n_edge_instances"] for _, sz in got) == want["n_edge_instances"]
     o = np.argsort(stamps, kind="stable")
     assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"])
+    assert np.array_equal(np.concatenate([d["keys_hi"] for d in parts])[o], want["keys_hi"])
     assert np.array_equal(counts[o], want["counts"])
-    mask = np.uint64((1 << (2 * k)) - 1)
-    crossing = 0
-    for v, d in enumerate(parts):
-        e = d["row_ptr"][:-1].astype(np.int64).copy()
-        for code in range(4):
-            has = ((d["flags"] >> (1 + code)) & 1).astype(bool)
-            cols, owners = d["col"][e[has]], d["col_part"][e[has]]
-            assert owners.size == 0 or int(owners.max()) < len(parts)
-            got_keys = np.empty(cols.size, dtype=np.uint64)
-            for q, dq in enumerate(parts):
-                sel = owners == q
-                assert np.all(cols[sel] < dq["keys"].size)
-                got_keys[sel] = dq["keys"][cols[sel]]
-            assert np.array_equal(got_keys, ((d["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
-            crossing += int((owners // n_passes != v // n_passes).sum())
-            e[has] += 1
+    crossing = check_successors(parts, k, n_passes)
     assert ranks == 1 or crossing > 0  # the exchange between ranks really carried successors
 
 
@@ -306,7 +313,7 @@ def test_part_entry_points_refuse_bad_arguments():
         with pytest.raises(_dbg.DbgError):
             g.shard_build_multipass(31, n_shards, me, passes, dummy, dummy, st, [0] * n_shards, [0] * n_shards,
                                     rows if n_shards == 2 else [[0] * 170] * 3 + [[0] * 2])
-    with pytest.raises(_dbg.DbgError, match="one-word"):
-        g.shard_build_multipass(40, 2, 0, 2, dummy, dummy, st, [0, 0], [0, 0], rows)
+    with pytest.raises(_dbg.DbgError, match="4-byte stamps"):  # two-word records carry 32-bit rank-local stamps
+        g.shard_build_multipass(40, 2, 0, 2, dummy, dummy, dummy, [0, 0], [0, 0], rows)
     g.build(31)                                   # the handle still works
     assert g.sizes()["n_nodes"] > 0

@@ -184,3 +184,27 @@ def test_views_for_a_generic_alphabet(name):
     assert dict(Ev) == E and list(Ev) == list(E)
     assert list(Cv.items()) == list(ect.items())
     assert ("?" * k) not in Vv and (labels[0] + "?") not in Cv
+
+
+def test_support_score_table_cache_follows_the_dict_and_its_content():
+    """IV_sortOutputs._pack_table (no GPU needed): the packed table is reused only for the SAME dict with the SAME items.
+    A temporary dict of equal length (CPython hands its id to the next one), an in-place update and an int score
+    replaced by the equal float must all be packed afresh -- the reference reads the dict on every call."""
+    import IV_sortOutputs as iv
+
+    def values(t):
+        return iv._pack_table(t)[2].tolist(), iv._pack_table(t)[3].tolist()
+
+    seen = []
+    for a, b in ((1.5, 2.5), (10.0, 20.0), (7.0, 8.0)):   # same length, each freed before the next is made
+        seen.append(values({"ACGT": a, "TTGA": b})[0])
+    assert seen == [[1.5, 2.5], [10.0, 20.0], [7.0, 8.0]]
+    t = {"ACGT": 1.5, "TTGA": 2.5}
+    first = iv._pack_table(t)
+    assert iv._pack_table(t) is first                      # unchanged: reused
+    t["TTGA"] = 4.0                                        # value updated in place
+    assert values(t)[0] == [1.5, 4.0]
+    t["GGG"] = 1                                           # key added
+    assert values(t) == ([1.5, 4.0, 1.0], [1, 1, 0])
+    t["GGG"] = 1.0                                         # 1 == 1.0 and hash alike; the result type differs
+    assert values(t) == ([1.5, 4.0, 1.0], [1, 1, 1])

@@ -55,20 +55,25 @@ def check(shards, world, k, n_reads, read_len):
     assert np.array_equal(keys[o], want["keys"]) and np.array_equal(keys_hi[o], want["keys_hi"])
     assert np.array_equal(stamps[o], want["stamps"])       # global first-occurrence stamps
     assert np.array_equal(counts[o], want["counts"])
-    if k > 31:
-        return  # two-word k-mers: the shards carry keys, stamps and counts; successors are resolved after the gather
-    mask = np.uint64((1 << (2 * k)) - 1)
-    for r, s in enumerate(shards):                           # successors: (owner << 29) | id on the owner
+    # successors: (owner << 29) | id on the owner; the successor's k-mer is this k-mer shifted by the base (two words for k > 31)
+    u64 = np.uint64
+    lo_mask = u64((1 << (2 * k)) - 1) if 2 * k < 64 else u64(0xFFFFFFFFFFFFFFFF)
+    hi_mask = u64((1 << (2 * k - 64)) - 1) if 2 * k > 64 else u64(0)
+    for r, s in enumerate(shards):
         for code in range(4):
             has = s["counts"][:, code] != 0
             ref = s["succ"][has, code]
             assert np.all(ref != 0xFFFFFFFF)
             owner, idx = ref >> 29, ref & ((1 << 29) - 1)
             got = np.empty(ref.size, dtype=np.uint64)
+            got_hi = np.empty(ref.size, dtype=np.uint64)
             for d in range(world):
                 sel = owner == d
                 got[sel] = shards[d]["keys"][idx[sel]]
-            assert np.array_equal(got, ((s["keys"][has] << np.uint64(2)) | np.uint64(code)) & mask)
+                got_hi[sel] = shards[d]["keys_hi"][idx[sel]]
+            lo, hi = s["keys"][has], s["keys_hi"][has]
+            assert np.array_equal(got, ((lo << u64(2)) | u64(code)) & lo_mask)
+            assert np.array_equal(got_hi, ((hi << u64(2)) | (lo >> u64(62))) & hi_mask)
             assert np.all(s["succ"][~has, code] == 0xFFFFFFFF)
 
 
@@ -200,7 +205,9 @@ def test_damaged_exchange_is_detected():
         return None
 
     got = inproc_dist.run_ranks(2, one)
-    assert got[0] is None and got[1] is not None and "damaged" in got[1]
+    # the check is collective: BOTH ranks raise (a rank that carried on alone would hang in the next collective), and
+    # both name the receiver and the sender of the damaged message
+    assert all(x is not None and "rank 1 received damaged 'test' messages from ranks [0]" in x for x in got), got
 
 
 @pytest.mark.gpu

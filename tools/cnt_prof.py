@@ -11,6 +11,9 @@ import _dbg
 K = int(os.environ.get("SWEEP_K", "31"))
 reads = int(os.environ.get("SWEEP_READS", "10000000"))
 g = _dbg.Graph()
+CK = int(os.environ.get("COUNT_KERNEL", "2"))
+if K <= 31:
+    g.set_option("count_kernel", CK)
 g.synth_reads(1, reads * 5, reads, 150, 0.01)
 lib = _dbg.load_library()
 out = (C.c_ulonglong * 64)()
@@ -23,6 +26,11 @@ names = {0: "queries out + top barrier", 1: "clear + stage + barrier", 2: "dedup
          17: "lookups: rest", 9: "reservation (thread 0)", 10: "barrier after lookups", 11: "node write",
          12: "barrier after write"}
 main = [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 9, 10, 11, 12]
+if K <= 31 and CK == 2:  # k_sk_count2 (dbg_sk2.h)
+    names = {0: "queries out + top barrier", 1: "clear + stage + barrier", 3: "dedupe + quad list + barrier", 4: "insert (+hints, pending list)",
+             5: "barrier after insert", 6: "prefetch + reservation + pending lookups", 7: "dense list", 8: "reservation wait (thread 0)",
+             9: "barrier after list", 11: "node write", 12: "barrier after write"}
+    main = [0, 1, 3, 4, 5, 6, 7, 8, 9, 11, 12]
 tot = sum(out[i] for i in main)
 st = g.stats()
 print(f"{out[31]} workgroups, {tot / out[31]:.0f} clocks each; count {st['ms_count']:.2f} ms, {st['n_buckets']} buckets")

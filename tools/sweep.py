@@ -25,8 +25,13 @@ for cfg in configs:
                 raise
     st = g.stats()
     sz = g.sizes()
+    digest = None
+    if os.environ.get("SWEEP_DIGEST"):  # 64-bit digest over (k-mer, stamp, 4 counts) of every node: equal graphs <=> equal digests
+        sys.path.insert(0, ROOT)
+        import bench
+        digest = "%016x" % bench.node_digest_gpu(g)
     print(json.dumps({"cfg": cfg, "k": kk, "compact": round(st["ms_compact"], 2), "extract": round(st["ms_extract"], 2), "partition": round(st["ms_partition"], 2),
                       "count": round(st["ms_count"], 2), "succ": round(st["ms_succ"], 2), "csr": round(st["ms_csr"], 2),
                       "total": round(st["ms_build_total"], 2), "n_nodes": sz["n_nodes"], "buckets": st["n_buckets"],
-                      "records": st["n_records"], "queries": st["n_queries"]}), flush=True)
+                      "records": st["n_records"], "queries": st["n_queries"], "n_edges": sz["n_edges"], "digest": digest}), flush=True)
     g.close()
