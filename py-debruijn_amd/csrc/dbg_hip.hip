@@ -3572,7 +3572,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             const unsigned grid = (unsigned)std::min<uint64_t>(n_buckets, (uint64_t)n_cu);  // persistent, one workgroup per CU
             SkCount2Args a2{out, b_start, b_cnt, w0[where], w1[where], (const void *)st[where], n_buckets, split_recs, k};
             SkCount2Args *d_a2 = (SkCount2Args *)(h->d_scalars + 64);
+            static_assert(sizeof(SkCount2Args) <= (SK2_QUERY_CURSOR - 64) * 8, "the query cursor sits behind the descriptor");
             HIPCHK(h, hipMemcpyAsync(d_a2, &a2, sizeof(a2), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(h, hipMemsetAsync(h->d_scalars + SK2_QUERY_CURSOR, 0, 8, h->stream));
             hipLaunchKernelGGL(kern2, dim3(grid), dim3(Cnt2Cfg<ST>::NT), lds2, h->stream, (const SkCount2Args *)d_a2);
             HIPCHK(h, hipGetLastError());
         }
@@ -3595,7 +3597,10 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         }
         h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
+        uint64_t q2 = 0;
+        if (use_count2 && n_rec) HIPCHK(h, hipMemcpyAsync(&q2, h->d_scalars + SK2_QUERY_CURSOR, 8, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_count = t.stop();
+        if (use_count2 && n_rec) sc[5] = q2;  // k_sk_count2 keeps its query cursor on a cache line of its own
         if (h->phase_limit) { h->err = "ablation run (phase_limit set): timing only"; return DBG_E_ARG; }
         // buckets that had to be split by hash sub-range turn in-bucket successors into queries:
         // the usual bound (one query per record) no longer holds, retry with the safe one

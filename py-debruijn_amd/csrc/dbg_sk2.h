@@ -7,21 +7,28 @@
 // What is different, and why (profiles/r02_*: the first kernel spends a quarter of its time probing the table a SECOND
 // time for the successor of every node, in waves that run as long as their slowest lane and loop once per base):
 //   * The successor of k-mer i of a record is k-mer i + 1 of the same record, and that k-mer is inserted by the
-//     neighbouring lane in the same instruction stream.  The lane that sees an edge (k-mer, next base) for the first
-//     time -- the counter add returns 0 -- takes the slot its neighbour ended up in and writes it into the upper half
-//     of the edge's counter word: one 32-bit LDS word per (slot, base) = 16-bit count | 16-bit successor hint.
+//     neighbouring lane in the same instruction stream.  Every lane takes the slot its neighbour ended up in (one DPP
+//     wave shift, no LDS) and writes it into the upper half of the edge's counter word: one 32-bit LDS word per
+//     (slot, base) = 16-bit count | 16-bit successor hint.
 //   * Only edges whose successor is NOT in the neighbouring lane (the last k-mer of a record, the last lane of a wave,
-//     a successor filtered into another hash sub-range) go on a dense pending list, and only those are looked up
-//     afterwards, one lane per edge: ~300 per bucket instead of ~1500 node slots times their bases.
-//   * Node and edge totals of the bucket are counted while inserting (compare-and-swap winners, first counter adds), so
-//     the one global atomic that reserves node ids and CSR rows goes out right after the insert phase and has the whole
-//     list phase to come back.
+//     a successor filtered into another hash sub-range) go on a pending list -- a private segment per wave, no atomics --
+//     and only those are looked up afterwards, one lane per edge: ~300 per bucket instead of ~1500 node slots times
+//     their bases.
+//   * Node and edge totals of the bucket are counted while inserting, per lane (compare-and-swap winners; counter adds
+//     that return 0, looked at one iteration later, when the value has long arrived) and summed once per wave, so the
+//     one global atomic that reserves node ids and CSR rows goes out right after the insert phase and has the list
+//     phase and the pending lookups to come back (same-address global atomics queue up chip-wide: ~1-2 us under load).
 //   * One descriptor in device memory for inputs and outputs, re-read through scalar loads where a phase needs it: no
-//     base pointers or 64-bit ranges live across the persistent loop.
+//     base pointers or 64-bit ranges live across the persistent loop; the next bucket's record range travels in vector
+//     registers so that nothing waits for it at the load.
 // 16-bit counters: a bucket whose records cannot add up to 65 536 instances of one edge needs no check; the others
 // check the value the add returns, raise flag 512 and the host repeats the build with the 32-bit counters of k_sk_count.
 #pragma once
 #include "dbg_sk.h"
+
+#ifndef DBG_SK2_PROBE
+#define DBG_SK2_PROBE 0   // 0: per-lane exit, unrolled 16-fold; 1: wave-uniform probe loop with a ballot exit (measured: 14.3 vs 12.4 ms)
+#endif
 
 namespace dbgk {
 
@@ -47,13 +54,16 @@ struct Cnt2Cfg {
     static constexpr int CAP = 4096;
     static constexpr int NT = 1024;
 #ifdef DBG_CNT_PROF
-    static constexpr int QBUF = sizeof(ST) == 8 ? 416 : 736;
+    static constexpr int QBUF = sizeof(ST) == 8 ? 296 : 736;
 #else
-    static constexpr int QBUF = sizeof(ST) == 8 ? 448 : 768;   // staged records per round; afterwards: staged queries
+    static constexpr int QBUF = sizeof(ST) == 8 ? 320 : 768;   // staged records per round
 #endif
+    static constexpr int QS = sizeof(ST) == 8 ? 256 : 512;     // staged queries per bucket pass (more go out one by one)
     static constexpr int PEND = sizeof(ST) == 8 ? 2048 : 4096;  // edges waiting for a successor lookup
 };
 
+// the query cursor of this kernel: far from the node / edge cursor (word 4) -- atomics on one cache line queue up behind each other
+constexpr int SK2_QUERY_CURSOR = 120;
 constexpr uint32_t HINT_VALID = 0x8000u;   // hint half of a counter word: the successor's slot is in bits 11:0
 constexpr uint32_t HINT_QUERY = 0x4000u;   // ... the successor is not in this table: a query (counted once)
 constexpr int PEND_SEG = 256;              // pending edges a wave can list per bucket pass (PEND = 16 waves x PEND_SEG)
@@ -68,15 +78,17 @@ struct Cnt2Lds {
     uint16_t list[CAP];        // insert: quad list; afterwards: local node index -> slot
     uint16_t eoff[CAP];        // insert: dedupe set (uint32[CAP / 2]); afterwards: local node index -> first CSR edge
     uint16_t pend[Cnt2Cfg<ST>::PEND];  // per wave a segment: slot * 4 + base of the edges whose successor slot no lane handed over
-    unsigned long long q_key[QBUF];    // insert: staged w0; write phase: staged query keys
-    unsigned long long q_meta[QBUF];   // insert: staged w1 (bucket-hash field = multiplicity); write phase: CSR column
+    unsigned long long q_key[QBUF];    // staged w0
+    unsigned long long q_meta[QBUF];   // staged w1 (bucket-hash field = multiplicity)
     ST st_stage[QBUF];
+    unsigned long long qs_key[Cnt2Cfg<ST>::QS];  // queries of the pass being written; they leave after the NEXT pass's first barrier
+    uint32_t qs_col[Cnt2Cfg<ST>::QS];
     unsigned long long dir_mask[CAP / 64];
     uint16_t dir_base[CAP / 64];
     uint16_t pend_cnt[16];
     uint32_t dummy[64];        // where the lanes without a hint to write store theirs (no branch in the insert loop)
     uint32_t stk_mask[CNT_STACK], stk_val[CNT_STACK];
-    uint32_t overflow, n_list /* nodes | edges << 16 */, n_q, n_q2, n_q3, n_flat, fail;
+    uint32_t overflow, n_new /* nodes | edges << 16, counted by the insert */, n_list /* the same from the list phase */, n_q, n_q2, n_q3, n_flat, fail, pend_over;
     unsigned long long gbase, ebase, qbase, ri;
 #ifdef DBG_CNT_PROF
     unsigned long long prof[64];
@@ -88,9 +100,21 @@ __device__ inline uint32_t from_next_lane(uint32_t v, uint32_t last) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
 
+// sum over the wave, valid in lane 63: four shifts inside the rows of 16 lanes, then the row totals are handed on
+// (row_bcast:15 -> rows 1 and 3, row_bcast:31 -> rows 2 and 3); VALU only
+__device__ inline uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
+    return v;
+}
+
 template <class ST>
 __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restrict__ argp) {
-    constexpr int CAP = Cnt2Cfg<ST>::CAP, NT = Cnt2Cfg<ST>::NT, QBUF = Cnt2Cfg<ST>::QBUF, PEND = Cnt2Cfg<ST>::PEND;
+    constexpr int CAP = Cnt2Cfg<ST>::CAP, NT = Cnt2Cfg<ST>::NT, QBUF = Cnt2Cfg<ST>::QBUF, PEND = Cnt2Cfg<ST>::PEND, QS = Cnt2Cfg<ST>::QS;
     constexpr int NPT = CAP / NT;
     constexpr int PSEG = PEND / 16;
     constexpr uint32_t STAGE = QBUF;
@@ -144,6 +168,43 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
         }
         load_range(bucket + gridDim.x);
     };
+    // The queries of a pass (successors that are not in its table) are staged in LDS while its nodes are written and go
+    // out after the first barrier of the NEXT pass: no barrier and no phase of their own.
+    uint32_t fl_nq = 0, fl_unst = 0;  // uniform: queries waiting; per thread: those that found no room in the staging, bit (u * 4 + base)
+    uint64_t fl_gbase = 0;
+    auto flush_queries = [&]() {  // all threads, after a barrier that follows the pass's write phase
+        if (!fl_nq || s.fail) return;  // (a failed pass -- no room in the query list -- ends the kernel at the next check)
+        const auto &oq = fresh_args2(argp)->out;
+        const uint64_t qbase = s.qbase;
+        if (s.n_q2 != fl_nq && threadIdx.x == 0) { atomicOr(&oq.scalars[0], 2048ull); s.fail = 1; }  // internal: query totals disagree
+        for (uint32_t i = threadIdx.x; i < min(fl_nq, (uint32_t)QS); i += NT) {
+            oq.q_key[qbase + i] = s.qs_key[i];
+            oq.q_col[qbase + i] = s.qs_col[i];
+        }
+        if (fl_nq > (uint32_t)QS) {  // rare: queries beyond the staging go out one by one, key and row re-read from the node arrays
+            const uint64_t kmask = (1ull << (2 * k)) - 1;
+#pragma unroll
+            for (int u = 0; u < NPT; ++u) {
+                const uint32_t mine = (fl_unst >> (u * 4)) & 15u;
+                uint32_t qi = wave_alloc_n<4>(&s.n_q3, (uint32_t)__popc(mine));
+                if (mine) {
+                    const uint64_t node = fl_gbase + threadIdx.x + u * NT;
+                    const uint64_t key = oq.keys[node];
+                    const uint32_t pres = (uint32_t)oq.flags[node] >> 1;
+                    const uint32_t e0 = oq.rowptr[node];
+                    uint32_t m = mine;
+                    while (m) {
+                        const uint32_t b = __ffs(m) - 1;
+                        m &= m - 1;
+                        oq.q_key[qbase + QS + qi] = ((key << 2) | (uint64_t)b) & kmask;
+                        oq.q_col[qbase + QS + qi] = e0 + __popc(pres & ((1u << b) - 1u));
+                        ++qi;
+                    }
+                }
+            }
+        }
+        fl_nq = 0;
+    };
     if (threadIdx.x == 0) s.fail = 0;
     load_range(blockIdx.x);
     prefetch(blockIdx.x);
@@ -172,6 +233,7 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
             root = false;
             __syncthreads();  // the previous pass (or bucket) is done with the staging arrays and the table
             CNT_TICK(0);
+            flush_queries();
             if (!clean) {
                 for (int i = threadIdx.x; i < CAP; i += NT) {
                     s.keys[i] = EMPTY_KEY;
@@ -180,8 +242,9 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                 }
             }
             clean = false;
-            if (threadIdx.x == 0) { s.overflow = 0; s.n_list = 0; s.n_q = 0; s.n_q2 = 0; s.n_q3 = 0; }
+            if (threadIdx.x == 0) { s.overflow = 0; s.n_new = 0; s.n_list = 0; s.n_q = 0; s.pend_over = 0; }
             uint32_t pcur = 0;  // wave-uniform: entries in this wave's pending segment
+            uint32_t my_new = 0;  // this lane's new nodes (low half) and new edges (high half)
             // ---- insert
             for (uint32_t c0 = 0; c0 < r_n; c0 += STAGE) {
                 const uint32_t n_st = min(STAGE, r_n - c0);
@@ -229,6 +292,7 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                 __syncthreads();
                 CNT_TICK(3);
                 const uint32_t n_flat = s.n_flat;
+                uint32_t p_old = 1, p_mult = 0;  // what the previous iteration's counter add returned (looked at one iteration later)
                 // every lane stays in the loop (predicated): the wave hands successor slots from lane to lane
                 for (uint32_t f0 = 0; f0 < n_flat; f0 += NT / 4) {
                     const uint32_t f = f0 + (threadIdx.x >> 2);
@@ -250,32 +314,51 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                     const ST stamp = i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0;
                     uint32_t slot = slot_of<CAP>(kmer);
                     bool ok = false;
+                    uint32_t won = 0;
+#if DBG_SK2_PROBE == 1
+                    {   // The probe as a wave-uniform loop: the exit test is a ballot (one scalar branch per step), the lanes that are
+                        // done stay in step under a predicate.  A loop whose lanes leave one by one is unrolled by the compiler
+                        // into nested regions, and every iteration pays three scalar instructions per level to close them.
+                        bool todo = act;
+                        for (int probe = 0; __ballot(todo) != 0 && probe < CNT_PROBE_LIMIT; ++probe) {
+                            unsigned long long cur = s.keys[slot];
+                            if (todo && cur == EMPTY_KEY) {
+                                cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
+                                if (cur == EMPTY_KEY) { cur = kmer; won = 1; }
+                            }
+                            const bool hit = todo && cur == kmer;
+                            ok = ok || hit;
+                            todo = todo && !hit;
+                            slot = todo ? ((slot + 1) & (CAP - 1)) : slot;
+                        }
+                        if (todo) s.overflow = 1;
+                    }
+#else
                     if (act) {
 #pragma unroll 16
                         for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
                             unsigned long long cur = s.keys[slot];
                             if (cur == EMPTY_KEY) {
                                 cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
-                                if (cur == EMPTY_KEY) cur = kmer;
+                                if (cur == EMPTY_KEY) { cur = kmer; won = 1; }
                             }
                             if (cur == kmer) { ok = true; break; }
                             slot = (slot + 1) & (CAP - 1);
                         }
                         if (!ok) s.overflow = 1;
                     }
+#endif
+                    // the previous iteration's counter add: a return of 0 was the first instance of that edge
+                    my_new += won + (((p_old & 0xFFFFu) == 0) ? 0x10000u : 0u);
+                    if (check16 && (p_old & 0xFFFFu) + p_mult > 0xFFFFu) s.fail = 2;
                     const bool good = act && ok;
                     // slot of the next k-mer of the record: the neighbouring lane's (quads of one record are consecutive)
                     const uint32_t nxt = from_next_lane(good ? slot : 0xFFFFu, 0xFFFFu);
                     const bool edge = good && has_succ;
                     const bool in_wave = edge && (i < len - 1) && nxt != 0xFFFFu;
-                    if (edge) {
-                        if (check16) {
-                            const uint32_t old = atomicAdd(&s.ch[slot * 4 + b], mult);
-                            if ((old & 0xFFFFu) + mult > 0xFFFFu) s.fail = 2;
-                        } else {
-                            atomicAdd(&s.ch[slot * 4 + b], mult);
-                        }
-                    }
+                    p_old = 1;
+                    p_mult = 0;
+                    if (edge) { p_old = atomicAdd(&s.ch[slot * 4 + b], mult); p_mult = mult; }
                     if (good) atomicMin(&s.stamp[slot], stamp);
                     // the hint: every instance of an edge that knows the successor's slot writes it (the same value each
                     // time); the others write to a dummy word -- an address select instead of a branch
@@ -293,15 +376,26 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                         pcur += (uint32_t)__popcll(m_pend);
                     }
                 }
+                my_new += ((p_old & 0xFFFFu) == 0) ? 0x10000u : 0u;  // the last iteration's add
+                if (check16 && (p_old & 0xFFFFu) + p_mult > 0xFFFFu) s.fail = 2;
             }
-            if (lane == 0) s.pend_cnt[wave] = (uint16_t)min(pcur, 0xFFFFu);
+            {   // this wave's share of the bucket's node and edge totals
+                const uint32_t tot = wave_sum_dpp(my_new);
+                if (lane == 63 && tot) atomicAdd(&s.n_new, tot);
+            }
+            if (lane == 0) {
+                s.pend_cnt[wave] = (uint16_t)min(pcur, (uint32_t)PSEG);
+                if (pcur > (uint32_t)PSEG) s.pend_over = 1;
+            }
             CNT_TICK(4);
             __syncthreads();
             CNT_TICK(5);
+            if (threadIdx.x == 0) { s.n_q2 = 0; s.n_q3 = 0; }  // used from the write phase on; the previous pass's queries are out
             if (have_prefetch) {
                 have_prefetch = false;
                 prefetch(bucket + gridDim.x);
             }
+            CNT_TICK(13);
             if (s.fail) { failed = true; break; }
             if (s.overflow) {  // split this hash sub-range in two and retry (nothing was written out)
                 const uint32_t bit = cur_mask + 1;
@@ -318,6 +412,37 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                 __syncthreads();
                 continue;
             }
+            // ---- the insert counted the bucket's nodes and edges: reserve node ids and CSR rows now; the pending lookups and
+            //      the list phase run while the answer is on its way
+            const uint32_t n_local = s.n_new & 0xFFFFu, n_edges_local = s.n_new >> 16;
+            unsigned long long got = 0;
+            if (threadIdx.x == 0)
+                got = atomicAdd(&fresh_args2(argp)->out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
+            CNT_TICK(14);
+            // ---- successor lookups of the pending edges: every wave its own segment (all (slot, base) words of the table
+            //      if any segment overflowed).  A miss marks the edge as a query; the lane that sets the mark counts it.
+            {
+                const uint64_t kmask = (1ull << (2 * k)) - 1;
+                const bool over = s.pend_over != 0;  // some wave's segment overflowed
+                const uint32_t n_items = over ? (uint32_t)CAP * 4u / 16u : (uint32_t)s.pend_cnt[wave];  // per wave
+                for (uint32_t e0 = 0; e0 < n_items; e0 += 64) {
+                    const uint32_t e = e0 + lane;
+                    bool miss = false;
+                    if (e < n_items) {
+                        const uint32_t sb = over ? (uint32_t)wave * ((uint32_t)CAP * 4u / 16u) + e : (uint32_t)s.pend[wave * PSEG + e];
+                        const uint32_t c = s.ch[sb];
+                        if ((c & 0xFFFFu) && (c >> 16) == 0) {
+                            const unsigned long long key = s.keys[sb >> 2];
+                            const int fnd = lds_find<CAP>(s.keys, ((key << 2) | (uint64_t)(sb & 3u)) & kmask);
+                            if (fnd >= 0) reinterpret_cast<uint16_t *>(&s.ch[sb])[1] = (uint16_t)(HINT_VALID | (uint32_t)fnd);
+                            else miss = !(atomicOr(&s.ch[sb], HINT_QUERY << 16) & (HINT_QUERY << 16));
+                        }
+                    }
+                    const unsigned long long mm = __ballot(miss);
+                    if (mm && lane == 0) atomicAdd(&s.n_q, (uint32_t)__popcll(mm));
+                }
+            }
+            CNT_TICK(6);
             // ---- dense list of occupied slots + CSR edge offsets
             {
                 unsigned long long kk[NPT];
@@ -362,40 +487,7 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                     base += nn[t] | (ne[t] << 16);
                 }
             }
-            CNT_TICK(6);
-            __syncthreads();
             CNT_TICK(7);
-            // ---- the bucket's nodes and edges are known: reserve node ids and CSR rows; the pending lookups run meanwhile
-            const uint32_t n_local = s.n_list & 0xFFFFu, n_edges_local = s.n_list >> 16;
-            unsigned long long got = 0;
-            if (threadIdx.x == 0)
-                got = atomicAdd(&fresh_args2(argp)->out.scalars[4], (unsigned long long)n_local | ((unsigned long long)n_edges_local << 32));
-            // ---- successor lookups of the pending edges: every wave its own segment (all (slot, base) words of the table
-            //      if any segment overflowed).  A miss marks the edge as a query; the lane that sets the mark counts it.
-            {
-                const uint64_t kmask = (1ull << (2 * k)) - 1;
-                bool over = false;
-#pragma unroll
-                for (int w2 = 0; w2 < 16; ++w2) over = over || s.pend_cnt[w2] > (uint16_t)PSEG;
-                const uint32_t n_items = over ? (uint32_t)CAP * 4u / 16u : (uint32_t)s.pend_cnt[wave];  // per wave
-                for (uint32_t e0 = 0; e0 < n_items; e0 += 64) {
-                    const uint32_t e = e0 + lane;
-                    bool miss = false;
-                    if (e < n_items) {
-                        const uint32_t sb = over ? (uint32_t)wave * ((uint32_t)CAP * 4u / 16u) + e : (uint32_t)s.pend[wave * PSEG + e];
-                        const uint32_t c = s.ch[sb];
-                        if ((c & 0xFFFFu) && (c >> 16) == 0) {
-                            const unsigned long long key = s.keys[sb >> 2];
-                            const int fnd = lds_find<CAP>(s.keys, ((key << 2) | (uint64_t)(sb & 3u)) & kmask);
-                            if (fnd >= 0) reinterpret_cast<uint16_t *>(&s.ch[sb])[1] = (uint16_t)(HINT_VALID | (uint32_t)fnd);
-                            else miss = !(atomicOr(&s.ch[sb], HINT_QUERY << 16) & (HINT_QUERY << 16));
-                        }
-                    }
-                    const unsigned long long mm = __ballot(miss);
-                    if (mm && lane == 0) atomicAdd(&s.n_q, (uint32_t)__popcll(mm));
-                }
-            }
-            CNT_TICK(8);
             if (threadIdx.x == 0) {
                 const auto &orr = fresh_args2(argp)->out;
                 const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
@@ -425,7 +517,8 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
             CNT_TICK(10);
             const uint32_t nq = s.n_q;
             unsigned long long qgot = 0;
-            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&fresh_args2(argp)->out.scalars[5], (unsigned long long)nq);
+            if (threadIdx.x == 64 && nq) qgot = atomicAdd(&fresh_args2(argp)->out.scalars[SK2_QUERY_CURSOR], (unsigned long long)nq);
+            if (s.n_list != s.n_new && threadIdx.x == 0) { atomicOr(&fresh_args2(argp)->out.scalars[0], 2048ull); s.fail = 1; }  // internal: the insert's totals are off
             if (s.fail) { failed = true; break; }  // written before the barrier above
             const uint64_t gbase = s.gbase, ebase = s.ebase;
             uint32_t unst = 0;  // queries of this thread that found no room in the staging: bit (u * 4 + base)
@@ -486,9 +579,9 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                     while (qmask) {
                         const uint32_t b = __ffs(qmask) - 1;
                         qmask &= qmask - 1;
-                        if (qi < (uint32_t)QBUF) {
-                            s.q_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
-                            s.q_meta[qi] = e0 + __popc(pres & ((1u << b) - 1u));
+                        if (qi < (uint32_t)QS) {
+                            s.qs_key[qi] = ((key << 2) | (uint64_t)b) & kmask;
+                            s.qs_col[qi] = e0 + __popc(pres & ((1u << b) - 1u));
                         } else {
                             unst |= 1u << (u * 4 + b);
                         }
@@ -502,40 +595,9 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                 const auto &oq = fresh_args2(argp)->out;
                 if (qgot + nq > oq.q_cap || qgot + nq > 0xFFFFFFF0ull) { atomicOr(&oq.scalars[0], 64ull); s.fail = 1; }
             }
-            __syncthreads();
-            CNT_TICK(12);
-            if (s.n_q2 != nq && threadIdx.x == 0) { atomicOr(&fresh_args2(argp)->out.scalars[0], 2048ull); s.fail = 1; }  // internal: query totals disagree
-            if (s.fail) { failed = true; break; }
-            if (nq) {
-                const auto &oq = fresh_args2(argp)->out;
-                const uint64_t qbase = s.qbase;
-                for (uint32_t i = threadIdx.x; i < min(nq, (uint32_t)QBUF); i += NT) {
-                    oq.q_key[qbase + i] = s.q_key[i];
-                    oq.q_col[qbase + i] = (uint32_t)s.q_meta[i];
-                }
-                if (nq > (uint32_t)QBUF) {  // rare: queries beyond the staging go out one by one, key and row re-read from the node arrays
-                    const uint64_t kmask = (1ull << (2 * k)) - 1;
-#pragma unroll
-                    for (int u = 0; u < NPT; ++u) {
-                        const uint32_t mine = (unst >> (u * 4)) & 15u;
-                        uint32_t qi = wave_alloc_n<4>(&s.n_q3, (uint32_t)__popc(mine));
-                        if (mine) {
-                            const uint64_t node = gbase + threadIdx.x + u * NT;
-                            const uint64_t key = oq.keys[node];
-                            const uint32_t pres = (uint32_t)oq.flags[node] >> 1;
-                            const uint32_t e0 = oq.rowptr[node];
-                            uint32_t m = mine;
-                            while (m) {
-                                const uint32_t b = __ffs(m) - 1;
-                                m &= m - 1;
-                                oq.q_key[qbase + QBUF + qi] = ((key << 2) | (uint64_t)b) & kmask;
-                                oq.q_col[qbase + QBUF + qi] = e0 + __popc(pres & ((1u << b) - 1u));
-                                ++qi;
-                            }
-                        }
-                    }
-                }
-            }
+            fl_nq = nq;        // the staged queries leave after the next barrier every thread passes (flush_queries)
+            fl_unst = unst;
+            fl_gbase = gbase;
             clean = true;
         }
         if (failed) {
@@ -543,6 +605,8 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
             return;
         }
     }
+    __syncthreads();
+    flush_queries();  // the last pass's
 #ifdef DBG_CNT_PROF
     if (threadIdx.x == 0) {
         for (int i = 0; i < 31; ++i) atomicAdd(&g_cnt_prof[i], s.prof[i]);

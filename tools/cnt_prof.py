@@ -28,9 +28,9 @@ names = {0: "queries out + top barrier", 1: "clear + stage + barrier", 2: "dedup
 main = [0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 9, 10, 11, 12]
 if K <= 31 and CK == 2:  # k_sk_count2 (dbg_sk2.h)
     names = {0: "queries out + top barrier", 1: "clear + stage + barrier", 3: "dedupe + quad list + barrier", 4: "insert (+hints, pending list)",
-             5: "barrier after insert", 6: "prefetch + reservation + pending lookups", 7: "dense list", 8: "reservation wait (thread 0)",
-             9: "barrier after list", 11: "node write", 12: "barrier after write"}
-    main = [0, 1, 3, 4, 5, 6, 7, 8, 9, 11, 12]
+             5: "barrier after insert", 13: "prefetch of the next bucket", 14: "reservation issue", 6: "pending lookups", 7: "dense list",
+             9: "reservation wait + range (thread 0)", 10: "barrier after list", 11: "node write", 12: "barrier after write"}
+    main = [0, 1, 3, 4, 5, 13, 14, 6, 7, 9, 10, 11, 12]
 tot = sum(out[i] for i in main)
 st = g.stats()
 print(f"{out[31]} workgroups, {tot / out[31]:.0f} clocks each; count {st['ms_count']:.2f} ms, {st['n_buckets']} buckets")
