@@ -192,6 +192,42 @@ int dbg_part_answer(dbg_t *h, int part, const void *d_q_keys, uint64_t n, void *
 int dbg_part_apply(dbg_t *h, int part, int owner, const void *d_answers);
 int dbg_multipass_finish(dbg_t *h);
 
+/* ---- traversal of a graph in parts (no reference counterpart for the partition; the steps are debruijn.py:150-186, :230-254,
+ *      :274-278, :288-347): the per-part primitives of py-debruijn_amd/part_traversal.py, which moves the small id lists and
+ *      rows they produce between parts and ranks.  A node is (virtual shard, local id).  Per part a byte of traversal flags
+ *      in the DBG_F_* layout (INDEG, keep mask, BRANCH, PULLED) plus DBG_PF_MARK for the caller's marks. */
+#define DBG_PF_MARK 0x80u
+/* pruningEdges + branch flag on the part's CSR rows; threshold >= 1 */
+int dbg_part_prune(dbg_t *h, int part, double threshold, uint64_t *n_branch);
+/* local ids (uint32, device, ascending) of the nodes with (flags & mask) == want; d_ids NULL: *n only */
+int dbg_part_select(dbg_t *h, int part, uint32_t mask, uint32_t want, void *d_ids, uint64_t capacity, uint64_t *n);
+/* rows of n nodes (d_ids uint32, device); outputs are device arrays, any may be NULL: keys, keys_hi, stamps u64[n],
+ * counts u32[n][4] by base code, succ_owner u8[n][4] (virtual shard; 0xFF none), succ_local u32[n][4], pflags u8[n] */
+int dbg_part_gather(dbg_t *h, int part, const void *d_ids, uint64_t n, void *d_keys, void *d_keys_hi, void *d_stamps,
+                    void *d_counts, void *d_succ_owner, void *d_succ_local, void *d_pflags);
+/* sets flag bits on n nodes; d_newly (u8[n], device, may be NULL) = 1 where the bits were not all set before */
+int dbg_part_mark(dbg_t *h, int part, const void *d_ids, uint64_t n, uint32_t bits, void *d_newly);
+int dbg_part_clear(dbg_t *h, int part, uint32_t bits); /* ... and clears them on every node */
+/* kept edges of the part's chain nodes (not branch, not pulled, one kept successor) that leave the part: the targets'
+ * local ids grouped by target virtual shard; counts[n_virtual]; d_targets (uint32, device) NULL: counts only */
+int dbg_part_cross_targets(dbg_t *h, int part, uint64_t *counts, void *d_targets, uint64_t capacity);
+/* one segment of the contig walk per entry node (d_entries uint32, device), inside the part.  kind u8[n]: 0 the path ends
+ * at a branch node / a node without kept successor (emitted, that node included), 1 the entry itself is pulled, 2 the chain
+ * leaves the part for (next_owner, next_local) -- then `last` holds the count of the leaving edge --, 3 a cycle inside the
+ * part, 4 the next node is pulled (emitted up to the current one).  hops u32[n] = edges walked inside the part, score u64[n] =
+ * sum of their counts, last u32[n] = node the segment ended at (kind 2: the leaving edge's count). */
+int dbg_part_segments(dbg_t *h, int part, const void *d_entries, uint64_t n, void *d_kind, void *d_next_owner, void *d_next_local,
+                      void *d_hops, void *d_score, void *d_last);
+int dbg_part_pflags(dbg_t *h, int part, const void **d_pflags); /* device pointer of the flags, NULL before dbg_part_prune */
+/* pull_out_read (debruijn.py:274-278) against an explicit list of k-mers (the branch k-mers of all parts and ranks): host
+ * arrays in and out; read_flags[n_reads] = 1 where the read holds one; first_seen[n_keys][4] (may be NULL) = smallest byte
+ * offset in this handle's reads of (k-mer, next base by code), UINT64_MAX if absent -- the Counter order of a branch node's
+ * successors is count descending, then the minimum of these over all ranks */
+int dbg_scan_reads_for_keys(dbg_t *h, int k, const uint64_t *keys, const uint64_t *keys_hi, uint64_t n_keys, uint8_t *read_flags,
+                            uint64_t *first_seen);
+/* successor ranks (the order bytes of dbg_export_orders) of the current graph, handed in instead of dbg_refine_edge_order */
+int dbg_set_orders(dbg_t *h, const uint8_t *order);
+
 /* ---- exact successor order (Counter semantics of debruijn.py:159-165 and :215-216): finds the first
  *      occurrence of every out-edge of the nodes with >= 2 distinct successors (one more pass over the
  *      reads) and rewrites the per-node rank bytes.  Without it equal-count successors are ranked

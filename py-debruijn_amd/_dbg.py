@@ -34,6 +34,8 @@ SYMBOLS = (
     "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
     "dbg_shard_build_multipass", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
     "dbg_export_marked", "dbg_part_keys_hi", "dbg_take_reads",
+    "dbg_part_prune", "dbg_part_select", "dbg_part_gather", "dbg_part_mark", "dbg_part_clear", "dbg_part_cross_targets",
+    "dbg_part_segments", "dbg_part_pflags", "dbg_scan_reads_for_keys", "dbg_set_orders",
 )
 
 
@@ -144,6 +146,16 @@ def load_library():
         "dbg_part_device_views": (C.c_int, [H, C.c_int] + [C.POINTER(vp)] * 2 + [C.POINTER(C.c_int)] + [C.POINTER(vp)] * 5),
         "dbg_part_keys_hi": (C.c_int, [H, C.c_int, vp, C.POINTER(vp)]),
         "dbg_take_reads": (C.c_int, [H, vp, C.c_uint64, vp, vp, C.c_uint64, u64p]),
+        "dbg_part_prune": (C.c_int, [H, C.c_int, C.c_double, u64p]),
+        "dbg_part_select": (C.c_int, [H, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_uint64, u64p]),
+        "dbg_part_gather": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
+        "dbg_part_mark": (C.c_int, [H, C.c_int, vp, C.c_uint64, C.c_uint32, vp]),
+        "dbg_part_clear": (C.c_int, [H, C.c_int, C.c_uint32]),
+        "dbg_part_cross_targets": (C.c_int, [H, C.c_int, u64p, vp, C.c_uint64]),
+        "dbg_part_segments": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, vp, vp]),
+        "dbg_part_pflags": (C.c_int, [H, C.c_int, C.POINTER(vp)]),
+        "dbg_scan_reads_for_keys": (C.c_int, [H, C.c_int, vp, vp, C.c_uint64, vp, vp]),
+        "dbg_set_orders": (C.c_int, [H, vp]),
         "dbg_shard_apply": (C.c_int, [H, vp]),
         "dbg_import_graph": (C.c_int, [H, C.c_int, C.c_int, u64p, vp, vp, vp, vp, vp]),
         "dbg_device_keys_hi": (C.c_int, [H, C.POINTER(vp)]),
@@ -527,6 +539,89 @@ class Graph:
                 "flags": device_tensor(p[2].value, n, "uint8", dev), "row_ptr": device_tensor(p[3].value, n + 1, "int32", dev),
                 "col": device_tensor(p[4].value, ne, "int32", dev), "col_part": device_tensor(p[5].value, ne, "uint8", dev),
                 "cnt": device_tensor(p[6].value, ne, "int32", dev)}
+
+    # ---- traversal of a graph in parts (part_traversal.py): per-part primitives; ids and rows are torch tensors on the device
+    def _dev(self):
+        import torch
+        return torch.device("cuda", self.sizes_device())
+
+    def part_prune(self, part, threshold):
+        n = C.c_uint64()
+        self._chk(self._lib.dbg_part_prune(self._h, int(part), float(threshold), C.byref(n)))
+        return n.value
+
+    def part_select(self, part, mask, want):
+        """-> int32 tensor of the local ids (as uint32) with (flags & mask) == want, ascending."""
+        import torch
+        n = C.c_uint64()
+        self._chk(self._lib.dbg_part_select(self._h, int(part), int(mask), int(want), None, 0, C.byref(n)))
+        ids = torch.empty(n.value, dtype=torch.int32, device=self._dev())
+        if n.value:
+            self._chk(self._lib.dbg_part_select(self._h, int(part), int(mask), int(want), C.c_void_p(ids.data_ptr()), n.value, C.byref(n)))
+        return ids
+
+    def part_gather(self, part, ids, what=("keys", "keys_hi", "stamps", "counts", "succ_owner", "succ_local", "pflags")):
+        """rows of the nodes `ids` (int32 device tensor): dict of device tensors for the names in `what`."""
+        import torch
+        n, dev = ids.numel(), self._dev()
+        shapes = {"keys": (torch.int64, n), "keys_hi": (torch.int64, n), "stamps": (torch.int64, n), "counts": (torch.int32, 4 * n),
+                  "succ_owner": (torch.uint8, 4 * n), "succ_local": (torch.int32, 4 * n), "pflags": (torch.uint8, n)}
+        out = {w: torch.empty(shapes[w][1], dtype=shapes[w][0], device=dev) for w in what}
+        if n:
+            ptr = lambda w: C.c_void_p(out[w].data_ptr()) if w in out else None  # noqa: E731
+            self._chk(self._lib.dbg_part_gather(self._h, int(part), C.c_void_p(ids.data_ptr()), n, ptr("keys"), ptr("keys_hi"),
+                                                ptr("stamps"), ptr("counts"), ptr("succ_owner"), ptr("succ_local"), ptr("pflags")))
+        return out
+
+    def part_mark(self, part, ids, bits, newly=False):
+        import torch
+        n = ids.numel()
+        flag = torch.zeros(n, dtype=torch.uint8, device=self._dev()) if newly else None
+        if n:
+            self._chk(self._lib.dbg_part_mark(self._h, int(part), C.c_void_p(ids.data_ptr()), n, int(bits),
+                                              C.c_void_p(flag.data_ptr()) if newly else None))
+        return flag
+
+    def part_clear(self, part, bits):
+        self._chk(self._lib.dbg_part_clear(self._h, int(part), int(bits)))
+
+    def part_cross_targets(self, part):
+        """-> (counts per virtual shard, int32 tensor of target local ids grouped by virtual shard)."""
+        import torch
+        nv = getattr(self, "_mp_virtual", 0)
+        counts = (C.c_uint64 * max(nv, 1))()
+        self._chk(self._lib.dbg_part_cross_targets(self._h, int(part), counts, None, 0))
+        counts_l = [int(x) for x in counts][:nv]
+        total = sum(counts_l)
+        t = torch.empty(total, dtype=torch.int32, device=self._dev())
+        if total:
+            self._chk(self._lib.dbg_part_cross_targets(self._h, int(part), counts, C.c_void_p(t.data_ptr()), total))
+        return counts_l, t
+
+    def part_segments(self, part, entries):
+        import torch
+        n, dev = entries.numel(), self._dev()
+        out = {"kind": torch.empty(n, dtype=torch.uint8, device=dev), "next_owner": torch.empty(n, dtype=torch.uint8, device=dev),
+               "next_local": torch.empty(n, dtype=torch.int32, device=dev), "hops": torch.empty(n, dtype=torch.int32, device=dev),
+               "score": torch.empty(n, dtype=torch.int64, device=dev), "last": torch.empty(n, dtype=torch.int32, device=dev)}
+        if n:
+            self._chk(self._lib.dbg_part_segments(self._h, int(part), C.c_void_p(entries.data_ptr()), n,
+                                                  *[C.c_void_p(out[w].data_ptr()) for w in ("kind", "next_owner", "next_local", "hops", "score", "last")]))
+        return out
+
+    def scan_reads_for_keys(self, k, keys, keys_hi=None, first_seen=True):
+        """-> (read_flags uint8[n_reads], first_seen uint64[n_keys, 4] or None); numpy in and out (dbg_scan_reads_for_keys)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        hi = None if keys_hi is None else np.ascontiguousarray(keys_hi, dtype=np.uint64)
+        rf = np.zeros(self.sizes()["n_reads"], dtype=np.uint8)
+        fs = np.full((keys.size, 4), np.iinfo(np.uint64).max, dtype=np.uint64) if first_seen else None
+        self._chk(self._lib.dbg_scan_reads_for_keys(self._h, int(k), _ptr(keys) if keys.size else None, _ptr(hi) if hi is not None and hi.size else None,
+                                                    keys.size, _ptr(rf) if rf.size else None, _ptr(fs) if fs is not None and fs.size else None))
+        return rf, fs
+
+    def set_orders(self, order):
+        order = np.ascontiguousarray(order, dtype=np.uint8)
+        self._chk(self._lib.dbg_set_orders(self._h, _ptr(order)))
 
     # ---- multi-GPU sharding (buffers are torch tensors on this handle's device; see multi_gpu.py)
     def shard_extract(self, k, n_shards):

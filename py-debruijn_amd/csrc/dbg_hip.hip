@@ -4814,6 +4814,7 @@ struct MultiPass {
     int n_virtual = 0, v_first = 0;    // part p is virtual shard v_first + p of n_virtual (ranks x passes; one GPU: n_passes, 0)
     std::vector<dbg *> part;
     std::vector<uint8_t *> col_owner;  // per part: [n_edges of the part] owner part of every CSR column
+    std::vector<uint8_t *> pflags;     // per part: [n_nodes] traversal flags (DBG_F_* layout + DBG_PF_*), dbg_part_prune allocates them
     std::vector<uint64_t> base;        // global id of the part's first node (prefix sums of the part sizes)
 };
 
@@ -4869,6 +4870,7 @@ static void multipass_free(dbg *h) {
     MultiPass *mp = (MultiPass *)h->multipass;
     if (!mp) return;
     for (auto *o : mp->col_owner) if (o) (void)hipFree(o);
+    for (auto *o : mp->pflags) if (o) (void)hipFree(o);
     for (dbg *sub : mp->part) if (sub) dbg_destroy(sub);
     delete mp;
     h->multipass = nullptr;
@@ -4921,6 +4923,7 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
     mp->v_first = v_first;
     mp->part.assign(n_passes, nullptr);
     mp->col_owner.assign(n_passes, nullptr);
+    mp->pflags.assign(n_passes, nullptr);
     mp->base.assign(n_passes + 1, 0);
     const int w = k - sk_m_for_k(k) + 1;
     double ms_count = 0, ms_part = h->stats.ms_partition, ms_succ = 0;
@@ -5347,6 +5350,466 @@ extern "C" int dbg_export_part(dbg_t *h, int part, uint64_t *keys, uint64_t *sta
     hipError_t e = hipStreamSynchronize(h->stream);
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return DBG_E_HIP; }
+    return DBG_OK;
+}
+
+
+// ==========================================================================================
+// Traversal of a graph that lives in PARTS (a multi-pass build on one GPU, a rank of a sharded build, ranks x passes):
+// prune, branch list, tip removal, pull-out reads and the contig walk without any GPU ever holding the whole graph.
+// A node is (virtual shard, local id); the per-part primitives below work on one part and hand small id lists and
+// attribute rows to the caller (py-debruijn_amd/part_traversal.py), which moves them between parts and ranks:
+//   dbg_part_prune          pruningEdges + branch flag on the part's CSR                  [debruijn.py:150-166, :230-236]
+//   dbg_part_select / _gather / _mark   nodes by flag; their rows; set flag bits          (frontiers, tip neighbourhoods)
+//   dbg_part_cross_targets  kept edges of chain nodes that leave the part                 (entries of the other parts' chains)
+//   dbg_part_segments       from every entry node along the part's own chain nodes        [debruijn.py:288-316, one segment]
+//   dbg_scan_reads_for_keys reads that hold one of a few k-mers + first appearance of their edges   [:274-278, Counter order]
+//   dbg_set_orders          successor ranks of an imported (tip neighbourhood) graph
+// Chains leave a part at almost every change of minimizer (the parts split the minimizer-hash space), so a segment is a
+// dozen nodes and one thread per entry walks it; the caller ranks the skeleton of segments (a few per cent of the nodes).
+// ==========================================================================================
+static int part_ctx(dbg_t *h, int part, MultiPass **mp_out, dbg **sub_out) {
+    MultiPass *mp = h ? (MultiPass *)h->multipass : nullptr;
+    if (!mp || part < 0 || part >= mp->n_passes) { if (h) h->err = "no such part (a multi-pass build must run first)"; return DBG_E_ARG; }
+    *mp_out = mp;
+    *sub_out = mp->part[part];
+    return DBG_OK;
+}
+
+// keep mask of every node from the counts of its CSR row (threshold >= 1: the kept SET does not depend on the Counter order)
+__global__ __launch_bounds__(256) void k_part_prune(uint64_t n, const uint8_t *__restrict__ flags, const uint32_t *__restrict__ rowptr,
+                                                    const uint32_t *__restrict__ ecnt, double threshold, uint8_t *pflags,
+                                                    unsigned long long *n_branch) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t br = 0;
+    if (i < n) {
+        const uint32_t f = flags[i], pres = (f >> 1) & 15u;
+        uint32_t e = rowptr[i], c[4] = {0, 0, 0, 0}, mx = 0;
+        for (int b = 0; b < 4; ++b)
+            if ((pres >> b) & 1u) { c[b] = ecnt[e++]; mx = max(mx, c[b]); }
+        uint32_t keep = 0;
+        if (__popc(pres) == 1) keep = pres;
+        else if (pres) {
+            const double lim = (double)mx / threshold;
+            for (int b = 0; b < 4; ++b)
+                if (c[b] && (c[b] == mx || (double)c[b] >= lim)) keep |= 1u << b;
+        }
+        const bool branch = __popc(keep) > 1;
+        br = branch;
+        pflags[i] = (uint8_t)((f & DBG_F_INDEG) | (keep << DBG_F_KEEP_SHIFT) | (branch ? DBG_F_BRANCH : 0));
+    }
+    br = wave_sum_u64(br);
+    if ((threadIdx.x & 63) == 0 && br) atomicAdd(n_branch, (unsigned long long)br);
+}
+
+extern "C" int dbg_part_prune(dbg_t *h, int part, double threshold, uint64_t *n_branch) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!(threshold >= 1.0)) { h->err = "traversal in parts takes threshold >= 1 (below, the kept successor depends on the Counter order)"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n_branch) *n_branch = 0;
+    if (!sub->n_nodes) return DBG_OK;
+    if (!mp->pflags[part]) HIPCHK(h, hipMalloc((void **)&mp->pflags[part], (sub->n_nodes + 3) / 4 * 4));
+    HIPCHK(h, hipMemsetAsync(h->d_scalars + 8, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_part_prune, dim3(grid_for(sub->n_nodes, 256)), dim3(256), 0, h->stream, sub->n_nodes, sub->d_flags,
+                       sub->d_rowptr32, sub->d_ecnt, threshold, mp->pflags[part], (unsigned long long *)(h->d_scalars + 8));
+    HIPCHK(h, hipGetLastError());
+    uint64_t nb = 0;
+    HIPCHK(h, hipMemcpyAsync(&nb, h->d_scalars + 8, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (n_branch) *n_branch = nb;
+    return DBG_OK;
+}
+
+struct PredPflags {
+    const uint8_t *f;
+    uint8_t mask, want;
+    __device__ bool operator()(uint64_t i) const { return (f[i] & mask) == want; }
+};
+
+// local ids (uint32, device, ascending) of the nodes with (pflags & mask) == want; *n is always set (d_ids NULL: count only)
+extern "C" int dbg_part_select(dbg_t *h, int part, uint32_t mask, uint32_t want, void *d_ids, uint64_t capacity, uint64_t *n) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!n) return DBG_E_ARG;
+    *n = 0;
+    if (!sub->n_nodes) return DBG_OK;
+    if (!mp->pflags[part]) { h->err = "dbg_part_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const PredPflags pred{mp->pflags[part], (uint8_t)mask, (uint8_t)want};
+    uint64_t total = 0;
+    if (!d_ids) { CHK(reduce_sum(h, sub->n_nodes, FlagSet{mp->pflags[part], (uint8_t)mask, (uint8_t)want}, &total)); *n = total; return DBG_OK; }
+    CHK(reduce_sum(h, sub->n_nodes, FlagSet{mp->pflags[part], (uint8_t)mask, (uint8_t)want}, &total));
+    *n = total;
+    if (total > capacity) { h->err = "dbg_part_select: capacity below the number of selected nodes"; return DBG_E_CAPACITY; }
+    uint64_t got = 0;
+    CHK(compact_ids(h, sub->n_nodes, pred, (uint32_t *)d_ids, &got));
+    return DBG_OK;
+}
+
+template <class ST>
+__global__ __launch_bounds__(256) void k_part_gather(const uint32_t *__restrict__ ids, uint64_t n, uint64_t n_nodes,
+                                                     const uint64_t *__restrict__ keys, const uint64_t *__restrict__ keys_hi,
+                                                     const ST *__restrict__ stamps, const uint8_t *__restrict__ flags,
+                                                     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                     const uint8_t *__restrict__ col_owner, const uint32_t *__restrict__ ecnt,
+                                                     const uint8_t *__restrict__ pflags, uint64_t *o_keys, uint64_t *o_hi,
+                                                     uint64_t *o_stamps, uint32_t *o_cnt, uint8_t *o_owner, uint32_t *o_local,
+                                                     uint8_t *o_pf, unsigned long long *err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = ids[j];
+    if (i >= n_nodes) { atomicOr(err, 1ull); return; }
+    if (o_keys) o_keys[j] = keys[i];
+    if (o_hi) o_hi[j] = keys_hi ? keys_hi[i] : 0ull;
+    if (o_stamps) o_stamps[j] = (uint64_t)stamps[i];
+    if (o_pf) o_pf[j] = pflags ? pflags[i] : (uint8_t)(flags[i] & DBG_F_INDEG);
+    const uint32_t pres = ((uint32_t)flags[i] >> 1) & 15u;
+    uint32_t e = rowptr[i];
+    for (int b = 0; b < 4; ++b) {
+        uint32_t c = 0, loc = NO_NODE;
+        uint8_t ow = 0xFF;
+        if ((pres >> b) & 1u) { c = ecnt[e]; loc = col[e]; ow = col_owner[e]; ++e; }
+        if (o_cnt) o_cnt[j * 4 + b] = c;
+        if (o_local) o_local[j * 4 + b] = loc;
+        if (o_owner) o_owner[j * 4 + b] = ow;
+    }
+}
+
+// rows of n nodes of a part (d_ids: uint32 local ids, device); every output is a device array and may be NULL:
+// keys / keys_hi / stamps u64[n], counts u32[n][4] by base code, succ_owner u8[n][4] (virtual shard, 0xFF: no successor),
+// succ_local u32[n][4], pflags u8[n] (DBG_F_INDEG alone before dbg_part_prune)
+extern "C" int dbg_part_gather(dbg_t *h, int part, const void *d_ids, uint64_t n, void *d_keys, void *d_keys_hi, void *d_stamps,
+                               void *d_counts, void *d_succ_owner, void *d_succ_local, void *d_pflags) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!n) return DBG_OK;
+    if (!d_ids || !sub->n_nodes) { h->err = "dbg_part_gather: no ids / the part is empty"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_scalars + 8, 0, 8, h->stream));
+    unsigned long long *err = (unsigned long long *)(h->d_scalars + 8);
+#define DBG_PG_ARGS (const uint32_t *)d_ids, n, sub->n_nodes, sub->d_keys, sub->k > 31 ? sub->d_keys_hi : (const uint64_t *)nullptr
+#define DBG_PG_REST sub->d_flags, sub->d_rowptr32, sub->d_col, mp->col_owner[part], sub->d_ecnt, mp->pflags[part], (uint64_t *)d_keys, \
+                    (uint64_t *)d_keys_hi, (uint64_t *)d_stamps, (uint32_t *)d_counts, (uint8_t *)d_succ_owner, (uint32_t *)d_succ_local, (uint8_t *)d_pflags, err
+    if (sub->stamps_st_bytes == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_gather<uint32_t>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream, DBG_PG_ARGS,
+                           (const uint32_t *)sub->d_stamps_st, DBG_PG_REST);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_part_gather<uint64_t>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream, DBG_PG_ARGS,
+                           (const uint64_t *)sub->d_stamps_st, DBG_PG_REST);
+#undef DBG_PG_ARGS
+#undef DBG_PG_REST
+    HIPCHK(h, hipGetLastError());
+    uint64_t e = 0;
+    HIPCHK(h, hipMemcpyAsync(&e, h->d_scalars + 8, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (e) { h->err = "dbg_part_gather: a node id is out of range"; return DBG_E_ARG; }
+    return DBG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_part_mark(const uint32_t *__restrict__ ids, uint64_t n, uint64_t n_nodes, uint8_t bits,
+                                                   uint8_t *pflags, uint8_t *newly, unsigned long long *err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t i = ids[j];
+    if (i >= n_nodes) { atomicOr(err, 1ull); return; }
+    // byte-wide read-modify-write through the enclosing word (several ids may share it)
+    uint32_t *w = reinterpret_cast<uint32_t *>(pflags + (i & ~3ull));
+    const uint32_t sh = 8u * (i & 3u);
+    const uint32_t old = atomicOr(w, (uint32_t)bits << sh);
+    if (newly) newly[j] = (uint8_t)((((old >> sh) & bits) != bits) ? 1 : 0);
+}
+
+// sets flag bits (DBG_F_PULLED, DBG_PF_*) on n nodes; d_newly (u8[n], device, may be NULL): 1 where not all bits were set
+// before.  The same id twice in one call: exactly one of the two reports "newly".
+extern "C" int dbg_part_mark(dbg_t *h, int part, const void *d_ids, uint64_t n, uint32_t bits, void *d_newly) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!n) return DBG_OK;
+    if (!d_ids || !sub->n_nodes || !mp->pflags[part]) { h->err = "dbg_part_mark: dbg_part_prune must run first"; return DBG_E_ARG; }
+    if (bits & ~0xFFu) return DBG_E_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_scalars + 8, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_part_mark, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const uint32_t *)d_ids, n, sub->n_nodes,
+                       (uint8_t)bits, mp->pflags[part], (uint8_t *)d_newly, (unsigned long long *)(h->d_scalars + 8));
+    HIPCHK(h, hipGetLastError());
+    uint64_t e = 0;
+    HIPCHK(h, hipMemcpyAsync(&e, h->d_scalars + 8, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (e) { h->err = "dbg_part_mark: a node id is out of range"; return DBG_E_ARG; }
+    return DBG_OK;
+}
+
+// A chain node: not a branch node, not pulled, exactly one kept successor (debruijn.py:288-316 walks through it).
+__device__ inline bool pf_chain(uint32_t pf) {
+    return !(pf & (DBG_F_BRANCH | DBG_F_PULLED)) && __popc(pf & DBG_F_KEEP_MASK) == 1;
+}
+// CSR column of the kept successor of a chain node
+__device__ inline uint32_t pf_kept_col(uint32_t flags_present, uint32_t pf, uint32_t row) {
+    const uint32_t pres = (flags_present >> 1) & 15u, b = __ffs((pf & DBG_F_KEEP_MASK) >> DBG_F_KEEP_SHIFT) - 1;
+    return row + __popc(pres & ((1u << b) - 1u));
+}
+
+// pass 0: counts per owner; pass 1: the targets, grouped by owner (cursor[v] starts at the group's offset)
+__global__ __launch_bounds__(256) void k_part_cross(uint64_t n, int me, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ pflags,
+                                                    const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                    const uint8_t *__restrict__ col_owner, unsigned long long *cursor /* [64] */,
+                                                    uint32_t *targets) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pf = pflags[i];
+    if (!pf_chain(pf)) return;
+    const uint32_t e = pf_kept_col(flags[i], pf, rowptr[i]);
+    const int ow = col_owner[e];
+    if (ow == me) return;
+    const unsigned long long at = atomicAdd(&cursor[ow & 63], 1ull);
+    if (targets) targets[at] = col[e];
+}
+
+// Kept edges of this part's chain nodes that leave the part: the local ids of their targets IN the target's part, grouped by
+// target virtual shard (counts[n_virtual], group v at the prefix sum of the counts before it).  d_targets NULL: counts only.
+extern "C" int dbg_part_cross_targets(dbg_t *h, int part, uint64_t *counts, void *d_targets, uint64_t capacity) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!counts) return DBG_E_ARG;
+    for (int v = 0; v < mp->n_virtual; ++v) counts[v] = 0;
+    if (!sub->n_nodes) return DBG_OK;
+    if (!mp->pflags[part]) { h->err = "dbg_part_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    unsigned long long *cur = (unsigned long long *)(h->d_scalars + 64);  // 64 words: the descriptor slot is free outside a build
+    HIPCHK(h, hipMemsetAsync(cur, 0, 64 * 8, h->stream));
+    const int me = mp->v_first + part;
+    hipLaunchKernelGGL(k_part_cross, dim3(grid_for(sub->n_nodes, 256)), dim3(256), 0, h->stream, sub->n_nodes, me, sub->d_flags,
+                       mp->pflags[part], sub->d_rowptr32, sub->d_col, mp->col_owner[part], cur, (uint32_t *)nullptr);
+    HIPCHK(h, hipGetLastError());
+    uint64_t hc[64];
+    HIPCHK(h, hipMemcpyAsync(hc, cur, 64 * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    uint64_t total = 0, off[64];
+    for (int v = 0; v < 64; ++v) { off[v] = total; total += hc[v]; if (v < mp->n_virtual) counts[v] = hc[v]; }
+    if (!d_targets || !total) return DBG_OK;
+    if (total > capacity) { h->err = "dbg_part_cross_targets: capacity below the number of cross edges"; return DBG_E_CAPACITY; }
+    HIPCHK(h, hipMemcpyAsync(cur, off, 64 * 8, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_part_cross, dim3(grid_for(sub->n_nodes, 256)), dim3(256), 0, h->stream, sub->n_nodes, me, sub->d_flags,
+                       mp->pflags[part], sub->d_rowptr32, sub->d_col, mp->col_owner[part], cur, (uint32_t *)d_targets);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
+// One segment of a contig walk (debruijn.py:288-316) inside a part.  Entry e is "entered" like DFS(current = e):
+//   kind 0 EMIT_HERE   the path ends AT node `last` (a branch node, or no kept successor): emit, last included
+//   kind 1 PULLED      e itself is pulled: the path ended at the previous node (nothing, if e is the start)
+//   kind 2 REMOTE      the chain leaves the part: next = (owner, local) of the node entered next
+//   kind 3 CYCLE       the chain came back to a node of this walk (`current in vec`): the start emits nothing
+//   kind 4 NEXT_PULLED the kept successor of `last` is pulled and lives in this part: emit, last included
+// hops = edges walked inside the part, score = sum of their counts.
+__global__ __launch_bounds__(256) void k_part_segments(const uint32_t *__restrict__ entries, uint64_t n, uint64_t n_nodes, int me,
+                                                       const uint8_t *__restrict__ flags, const uint8_t *__restrict__ pflags,
+                                                       const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
+                                                       const uint8_t *__restrict__ col_owner, const uint32_t *__restrict__ ecnt,
+                                                       uint8_t *o_kind, uint8_t *o_owner, uint32_t *o_local, uint32_t *o_hops,
+                                                       uint64_t *o_score, uint32_t *o_last) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t cur = entries[j], hops = 0, kind = 0, nloc = NO_NODE, nown = 0xFF;
+    uint64_t score = 0;
+    if (cur >= n_nodes) { o_kind[j] = 3; o_owner[j] = 0xFF; o_local[j] = NO_NODE; o_hops[j] = 0; o_score[j] = 0; o_last[j] = NO_NODE; return; }
+    if (pflags[cur] & DBG_F_PULLED) kind = 1;
+    else {
+        // Brent's cycle test: a chain that stays inside the part for ever visits a node twice
+        uint32_t tortoise = cur, power = 1, lam = 0;
+        for (;;) {
+            const uint32_t pf = pflags[cur];
+            if (!pf_chain(pf)) { kind = 0; break; }   // branch node or no kept successor (a pulled node is never entered here)
+            const uint32_t e = pf_kept_col(flags[cur], pf, rowptr[cur]);
+            const uint32_t ow = col_owner[e], nx = col[e];
+            if ((int)ow != me) { kind = 2; nown = ow; nloc = nx; cur = ecnt[e]; break; }  // `last` carries the leaving edge's count
+            if (pflags[nx] & DBG_F_PULLED) { kind = 4; break; }
+            score += ecnt[e];
+            ++hops;
+            cur = nx;
+            if (cur == tortoise) { kind = 3; break; }
+            if (++lam == power) { tortoise = cur; power <<= 1; lam = 0; }
+        }
+    }
+    o_kind[j] = (uint8_t)kind; o_owner[j] = (uint8_t)nown; o_local[j] = nloc; o_hops[j] = hops; o_score[j] = score; o_last[j] = cur;
+}
+
+// segments from n entry nodes (d_entries: uint32 local ids, device).  Outputs (device): kind u8[n], next_owner u8[n],
+// next_local u32[n], hops u32[n], score u64[n], last u32[n] (the node the segment ended at; kind REMOTE: the count of the edge
+// that leaves the part -- the caller adds it when the node it enters is not pulled).
+extern "C" int dbg_part_segments(dbg_t *h, int part, const void *d_entries, uint64_t n, void *d_kind, void *d_next_owner,
+                                 void *d_next_local, void *d_hops, void *d_score, void *d_last) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!n) return DBG_OK;
+    if (!d_entries || !d_kind || !d_next_owner || !d_next_local || !d_hops || !d_score || !d_last) return DBG_E_ARG;
+    if (!sub->n_nodes || !mp->pflags[part]) { h->err = "dbg_part_segments: dbg_part_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int me = mp->v_first + part;
+    hipLaunchKernelGGL(k_part_segments, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const uint32_t *)d_entries, n, sub->n_nodes, me,
+                       sub->d_flags, mp->pflags[part], sub->d_rowptr32, sub->d_col, mp->col_owner[part], sub->d_ecnt, (uint8_t *)d_kind,
+                       (uint8_t *)d_next_owner, (uint32_t *)d_next_local, (uint32_t *)d_hops, (uint64_t *)d_score, (uint32_t *)d_last);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_part_clear(uint64_t n_words, uint32_t keep4, uint32_t *pflags_words) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) pflags_words[i] &= keep4;
+}
+
+// clears flag bits on every node of the part (a mark of one phase, before the next phase uses the bit)
+extern "C" int dbg_part_clear(dbg_t *h, int part, uint32_t bits) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (bits & ~0xFFu) return DBG_E_ARG;
+    if (!sub->n_nodes || !mp->pflags[part]) return DBG_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint32_t keep = ~bits & 0xFFu, keep4 = keep * 0x01010101u;
+    const uint64_t n_words = sub->n_nodes / 4;  // hipMalloc'd: whole words up to the last partial one, which goes byte by byte
+    if (n_words) hipLaunchKernelGGL(k_part_clear, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, n_words, keep4, (uint32_t *)mp->pflags[part]);
+    HIPCHK(h, hipGetLastError());
+    const uint64_t rest = sub->n_nodes - n_words * 4;
+    if (rest) {
+        uint8_t tail[4] = {0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(tail, mp->pflags[part] + n_words * 4, rest, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        for (uint64_t q = 0; q < rest; ++q) tail[q] &= (uint8_t)keep;
+        HIPCHK(h, hipMemcpyAsync(mp->pflags[part] + n_words * 4, tail, rest, hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return DBG_OK;
+}
+
+// device pointer of a part's traversal flags (u8[n_nodes]; NULL before dbg_part_prune)
+extern "C" int dbg_part_pflags(dbg_t *h, int part, const void **d_pflags) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!d_pflags) return DBG_E_ARG;
+    *d_pflags = mp->pflags[part];
+    return DBG_OK;
+}
+
+// ---- reads against a small set of k-mers (the branch k-mers of the WHOLE graph, gathered from all parts and ranks)
+struct ScanKey { unsigned long long lo, hi; };
+__device__ inline uint64_t scan_hash(uint64_t lo, uint64_t hi) { return mix64(lo * 0x9E3779B97F4A7C15ull ^ mix64(hi + 0x632BE59BD9B4E019ull)); }
+
+__global__ __launch_bounds__(256) void k_scan_insert(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, uint64_t n,
+                                                     unsigned long long *tab_lo, unsigned long long *tab_hi, uint32_t *tab_idx,
+                                                     uint64_t cap_mask) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long kl = lo[i], kh = hi ? hi[i] : 0ull;
+    uint64_t slot = scan_hash(kl, kh) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        // claim by index (the keys are distinct: no two threads insert the same one)
+        if (atomicCAS(&tab_idx[slot], 0xFFFFFFFFu, (uint32_t)i) == 0xFFFFFFFFu) { tab_lo[slot] = kl; tab_hi[slot] = kh; return; }
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
+// every k-mer window of the reads (two words: any k <= 63) against the set; a hit marks its read and lowers the first
+// appearance of the edge (k-mer, next base) -- position of the k-mer in THIS handle's reads -- when the window has a successor
+__global__ __launch_bounds__(256) void k_scan_reads(const char *__restrict__ bases, uint64_t n_bytes, const uint64_t *__restrict__ offsets,
+                                                    uint64_t n_reads, int k, const unsigned long long *__restrict__ tab_lo,
+                                                    const unsigned long long *__restrict__ tab_hi, const uint32_t *__restrict__ tab_idx,
+                                                    uint64_t cap_mask, uint8_t *read_flags, unsigned long long *first_seen) {
+    // one thread per read position; the k-mer is rebuilt from the bytes (the set is small and most windows miss on the
+    // first probe, so the pass is bound by reading the bases: k bytes per window out of L1)
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p + k > n_bytes) return;
+    // read of position p: last r with offsets[r] <= p
+    uint64_t rlo = 0, rhi = n_reads;
+    while (rhi - rlo > 1) {
+        const uint64_t mid = (rlo + rhi) >> 1;
+        if (offsets[mid] <= p) rlo = mid; else rhi = mid;
+    }
+    const uint64_t r_end = offsets[rlo + 1];
+    if (p + k > r_end) return;  // the window crosses into the next read
+    unsigned long long lo = 0, hi = 0;
+    for (int q = 0; q < k; ++q) {
+        const uint32_t code = ((uint32_t)(uint8_t)bases[p + q] >> 1) & 3u;
+        hi = (hi << 2) | (lo >> 62);
+        lo = (lo << 2) | code;
+    }
+    if (k < 32) { lo &= (1ull << (2 * k)) - 1; hi = 0; }
+    else if (k == 32) hi = 0;
+    else hi &= (1ull << (2 * k - 64)) - 1;
+    uint64_t slot = scan_hash(lo, hi) & cap_mask;
+    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+        const uint32_t idx = tab_idx[slot];
+        if (idx == 0xFFFFFFFFu) return;
+        if (tab_lo[slot] == lo && tab_hi[slot] == hi) {
+            read_flags[rlo] = 1;
+            if (first_seen && p + k < r_end) {
+                const uint32_t nb = ((uint32_t)(uint8_t)bases[p + k] >> 1) & 3u;
+                atomicMin(&first_seen[(uint64_t)idx * 4 + nb], (unsigned long long)p);
+            }
+            return;
+        }
+        slot = (slot + 1) & cap_mask;
+    }
+}
+
+// pull_out_read (debruijn.py:274-278) for a graph in parts: read_flags[n_reads] (host) = 1 where this handle's read holds
+// one of the n_keys k-mers (host arrays; keys_hi NULL for k <= 32); first_seen[n_keys][4] (host, may be NULL): smallest
+// byte offset in this handle's reads of the window k-mer + next base, UINT64_MAX if it never occurs here (the caller takes
+// the minimum over ranks after adding each rank's byte base: Counter order of the successors of the branch nodes).
+extern "C" int dbg_scan_reads_for_keys(dbg_t *h, int k, const uint64_t *keys, const uint64_t *keys_hi, uint64_t n_keys,
+                                       uint8_t *read_flags, uint64_t *first_seen) {
+    if (!h || k < 1 || k > 63 || (n_keys && !keys)) return DBG_E_ARG;
+    if (!h->d_offsets) { h->err = "no reads set"; return DBG_E_ARG; }
+    if (n_keys >= 0xFFFFFFF0ull) { h->err = "too many keys"; return DBG_E_CAPACITY; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (read_flags && h->n_reads) memset(read_flags, 0, h->n_reads);
+    if (first_seen && n_keys) memset(first_seen, 0xFF, n_keys * 32);
+    if (!n_keys || !h->n_reads || h->n_bytes < (uint64_t)k) return DBG_OK;
+    uint64_t cap = 1024;
+    while (cap < n_keys * 2) cap <<= 1;
+    unsigned long long *t_lo = nullptr, *t_hi = nullptr, *d_fs = nullptr;
+    uint64_t *d_lo = nullptr, *d_hi = nullptr;
+    uint32_t *t_idx = nullptr;
+    uint8_t *d_rf = nullptr;
+    auto done = [&](int code) { dev_free(t_lo); dev_free(t_hi); dev_free(d_fs); dev_free(d_lo); dev_free(d_hi); dev_free(t_idx); dev_free(d_rf); return code; };
+    int rc = dev_alloc(h, &t_lo, cap);
+    if (rc == DBG_OK) rc = dev_alloc(h, &t_hi, cap);
+    if (rc == DBG_OK) rc = dev_alloc(h, &t_idx, cap);
+    if (rc == DBG_OK) rc = dev_alloc(h, &d_lo, n_keys);
+    if (rc == DBG_OK) rc = dev_alloc(h, &d_hi, n_keys);
+    if (rc == DBG_OK) rc = dev_alloc(h, &d_rf, h->n_reads);
+    if (rc == DBG_OK && first_seen) rc = dev_alloc(h, &d_fs, n_keys * 4);
+    if (rc != DBG_OK) return done(rc);
+    hipError_t e = hipMemsetAsync(t_idx, 0xFF, cap * 4, h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_rf, 0, h->n_reads, h->stream);
+    if (e == hipSuccess && d_fs) e = hipMemsetAsync(d_fs, 0xFF, n_keys * 32, h->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_lo, keys, n_keys * 8, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = keys_hi ? hipMemcpyAsync(d_hi, keys_hi, n_keys * 8, hipMemcpyHostToDevice, h->stream) : hipMemsetAsync(d_hi, 0, n_keys * 8, h->stream);
+    if (e != hipSuccess) { h->err = std::string("dbg_scan_reads_for_keys: ") + hipGetErrorString(e); return done(DBG_E_HIP); }
+    hipLaunchKernelGGL(k_scan_insert, dim3(grid_for(n_keys, 256)), dim3(256), 0, h->stream, d_lo, d_hi, n_keys, t_lo, t_hi, t_idx, cap - 1);
+    hipLaunchKernelGGL(k_scan_reads, dim3(grid_for(h->n_bytes, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, h->d_offsets,
+                       h->n_reads, k, t_lo, t_hi, t_idx, cap - 1, d_rf, d_fs);
+    e = hipGetLastError();
+    if (e == hipSuccess && read_flags) e = hipMemcpyAsync(read_flags, d_rf, h->n_reads, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && first_seen) e = hipMemcpyAsync(first_seen, d_fs, n_keys * 32, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { h->err = std::string("dbg_scan_reads_for_keys: ") + hipGetErrorString(e); return done(DBG_E_HIP); }
+    return done(DBG_OK);
+}
+
+// successor ranks of the current (single-piece) graph: order[n_nodes] bytes in the layout of dbg_export_orders -- what
+// dbg_refine_edge_order would compute from the reads, handed in by a caller that knows it (an imported neighbourhood graph)
+extern "C" int dbg_set_orders(dbg_t *h, const uint8_t *order) {
+    if (!h || !h->k || !order) return DBG_E_ARG;
+    if (h->multipass) { h->err = kMultipassGraph; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    CHK(ensure_dense(h));
+    if (h->D == GEN_D || !h->d_order) { h->err = "dbg_set_orders takes a graph over ACGT"; return DBG_E_ARG; }
+    if (h->n_nodes) HIPCHK(h, hipMemcpyAsync(h->d_order, order, h->n_nodes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->order_exact = true;
     return DBG_OK;
 }
 
