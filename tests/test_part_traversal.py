@@ -109,3 +109,163 @@ def test_traversal_refuses_what_it_cannot_do():
     with pytest.raises(_dbg.DbgError):
         g.part_select(0, 0x20, 0x20)                  # before dbg_part_prune
     g.close()
+
+
+def rewalk(g, k, starts_v, starts_local, max_steps=100000):
+    """Independent restatement of one contig walk per start (debruijn.py:288-316, non-final) over the parts' rows
+    (dbg_part_gather only): follows (virtual shard, local id) step by step.  -> (emits, length, score) numpy arrays."""
+    import torch
+    n = len(starts_v)
+    v = np.asarray(starts_v, dtype=np.int64).copy()
+    loc = np.asarray(starts_local, dtype=np.int64).copy()
+    hops = np.zeros(n, dtype=np.int64)
+    score = np.zeros(n, dtype=np.int64)
+    emits = np.zeros(n, dtype=bool)
+    active = np.ones(n, dtype=bool)
+    seen = [set() for _ in range(n)]
+    last_cnt = np.zeros(n, dtype=np.int64)
+    for _ in range(max_steps):
+        if not active.any():
+            break
+        rows = {}
+        for p in np.unique(v[active]):
+            sel = np.nonzero(active & (v == p))[0]
+            ids = torch.from_numpy(loc[sel].astype(np.uint32).view(np.int32).copy()).cuda()
+            r = g.part_gather(int(p), ids, what=("counts", "succ_owner", "succ_local", "pflags"))
+            rows[int(p)] = (sel, r["counts"].cpu().numpy().view(np.uint32).reshape(-1, 4), r["succ_owner"].cpu().numpy().reshape(-1, 4),
+                            r["succ_local"].cpu().numpy().view(np.uint32).reshape(-1, 4), r["pflags"].cpu().numpy())
+        for p, (sel, cnt, so, sl, pf) in rows.items():
+            for j, i in enumerate(sel):
+                node = (int(v[i]), int(loc[i]))
+                if node in seen[i]:                     # current in vec: nothing is emitted
+                    active[i] = False
+                    emits[i] = False
+                    continue
+                if pf[j] & 0x40:                        # current in already_pull_out: the path ended at the previous node
+                    active[i] = False
+                    emits[i] = len(seen[i]) > 0         # len(vec) == 1 (the start itself is pulled): nothing
+                    if emits[i]:
+                        hops[i] -= 1                    # ... so the edge that entered it does not count
+                        score[i] -= last_cnt[i]
+                    continue
+                seen[i].add(node)
+                keep = (pf[j] >> 1) & 15
+                if (pf[j] & 0x20) or keep == 0:         # branch node, or no successor left
+                    active[i] = False
+                    emits[i] = True
+                    continue
+                b = (int(keep) & -int(keep)).bit_length() - 1
+                last_cnt[i] = int(cnt[j, b])
+                hops[i] += 1
+                score[i] += int(cnt[j, b])
+                v[i], loc[i] = int(so[j, b]), int(sl[j, b])
+    assert not active.any(), "a sampled walk did not end"
+    return emits, hops + k, score
+
+
+
+@pytest.mark.parametrize("k,n_passes", [(31, 4)])
+def test_rewalk_of_sampled_starts_equals_the_index(k, n_passes):
+    """The contig index of the segment skeleton against an independent step-by-step walk over dbg_part_gather rows."""
+    import part_traversal
+    import torch
+    reads = synth.reads_ascii(29, 40000, 8000, 150, 0.01)
+    g = _dbg.Graph()
+    g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, 150, dtype=np.uint64))
+    g.build_multipass(k, n_passes)
+    t = part_traversal.PartTraversal(g, k)
+    t.prune(2); t.pull_out_reads(); t.remove_tips()
+    idx = t.walk_index()
+    by_stamp = {int(s): (int(l), int(c)) for s, l, c in zip(idx["stamp"], idx["length"], idx["score"])}
+    rng = np.random.default_rng(3)
+    sv, sl, ss = [], [], []
+    for p in range(n_passes):
+        ids = g.part_select(p, 0x01, 0)
+        pick = ids[torch.from_numpy(rng.choice(ids.numel(), size=min(60, ids.numel()), replace=False)).cuda()].contiguous()
+        st = g.part_gather(p, pick, what=("stamps",))["stamps"].cpu().numpy()
+        sv += [p] * pick.numel(); sl += (pick.cpu().numpy().view(np.uint32)).tolist(); ss += st.tolist()
+    emits, length, score = rewalk(g, k, sv, sl)
+    assert emits.sum() > 100
+    for e, l, c, s in zip(emits, length, score, ss):
+        assert (int(s) in by_stamp) == bool(e)
+        if e:
+            assert by_stamp[int(s)] == (int(l), int(c))
+    g.close()
+
+
+def test_traversal_in_parts_at_the_baseline_size():
+    """BASELINE.json configs[1] (10 M x 150 bp, k = 31, 1 % substitutions): the graph built in four parts and traversed
+    part by part equals the single-GPU path -- branch list, pulled list, pull-out reads, and the 3 million contigs' (start
+    stamp, length, score) -- without the four parts ever being one graph."""
+    import part_traversal
+    n, L, k = 10_000_000, 150, 31
+    g1 = _dbg.Graph()
+    g1.synth_reads(1, n * L // 30, n, L, 0.01)
+    g1.build(k); g1.refine_edge_order(); g1.prune(2); g1.remove_tips(); g1.mark_pull_reads()
+    sz = g1.sizes()
+    br_rows, br_keys, _ = g1.export_marked(_dbg.F_BRANCH)
+    pu_rows, pu_keys, _ = g1.export_marked(_dbg.F_PULLED)
+    rf = g1.export_pull_reads()
+    g1.walk(False, 1)
+    off, score, stamp, seq = g1.export_contig_index()
+    o = np.lexsort((seq, stamp))
+    want = (stamp[o], (off[1:] - off[:-1])[o].astype(np.int64), score[o].astype(np.int64))
+    bases, offsets = g1.copy_reads()
+    g1.close()
+    g = _dbg.Graph()
+    g.set_reads(bases, offsets)
+    g.build_multipass(k, 4)
+    res = part_traversal.traverse(g, k, 2)
+    assert sz["n_branch"] == res["branch"]["keys"].size and np.array_equal(res["branch"]["keys"].astype(np.uint64), br_keys)
+    assert sz["n_pulled"] == res["pulled"]["keys"].size and np.array_equal(res["pulled"]["keys"], pu_keys)
+    assert np.array_equal(res["read_flags"], rf)
+    assert np.array_equal(res["contigs"]["stamp"], want[0])
+    assert np.array_equal(res["contigs"]["length"], want[1]) and np.array_equal(res["contigs"]["score"], want[2])
+    g.close()
+
+
+def test_traversal_of_more_than_two_to_the_32_nodes():
+    """BASELINE.json configs[3]'s per-rank size on one GPU: 4.4e9 nodes in 8 parts (45 M x 150 bp, 5 % substitutions).
+    pruningEdges on every part and the contig index through the segment skeleton (3.5e8 entries ranked on the device); the
+    index is checked against an independent step-by-step walk of sampled starts and through totals that hold at any size.
+    (The tip neighbourhoods are not collected here: at 5 % errors a third of all nodes is within five steps of a branch node,
+    so they are not the small graph the method assumes -- the BASELINE error rate is covered at full size above.)"""
+    import part_traversal
+    import torch
+    torch.zeros(1, device="cuda")
+    n, L, k, G = 45_000_000, 150, 31, 225_000_000
+    g = _dbg.Graph()
+    g.synth_reads(1, G, n, L, 0.05)
+    g.build_multipass(k, 8)
+    sz = g.sizes()
+    assert sz["n_nodes"] > (1 << 32)
+    t = part_traversal.PartTraversal(g, k)
+    branch = t.prune(2)
+    n_branch = branch["gid"].size
+    assert n_branch > 0
+    # every branch node keeps at least two successors, each at least half as frequent as the most frequent one (threshold 2)
+    keep = (branch["pflags"][:, None] >> (1 + np.arange(4)[None, :])) & 1
+    assert np.all(keep.sum(axis=1) >= 2)
+    mx = branch["counts"].max(axis=1)
+    assert np.all(np.where(keep == 1, 2 * branch["counts"] >= mx[:, None], True))
+    idx = t.walk_index()
+    n_starts = sz["n_starts"]
+    assert 0 < idx["stamp"].size <= n_starts
+    assert np.all(idx["length"] >= k) and np.all(idx["score"] >= 0) and np.all(idx["stamp"][1:] > idx["stamp"][:-1])
+    assert np.all((idx["stamp"] & np.uint64(1)) == 0) and np.all((idx["stamp"] >> np.uint64(1)) % np.uint64(L) == 0)  # starts: position 0 of a read
+    by_stamp = dict(zip(idx["stamp"].tolist(), zip(idx["length"].tolist(), idx["score"].tolist())))
+    rng = np.random.default_rng(5)
+    sv, sl, ss = [], [], []
+    for p in range(8):
+        ids = g.part_select(p, 0x01, 0)
+        pick = ids[torch.from_numpy(rng.choice(ids.numel(), size=40, replace=False)).cuda()].contiguous()
+        st = g.part_gather(p, pick, what=("stamps",))["stamps"].cpu().numpy()
+        sv += [p] * pick.numel(); sl += (pick.cpu().numpy().view(np.uint32)).tolist(); ss += st.tolist()
+        del ids
+    emits, length, score = rewalk(g, k, sv, sl)
+    assert emits.sum() > 100
+    for e, l, c, s in zip(emits, length, score, ss):
+        assert (int(s) in by_stamp) == bool(e)
+        if e:
+            assert by_stamp[int(s)] == (int(l), int(c))
+    g.close()
