@@ -8,11 +8,13 @@ resident in HBM.
 Workloads:
   N = 1              BASELINE.json configs[1]: 10 M x 150 bp reads, k = 31, one MI355X, dbg_build.
   N > 1 (default)    BASELINE.json configs[2] scaled by N/8: 12.5 M reads per rank over an N x 62.5 Mbp genome, hash-prefix
-                     sharded build with RCCL all-to-all (multi_gpu.sharded_build); N = 8 is configs[2] itself
-                     (100 M x 150 bp).  Per-GPU work is fixed: "scaling": "weak".
-  --scaling strong   a FIXED total (--total-reads, default 14 M: the N = 1 leg is ONE shard, and a shard names 2^29 - 16
-                     nodes; 14 M reads give 5.1e8) split over the ranks: "scaling": "strong".  N = 1 runs the sharded
-                     path on one rank so that every N runs the same code.
+                     sharded build with RCCL all-to-all (multi_gpu.sharded_build_multipass with one pass: every successor
+                     is (owner byte, 32-bit local id), so a shard names 2^32 - 16 nodes -- configs[2] fills a tenth of
+                     that, configs[4] (--k 63) an eighth); N = 8 is configs[2] itself (100 M x 150 bp).  Per-GPU work is
+                     fixed: "scaling": "weak".
+  --scaling strong   a FIXED total (--total-reads, default 40 M: 1.45e9 nodes, which the one shard of the N = 1 leg holds)
+                     split over the ranks: "scaling": "strong".  N = 1 runs the sharded path on one rank so that every N
+                     runs the same code.
 The driver launches N > 1 as  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel AND whole step) and
@@ -53,7 +55,7 @@ def pmc_traffic(kernel):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile (rocprofv3 --pmc passes of their own,
     FETCH_SIZE x2 per the gfx950 correction) -- only when that profile was collected on exactly these kernel sources
     (it records their hash); otherwise None: a stale figure next to a fresh time would be worse than none."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic_pmc.json")
     try:
         with open(path) as fh:
             prof = json.load(fh)
@@ -62,7 +64,7 @@ def pmc_traffic(kernel):
         for row in prof["kernels"]:
             if kernel in row["kernel"]:
                 return (row["hbm_read_GB_corrected_x2"] + row["hbm_write_GB"]) * 1e9, \
-                    f"profiles/r02_hbm_traffic_pmc.json (kernel sources {prof['kernel_source_hash']})"
+                    f"profiles/r03_hbm_traffic_pmc.json (kernel sources {prof['kernel_source_hash']})"
     except (OSError, ValueError, KeyError):
         pass
     return None, None
@@ -133,6 +135,32 @@ def extras(g, args, k, L, genome_len, reads_per_rank):
         del text, rec, bases
     except MemoryError:
         out["fasta_ingest"] = None
+    # the same graph built in four parts and traversed part by part (part_traversal.py): what a rank of configs[2..4] runs
+    # after its build, here with the parts of one GPU -- equal results to the path above are asserted in
+    # tests/test_part_traversal.py at this very size
+    try:
+        import part_traversal
+        gp = _dbg.Graph(device=int(os.environ.get("LOCAL_RANK", "0")))
+        gp.synth_reads(args.seed, genome_len, reads_per_rank, L, args.err)
+        tp = {}
+        for rep in range(2):
+            t0 = time.perf_counter(); gp.build_multipass(k, 4); tp["build_multipass_4"] = round((time.perf_counter() - t0) * 1e3, 2)
+            pt = part_traversal.PartTraversal(gp, k)
+            for name, fn in (("prune_and_branch_list", lambda: pt.prune(2)), ("pull_out_reads_and_counter_order", pt.pull_out_reads),
+                             ("remove_tips", pt.remove_tips), ("walk_index_nonfinal", pt.walk_index)):
+                t0 = time.perf_counter()
+                r = fn()
+                tp[name] = round((time.perf_counter() - t0) * 1e3, 2)
+            n_ctg = int(r["stamp"].size)
+        out["traversal_in_parts_ms"] = tp
+        out["traversal_in_parts_sizes"] = {"n_branch": int(pt.branch["gid"].size), "n_pulled": int(pt.pulled["gid"].size),
+                                           "n_pull_reads": int(pt.read_flags.sum()), "n_contigs": n_ctg,
+                                           "same_as_single_graph": bool(int(pt.branch["gid"].size) == sz["n_branch"] and
+                                                                        int(pt.pulled["gid"].size) == sz["n_pulled"] and
+                                                                        int(pt.read_flags.sum()) == sz["n_pull_reads"] and n_ctg == sz["n_contigs"])}
+        gp.close()
+    except Exception as e:  # noqa: BLE001
+        out["traversal_in_parts_error"] = f"{type(e).__name__}: {e}"
     if args.err > 0:
         g0 = _dbg.Graph(device=int(os.environ.get("LOCAL_RANK", "0")))
         g0.synth_reads(args.seed, genome_len, reads_per_rank, L, 0.0)
@@ -187,16 +215,29 @@ def cpu_baseline(g, read_len, k, n_reads, gpu_sizes, gpu_digest):
     t0 = time.perf_counter()
     res = orc_c.build_mt(reads, off, k, cores)
     dt = time.perf_counter() - t0
-    del reads
     with open("/proc/cpuinfo") as fh:
         model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "?")
     same = (res["n_nodes"] == gpu_sizes["n_nodes"] and res["n_edges"] == gpu_sizes["n_edges"] and
             res["n_kmer_instances"] == gpu_sizes["n_kmer_instances"] and
             (gpu_digest is None or res["digest"] == gpu_digest))
+    # one thread on a sixteenth of the reads: what a thread does when it keeps everything it hashes
+    one = None
+    try:
+        n1 = max(1, n_reads // 16)
+        r1, o1 = reads[:int(off[n1])], off[:n1 + 1]
+        t1 = time.perf_counter()
+        res1 = orc_c.build_mt(r1, o1, k, 1)
+        dt1 = time.perf_counter() - t1
+        one = {"value": res1["n_kmer_instances"] / dt1, "unit": "k-mers/s", "cores": 1, "reads": int(n1), "seconds": round(dt1, 2)}
+    except Exception as e:  # noqa: BLE001
+        one = {"error": f"{type(e).__name__}: {e}"}
     out = {"value": res["n_kmer_instances"] / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
            "sample": f"the full input of this run ({n_reads} reads, {res['n_kmer_instances']} k-mer instances, "
                      f"{res['n_nodes']} distinct), oracle/dbg_oracle.c orc_build_mt with {cores} threads, {dt:.1f} s; "
+                     f"every thread rolls and hashes ALL k-mers and keeps its 1/{cores} of them (no pre-partition), so the "
+                     f"scan work grows with the thread count -- see one_thread for a thread that keeps all it hashes; "
                      f"{model}, {os.cpu_count()} cpus visible, {cores} usable (affinity / cgroup quota)",
+           "one_thread": one,
            "same_graph_as_gpu": bool(same),
            "compared": "node, edge and k-mer instance totals" + ("" if gpu_digest is None else
                                                                     " + 64-bit digest over (k-mer, stamp, 4 counts) of every node")}
@@ -226,7 +267,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 10 M at N = 1, 12.5 M at N > 1)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
-    ap.add_argument("--total-reads", type=int, default=14_000_000, help="--scaling strong: the fixed total")
+    ap.add_argument("--total-reads", type=int, default=40_000_000, help="--scaling strong: the fixed total")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--err", type=float, default=0.01, help="per-base substitution rate")
@@ -294,7 +335,8 @@ def main():
         if not sharded:
             g.build(k, args.table_hint)
             return g
-        return multi_gpu.sharded_build(g, k, dist, check=not args.no_exchange_check)
+        # one pass per rank: the plain sharded build with (owner byte, 32-bit local id) successors
+        return multi_gpu.sharded_build_multipass(g, k, dist, 1, check=not args.no_exchange_check)
 
     def sync():
         torch.cuda.synchronize()
@@ -319,6 +361,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the first build on a read set also scans it for its alphabet (cached per read set): what the multi-k driver pays
+    # after every `sequences.extend(...)`; the timed steps above are the steady state
+    first_build_ms = None
+    if not sharded:
+        g.synth_reads(args.seed, genome_len, reads_per_rank, L, args.err, first_read=rank * reads_per_rank)
+        sync()
+        t1 = time.perf_counter()
+        step()
+        sync()
+        first_build_ms = (time.perf_counter() - t1) * 1e3
     sz = built.sizes()
     n_k_rank = reads_per_rank * (L - k + 1)  # k-mer instances this rank's reads hold
     assert sharded or sz["n_kmer_instances"] == n_k_rank, (sz, n_k_rank)
@@ -333,7 +385,8 @@ def main():
     achieved_step = n_k_rank * b_alg(L, k) / (dt / args.steps) / 1e9
 
     if rank == 0:
-        kernel = "k_sk_count" if k <= 31 else "k_wsk_count"
+        # 32-bit stamps (a single GPU below 2 GiB of reads): k_sk_count2; 64-bit stamps (shards): k_sk_count; k > 31: k_wsk_count
+        kernel = ("k_sk_count2" if not sharded and reads_per_rank * L < (1 << 31) else "k_sk_count") if k <= 31 else "k_wsk_count"
         phases = {key: round(sum(p[key] for p in ms_phases) / len(ms_phases), 3)
                   for key in ("ms_extract", "ms_partition", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total")}
         traffic, traffic_src = (pmc_traffic(kernel) if (not sharded and reads_per_rank == 10_000_000 and args.err == 0.01 and
@@ -341,7 +394,7 @@ def main():
         out = {
             "metric": f"k-mers/s hashed+graph-built at k={k}", "value": value, "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": dt / args.steps * 1e3, "first_build_ms": first_build_ms, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "k": k, "reads_per_gpu": reads_per_rank, "reads_total": n_total, "read_len": L,
                        "err_rate": args.err,

@@ -123,6 +123,7 @@ struct dbg {
     int phase_limit = 0;     // ablation of k_sk_count (timing only; the build then fails on purpose)
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
     int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
+    int count_kernel_u64 = 1; // option "count_kernel_u64": the same choice for 64-bit stamps (measured: 1)
     int count_kernel = 2;    // k <= 31, 4096 slots: 2 = k_sk_count2 (successor hints, 16-bit counters; falls back to 1 on counter overflow), 1 = k_sk_count
 
     // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
@@ -2109,6 +2110,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
     if (n == "count_kernel" && (value == 1 || value == 2)) { h->count_kernel = (int)value; return DBG_OK; }
+    if (n == "count_kernel_u64" && (value == 1 || value == 2)) { h->count_kernel_u64 = (int)value; return DBG_OK; }
     if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -3537,7 +3539,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     const uint64_t own_cnt = n_buckets >> shard_bits, own_lo = (uint64_t)my_shard * own_cnt;
     CHK(buf_ensure(h, h->ar_dir, (own_cnt + (range_cap - n_buckets)) * (CAP / 64) * sizeof(SkDirEnt)));
     SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
-    bool use_count2 = CAP == 4096 && h->count_kernel == 2 && !h->phase_limit;
+    // k_sk_count2 for 32-bit stamps; with 64-bit stamps (sharded builds, reads of 2 GiB and more) its LDS leaves room for
+    // 320 staged records where the first kernel stages 640, and it loses: 15.4 vs 13.9 ms on a 10 M-read shard
+    bool use_count2 = CAP == 4096 && h->count_kernel == 2 && !h->phase_limit && (sizeof(ST) == 4 || h->count_kernel_u64 == 2);
     int extra_attempts = 0;
     for (int attempt = 0; attempt < 3 + extra_attempts; ++attempt) {
         CHK(ensure_node_arrays());
@@ -4869,7 +4873,7 @@ static int part_compact(dbg *sub, uint64_t n_dir_entries) {
 static void multipass_free(dbg *h) {
     MultiPass *mp = (MultiPass *)h->multipass;
     if (!mp) return;
-    for (auto *o : mp->col_owner) if (o) (void)hipFree(o);
+    for (auto *o : mp->col_owner) if (o) (void)hipFreeAsync(o, h->stream);
     for (auto *o : mp->pflags) if (o) (void)hipFree(o);
     for (dbg *sub : mp->part) if (sub) dbg_destroy(sub);
     delete mp;
@@ -4938,9 +4942,11 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
         sub->borrowed_stream = true;
         sub->wide_owner = true;
         sub->bucket_bits = h->bucket_bits;
+        sub->count_kernel = h->count_kernel;
+        sub->count_kernel_u64 = h->count_kernel_u64;
         sub->target_distinct = h->target_distinct;
         sub->est_scale_pct = h->est_scale_pct;
-        HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));
+        HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));  // (small: the allocator answers from a cached block)
         sub->k = k;
         uint64_t n_rec_p = 0;
         for (int r = 0; r < n_senders; ++r) {
@@ -4979,14 +4985,14 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
             rc = sk_count_from_segments<ST, 4096, STI>(sub, k, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w,
                                                        in_w0, in_w1, (const ST *)nullptr, pw0, pw1, pst, 0, shard_bits, v_first + p, &pre);
         if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
-        if (n_rec_p) {
+        if (n_rec_p && n_passes > 1) {  // parts parked side by side: cut to size (one part: the estimate's slack may stay)
             const uint64_t own_cnt = sub->sk_n_buckets >> shard_bits;
             rc = part_compact(sub, (own_cnt + (sub->sk_n_ranges - sub->sk_n_buckets)) * (4096 / 64));
             if (rc != DBG_OK) { h->err = "pass " + std::to_string(p) + ": " + sub->err; return rc; }
         }
         mp->base[p + 1] = mp->base[p] + sub->n_nodes;
         if (sub->n_edges) {
-            HIPCHK(h, hipMalloc((void **)&mp->col_owner[p], sub->n_edges));
+            HIPCHK(h, hipMallocAsync((void **)&mp->col_owner[p], sub->n_edges, h->stream));
             HIPCHK(h, hipMemsetAsync(mp->col_owner[p], v_first + p, sub->n_edges, h->stream));
         }
         ms_count += sub->stats.ms_count; ms_part += sub->stats.ms_partition; ms_succ += sub->stats.ms_succ;
@@ -5146,8 +5152,11 @@ extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_s
     if (h->bucket_bits && h->bucket_bits < 9) { h->err = "multi-pass builds split by 9 bits first: bucket_bits must be 0 or >= 9"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
     free_build(h);
+    // One pass: a plain sharded build with (owner byte, 32-bit local id) successors.  Such builds repeat on one handle
+    // (bench.py), and the freed blocks of the last one are exactly what this one asks for: they stay in the pool.
+    // Several passes are the memory-tight case: everything goes back to the device first.
     h->arena_freed = true;
-    pool_trim(h);
+    if (n_passes > 1) pool_trim(h);
     h->stats = dbg_stats_t{};
     const int own_groups = 512 / n_shards;
     std::vector<uint64_t> off(n_shards), add(n_shards);
@@ -5249,7 +5258,7 @@ extern "C" int dbg_multipass_finish(dbg_t *h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (dbg *sub : mp->part) { buf_free(sub, sub->ar_shard[0]); buf_free(sub, sub->ar_shard[3]); }
     h->arena_freed = true;
-    pool_trim(h);
+    if (mp->n_passes > 1) pool_trim(h);
     if (sc0 & 256) { h->err = "a successor owned by another rank came back unresolved"; return DBG_E_HIP; }
     return DBG_OK;
 }

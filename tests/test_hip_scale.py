@@ -330,6 +330,8 @@ def test_bench_line_contract_at_a_small_size(tmp_path):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["same_graph_as_gpu"] is True and c["value"] > 0
     assert d["extras"]["fasta_ingest"]["same_reads_and_graph"] is True
+    assert d["extras"]["traversal_in_parts_sizes"]["same_as_single_graph"] is True
+    assert d["first_build_ms"] > 0 and c["one_thread"]["value"] > 0
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
