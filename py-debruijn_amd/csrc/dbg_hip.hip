@@ -5559,20 +5559,32 @@ __device__ inline uint32_t pf_kept_col(uint32_t flags_present, uint32_t pf, uint
     return row + __popc(pres & ((1u << b) - 1u));
 }
 
-// pass 0: counts per owner; pass 1: the targets, grouped by owner (cursor[v] starts at the group's offset)
+// pass 0: counts per owner; pass 1: the targets, grouped by owner (cursor[v] starts at the group's offset).  A workgroup
+// counts its edges per owner in LDS and takes ONE global atomic per owner it met: per-edge atomics on 64 cursors are
+// same-address atomics, ~12 ns each and serialised chip-wide (0.35 s per pass for the 2.9e7 cross edges of a 10 M-read graph).
 __global__ __launch_bounds__(256) void k_part_cross(uint64_t n, int me, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ pflags,
                                                     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                                                     const uint8_t *__restrict__ col_owner, unsigned long long *cursor /* [64] */,
                                                     uint32_t *targets) {
+    __shared__ uint32_t bin[64];
+    __shared__ unsigned long long base[64];
+    if (threadIdx.x < 64) bin[threadIdx.x] = 0;
+    __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t pf = pflags[i];
-    if (!pf_chain(pf)) return;
-    const uint32_t e = pf_kept_col(flags[i], pf, rowptr[i]);
-    const int ow = col_owner[e];
-    if (ow == me) return;
-    const unsigned long long at = atomicAdd(&cursor[ow & 63], 1ull);
-    if (targets) targets[at] = col[e];
+    int ow = -1;
+    uint32_t tgt = 0, rank = 0;
+    if (i < n) {
+        const uint32_t pf = pflags[i];
+        if (pf_chain(pf)) {
+            const uint32_t e = pf_kept_col(flags[i], pf, rowptr[i]);
+            const int o = col_owner[e];
+            if (o != me) { ow = o & 63; tgt = col[e]; rank = atomicAdd(&bin[ow], 1u); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && bin[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)bin[threadIdx.x]);
+    __syncthreads();
+    if (ow >= 0 && targets) targets[base[ow] + rank] = tgt;
 }
 
 // Kept edges of this part's chain nodes that leave the part: the local ids of their targets IN the target's part, grouped by

@@ -214,12 +214,13 @@ class PartTraversal:
         mine = self._cat(rows)
         mine["dist"] = torch.cat(dist_of)
         cols = list(mine.keys())
-        got = self.net.gather_all(*[mine[c].reshape(-1) for c in cols], widths=[4 if c in ("counts", "succ") else 1 for c in cols])
-        m = {c: t.cpu().numpy() for c, t in zip(cols, got)}
-        n = m["gid"].size
-        m["counts"], m["succ"] = m["counts"].reshape(n, 4), m["succ"].reshape(n, 4)
-        o = np.argsort(m["gid"], kind="stable")
-        m = {c: a[o] for c, a in m.items()}
+        got = dict(zip(cols, self.net.gather_all(*[mine[c].reshape(-1) for c in cols], widths=[4 if c in ("counts", "succ") else 1 for c in cols])))
+        n = got["gid"].numel()
+        got["counts"], got["succ"] = got["counts"].reshape(n, 4), got["succ"].reshape(n, 4)
+        o = torch.argsort(got["gid"])                      # sorted by global id on the device: the join below is a binary search
+        got = {c: t[o] for c, t in got.items()}
+        pos_t = torch.searchsorted(got["gid"], torch.where(got["succ"] >= 0, got["succ"], torch.zeros_like(got["succ"]))).clamp_(max=max(n - 1, 0))
+        m = {c: t.cpu().numpy() for c, t in got.items()}
         assert n == 0 or np.all(m["gid"][1:] != m["gid"][:-1]), "a node was collected twice"
         pulled_gid = np.empty(0, dtype=np.int64)
         ranks = np.empty(0, dtype=np.uint64)
@@ -227,8 +228,7 @@ class PartTraversal:
             keep = ((m["pflags"][:, None] >> (F_KEEP_SHIFT + np.arange(4)[None, :])) & 1).astype(bool)
             full = (m["dist"] < TIP_REACH)[:, None]
             counts = np.where(keep & full, m["counts"], 0).astype(np.uint32)   # pruned edges and the outermost ring: no successors
-            pos = np.searchsorted(m["gid"], np.where(m["succ"] >= 0, m["succ"], 0))
-            pos = np.minimum(pos, n - 1)
+            pos = pos_t.cpu().numpy()
             found = (m["gid"][pos] == m["succ"]) & (counts != 0)
             assert np.all(found == (counts != 0)), "a kept successor inside the neighbourhood was not collected"
             succ = np.where(found, pos, NO_NODE).astype(np.uint32)
@@ -321,19 +321,16 @@ class PartTraversal:
         dead = e["kind"] == K_CYCLE
         done = ~go_on
         jump = torch.where(go_on, j, torch.arange(n, device=e["gid"].device))
+        # pointer jumping over the entries that are not resolved yet (the list shrinks fast: most chains are a few segments);
+        # a round reads the old values of its targets before anything is written
+        act = torch.nonzero(~done).reshape(-1)
         for _ in range(max(1, math.ceil(math.log2(n + 1))) + 1):
-            if bool(done.all()):
+            if act.numel() == 0:
                 break
-            act = ~done
             tj = jump[act]
-            hops[act] = hops[act] + hops[tj]
-            score[act] = score[act] + score[tj]
-            dead[act] = dead[act] | dead[tj]
-            done_new = done.clone()
-            done_new[act] = done[tj]
-            jump_new = jump.clone()
-            jump_new[act] = jump[tj]
-            done, jump = done_new, jump_new
+            h2, s2, d2, dn, j2 = hops[act] + hops[tj], score[act] + score[tj], dead[act] | dead[tj], done[tj], jump[tj]
+            hops[act], score[act], dead[act], done[act], jump[act] = h2, s2, d2, dn, j2
+            act = act[~dn]
         emit = (e["start"] == 1) & (e["kind"] != K_PULLED) & done & ~dead   # not done after log2(n) doublings: a cycle across parts
         st = e["stamp"][emit].cpu().numpy().astype(np.uint64)
         ln = (hops[emit] + self.k).cpu().numpy()
