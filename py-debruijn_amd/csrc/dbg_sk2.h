@@ -26,6 +26,9 @@
 #pragma once
 #include "dbg_sk.h"
 
+#ifndef DBG_SK2_UNROLL
+#define DBG_SK2_UNROLL 8   // probe steps per unrolled body of the insert loop (4: 12.13, 8: 12.06, 16: 12.22 ms)
+#endif
 #ifndef DBG_SK2_PROBE
 #define DBG_SK2_PROBE 0   // 0: per-lane exit, unrolled 16-fold; 1: wave-uniform probe loop with a ballot exit (measured: 14.3 vs 12.4 ms)
 #endif
@@ -335,7 +338,7 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                     }
 #else
                     if (act) {
-#pragma unroll 16
+#pragma unroll DBG_SK2_UNROLL
                         for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
                             unsigned long long cur = s.keys[slot];
                             if (cur == EMPTY_KEY) {

@@ -81,3 +81,24 @@ def test_key_codec_roundtrip():
     for ch in b"EVQLV":
         key = (key << 5) | alpha.index(ch)
     assert _dbg.decode_keys(np.array([key], dtype=np.uint64), 5, alpha, 5) == ["EVQLV"]
+
+
+@pytest.mark.gpu
+def test_hidden_gpu_fails_loudly_on_a_gpu_box():
+    """The GPU-present twin of test_no_gpu_fails_loudly: on a box that HAS a GPU the library works in this process, and a
+    child process that cannot see the device (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES hide it) must get DbgError from the
+    product path -- no CPU fallback takes over."""
+    import sys
+    import _dbg
+    _dbg.Graph().close()  # this process sees the GPU
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import _dbg, debruijn\n"
+            "try:\n"
+            "    debruijn.construct_graph(['ACGTACGT'], 3)\n"
+            "except _dbg.DbgError as e:\n"
+            "    print('DbgError', e); sys.exit(42)\n"
+            "sys.exit(0)\n") % PKG
+    env = dict(os.environ, ROCR_VISIBLE_DEVICES="-1", HIP_VISIBLE_DEVICES="-1", CUDA_VISIBLE_DEVICES="-1")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 42, (p.returncode, p.stdout[-500:], p.stderr[-500:])
+    assert "no usable MI355X" in p.stdout or "dbg error" in p.stdout

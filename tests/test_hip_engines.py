@@ -317,3 +317,46 @@ def test_every_window_width_both_extraction_kernels(k):
         n_rec.append(g.stats()["n_records"])
         g.close()
     assert n_rec[0] == n_rec[1] and n_rec[0] > 0  # the same super-k-mers either way
+
+
+@pytest.mark.parametrize("k", [21, 31])
+def test_count_kernel_16_bit_counters_fall_back_to_32_bit(k):
+    """k_sk_count2 keeps 16-bit edge counters beside the successor hints: an edge seen more than 65 535 times must repeat
+    the build with k_sk_count (32-bit counters) -- same result, two launches of the dominant kernel."""
+    read = synth.reads_ascii(4, 200, 1, 60, 0.0)[0]
+    rng = np.random.default_rng(1)
+    other = synth.reads_ascii(5, 3000, 300, 60, 0.01)
+    reads = np.concatenate([np.tile(read, (70000, 1)), other])
+    reads = reads[rng.permutation(reads.shape[0])]
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, 60, dtype=np.uint64), k)
+    assert int(want["counts"].max()) >= 70000
+    g = build(reads, k)
+    assert g.stats()["count_launches"] == 2
+    keys, stamps, counts, flags, succ, keys_raw = table(g, k)
+    assert np.array_equal(keys, want["keys"]) and np.array_equal(stamps, want["stamps"]) and np.array_equal(counts, want["counts"])
+    _, _, counts_raw, _ = g.export_nodes()
+    check_succ(keys_raw, counts_raw, succ, k)
+    g1 = build(reads, k, count_kernel=1)   # the first kernel needs one launch
+    assert g1.stats()["count_launches"] == 1 and np.array_equal(table(g1, k)[2], want["counts"])
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(bucket_bits=9), dict(bucket_bits=3), dict(bucket_bits=14)])
+def test_both_count_kernels_write_the_same_graph(opts):
+    """k_sk_count (lookups after the insert) and k_sk_count2 (successor hints, pending list) on the same reads and geometry:
+    the same nodes, counts, flags and successors (compared in dict order) and the same cross-bucket query count.  bucket_bits = 3: eight buckets, every table overflows into hash
+    sub-ranges, so in-record successors land in other ranges (pending lookups that miss, queries beyond the LDS staging)."""
+    reads = synth.reads_ascii(17, 80000, 8000, 100, 0.01)
+    out = []
+    for ck in (1, 2):
+        g = build(reads, 31, count_kernel=ck, **opts)
+        keys, stamps, counts, flags = g.export_nodes()
+        succ = g.export_succ()
+        rp, col, cnt = g.export_csr()
+        assert np.array_equal(col, succ[counts != 0]) and np.array_equal(cnt, counts[counts != 0])
+        o = np.argsort(stamps, kind="stable")     # node ids follow the order in which buckets reserve them: compare in dict order
+        succ_keys = np.where(succ == _dbg.NO_NODE, np.uint64(0xFFFFFFFFFFFFFFFF), keys[np.minimum(succ, keys.size - 1)])
+        out.append((keys[o], stamps[o], counts[o], flags[o], succ_keys[o], g.stats()["n_queries"], g.stats()["n_buckets"]))
+    a, b = out
+    for x, y in zip(a[:5], b[:5]):
+        assert np.array_equal(x, y)
+    assert a[5] == b[5] and a[6] == b[6]
