@@ -218,6 +218,10 @@ int dbg_part_cross_targets(dbg_t *h, int part, uint64_t *counts, void *d_targets
  * sum of their counts, last u32[n] = node the segment ended at (kind 2: the leaving edge's count). */
 int dbg_part_segments(dbg_t *h, int part, const void *d_entries, uint64_t n, void *d_kind, void *d_next_owner, void *d_next_local,
                       void *d_hops, void *d_score, void *d_last);
+/* the characters n segments contribute to their contigs: for entry j, at [d_off[j], d_off[j + 1]) of d_chars, the last base of
+ * the entry node and of each of the hops[j] nodes the segment appends (d_off[j + 1] - d_off[j] = 1 + hops[j], or 0 to skip);
+ * device pointers, d_off uint64[n + 1] */
+int dbg_part_segment_text(dbg_t *h, int part, const void *d_entries, uint64_t n, const void *d_off, void *d_chars, uint64_t capacity);
 int dbg_part_pflags(dbg_t *h, int part, const void **d_pflags); /* device pointer of the flags, NULL before dbg_part_prune */
 /* pull_out_read (debruijn.py:274-278) against an explicit list of k-mers (the branch k-mers of all parts and ranks): host
  * arrays in and out; read_flags[n_reads] = 1 where the read holds one; first_seen[n_keys][4] (may be NULL) = smallest byte

@@ -35,7 +35,7 @@ SYMBOLS = (
     "dbg_shard_build_multipass", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
     "dbg_export_marked", "dbg_part_keys_hi", "dbg_take_reads",
     "dbg_part_prune", "dbg_part_select", "dbg_part_gather", "dbg_part_mark", "dbg_part_clear", "dbg_part_cross_targets",
-    "dbg_part_segments", "dbg_part_pflags", "dbg_scan_reads_for_keys", "dbg_set_orders",
+    "dbg_part_segments", "dbg_part_pflags", "dbg_scan_reads_for_keys", "dbg_set_orders", "dbg_part_segment_text",
 )
 
 
@@ -154,6 +154,7 @@ def load_library():
         "dbg_part_cross_targets": (C.c_int, [H, C.c_int, u64p, vp, C.c_uint64]),
         "dbg_part_segments": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp, vp, vp, vp, vp, vp]),
         "dbg_part_pflags": (C.c_int, [H, C.c_int, C.POINTER(vp)]),
+        "dbg_part_segment_text": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64]),
         "dbg_scan_reads_for_keys": (C.c_int, [H, C.c_int, vp, vp, C.c_uint64, vp, vp]),
         "dbg_set_orders": (C.c_int, [H, vp]),
         "dbg_shard_apply": (C.c_int, [H, vp]),
@@ -608,6 +609,16 @@ class Graph:
             self._chk(self._lib.dbg_part_segments(self._h, int(part), C.c_void_p(entries.data_ptr()), n,
                                                   *[C.c_void_p(out[w].data_ptr()) for w in ("kind", "next_owner", "next_local", "hops", "score", "last")]))
         return out
+
+    def part_segment_text(self, part, entries, off):
+        """characters of the segments at `entries` (int32 device tensor); off: int64 device tensor [n + 1] -> uint8 device tensor"""
+        import torch
+        total = int(off[-1].item()) if off.numel() else 0
+        chars = torch.empty(total, dtype=torch.uint8, device=self._dev())
+        if entries.numel() and total:
+            self._chk(self._lib.dbg_part_segment_text(self._h, int(part), C.c_void_p(entries.data_ptr()), entries.numel(),
+                                                      C.c_void_p(off.data_ptr()), C.c_void_p(chars.data_ptr()), total))
+        return chars
 
     def scan_reads_for_keys(self, k, keys, keys_hi=None, first_seen=True):
         """-> (read_flags uint8[n_reads], first_seen uint64[n_keys, 4] or None); numpy in and out (dbg_scan_reads_for_keys)."""

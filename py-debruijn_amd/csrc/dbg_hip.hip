@@ -5677,6 +5677,53 @@ extern "C" int dbg_part_segments(dbg_t *h, int part, const void *d_entries, uint
     return DBG_OK;
 }
 
+// the characters one segment contributes to a contig: the last base of its entry node, then of every node it appends
+__global__ __launch_bounds__(256) void k_part_segment_text(const uint32_t *__restrict__ entries, uint64_t n, uint64_t n_nodes, int me,
+                                                          const uint64_t *__restrict__ keys, const uint8_t *__restrict__ flags,
+                                                          const uint8_t *__restrict__ pflags, const uint32_t *__restrict__ rowptr,
+                                                          const uint32_t *__restrict__ col, const uint8_t *__restrict__ col_owner,
+                                                          const uint64_t *__restrict__ off, char *out, uint64_t cap,
+                                                          unsigned long long *err) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    uint32_t cur = entries[j];
+    uint64_t at = off[j];
+    const uint64_t end = off[j + 1];
+    if (cur >= n_nodes || end > cap) { atomicOr(err, 1ull); return; }
+    if (at < end) out[at++] = code_to_ascii((uint32_t)(keys[cur] & 3u));
+    while (at < end) {   // the caller sized the piece from dbg_part_segments' hops: the same walk, inside the part
+        const uint32_t pf = pflags[cur];
+        if (!pf_chain(pf)) { atomicOr(err, 2ull); return; }
+        const uint32_t e = pf_kept_col(flags[cur], pf, rowptr[cur]);
+        if ((int)col_owner[e] != me) { atomicOr(err, 2ull); return; }
+        cur = col[e];
+        out[at++] = code_to_ascii((uint32_t)(keys[cur] & 3u));
+    }
+}
+
+// Text of n segments (dbg_part_segments): for entry j the characters at [d_off[j], d_off[j + 1]) of d_chars -- the last base
+// of the entry node followed by the last base of each of the `hops` nodes the segment appends, so d_off[j + 1] - d_off[j] must
+// be 1 + hops[j] (or 0 to skip the segment).  All pointers are device pointers; d_off is uint64[n + 1].
+extern "C" int dbg_part_segment_text(dbg_t *h, int part, const void *d_entries, uint64_t n, const void *d_off, void *d_chars,
+                                     uint64_t capacity) {
+    MultiPass *mp; dbg *sub;
+    CHK(part_ctx(h, part, &mp, &sub));
+    if (!n) return DBG_OK;
+    if (!d_entries || !d_off || !d_chars) return DBG_E_ARG;
+    if (!sub->n_nodes || !mp->pflags[part]) { h->err = "dbg_part_segment_text: dbg_part_prune must run first"; return DBG_E_ARG; }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_scalars + 8, 0, 8, h->stream));
+    hipLaunchKernelGGL(k_part_segment_text, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const uint32_t *)d_entries, n, sub->n_nodes,
+                       mp->v_first + part, sub->d_keys, sub->d_flags, mp->pflags[part], sub->d_rowptr32, sub->d_col, mp->col_owner[part],
+                       (const uint64_t *)d_off, (char *)d_chars, capacity, (unsigned long long *)(h->d_scalars + 8));
+    HIPCHK(h, hipGetLastError());
+    uint64_t e = 0;
+    HIPCHK(h, hipMemcpyAsync(&e, h->d_scalars + 8, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (e) { h->err = "dbg_part_segment_text: an entry, a piece size or the capacity does not fit the segments of this part"; return DBG_E_ARG; }
+    return DBG_OK;
+}
+
 __global__ __launch_bounds__(256) void k_part_clear(uint64_t n_words, uint32_t keep4, uint32_t *pflags_words) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) pflags_words[i] &= keep4;

@@ -271,10 +271,11 @@ class PartTraversal:
         return self.pulled
 
     # ---- a11 + a12 + a13, non-final mode
-    def walk_index(self):
+    def walk_index(self, keep_skeleton=False):
         """output_contigs (debruijn.py:326-347) with the branch list of construct_graph: the contig index in dict order of the
         starts -- dict(stamp uint64, length int64, score int64) numpy arrays.  A start whose chain runs into a cycle emits
-        nothing (debruijn.py:289-290), nor does a start that was pulled."""
+        nothing (debruijn.py:289-290), nor does a start that was pulled.  keep_skeleton: keep the segment skeleton on the
+        host (26 bytes per entry) so that ``contig_texts`` can spell contigs afterwards."""
         g, P, dev = self.g, self.P, self.device
         # entries: the starts (indegree 0) and every node a chain of another part continues at
         sends = []
@@ -316,6 +317,9 @@ class PartTraversal:
         j = torch.searchsorted(e["gid"], torch.where(remote, e["next"], e["gid"])).clamp_(max=n - 1)
         assert bool((e["gid"][j] == torch.where(remote, e["next"], e["gid"])).all()), "a chain continues at a node that is no entry"
         go_on = remote & (e["kind"][j] != K_PULLED)     # entering a pulled node ends the path at the previous one
+        if keep_skeleton:
+            self.skeleton = {"gid": e["gid"].cpu().numpy(), "next": j.cpu().numpy(), "go_on": go_on.cpu().numpy(),
+                             "hops": e["hops"].cpu().numpy()}
         hops = e["hops"] + go_on.to(torch.int64)
         score = e["score"] + torch.where(go_on, e["exit"], torch.zeros_like(e["exit"]))
         dead = e["kind"] == K_CYCLE
@@ -336,7 +340,124 @@ class PartTraversal:
         ln = (hops[emit] + self.k).cpu().numpy()
         sc = score[emit].cpu().numpy()
         o2 = np.argsort(st, kind="stable")
+        if keep_skeleton:
+            self.skeleton["emit"] = torch.nonzero(emit).reshape(-1).cpu().numpy()[o2]   # skeleton index of contig i's start
         return {"stamp": st[o2], "length": ln[o2], "score": sc[o2]}
+
+    def contig_texts(self, which):
+        """The text of the contigs ``which`` (positions in the index ``walk_index(keep_skeleton=True)`` returned) -- every rank
+        calls it with the same list and gets the same strings.  A contig is its start k-mer followed by the last base of every
+        node its chain appends (debruijn.py:296-299); every part spells the segments it holds (dbg_part_segment_text)."""
+        sk, g, dev = self.skeleton, self.g, self.device
+        which = [int(c) for c in which]
+        seg, owner_of_seg, first = [], [], []
+        for c in which:
+            i = int(sk["emit"][c])
+            first.append(len(seg))
+            seg.append(i)
+            while sk["go_on"][i]:
+                i = int(sk["next"][i])
+                seg.append(i)
+        first.append(len(seg))
+        seg = np.asarray(seg, dtype=np.int64)
+        gid = sk["gid"][seg] if seg.size else np.empty(0, dtype=np.int64)
+        v = gid >> 32
+        plen = 1 + sk["hops"][seg] if seg.size else np.empty(0, dtype=np.int64)
+        # my pieces, in segment order; then everybody's
+        pos_l, bytes_l = [], []
+        for p in range(self.P):
+            mine = np.nonzero(v == self._v(p))[0]
+            if not mine.size:
+                continue
+            ent = torch.from_numpy((gid[mine] & 0xFFFFFFFF).astype(np.uint32).view(np.int32).copy()).to(dev)
+            off = torch.zeros(mine.size + 1, dtype=torch.int64, device=dev)
+            off[1:] = torch.cumsum(torch.from_numpy(plen[mine]).to(dev), 0)
+            bytes_l.append(g.part_segment_text(p, ent, off))
+            pos_l.append(torch.from_numpy(mine).to(dev))
+        pos = torch.cat(pos_l) if pos_l else torch.empty(0, dtype=torch.int64, device=dev)
+        byts = torch.cat(bytes_l) if bytes_l else torch.empty(0, dtype=torch.uint8, device=dev)
+        # the start k-mers
+        starts = np.asarray([int(sk["emit"][c]) for c in which], dtype=np.int64)
+        sg = sk["gid"][starts] if starts.size else np.empty(0, dtype=np.int64)
+        kl, kh, kg = [], [], []
+        for p in range(self.P):
+            mine = np.nonzero((sg >> 32) == self._v(p))[0]
+            if mine.size:
+                ids = torch.from_numpy((sg[mine] & 0xFFFFFFFF).astype(np.uint32).view(np.int32).copy()).to(dev)
+                r = g.part_gather(p, ids, what=("keys", "keys_hi"))
+                kl.append(r["keys"]); kh.append(r["keys_hi"]); kg.append(torch.from_numpy(sg[mine]).to(dev))
+        z = torch.empty(0, dtype=torch.int64, device=dev)
+        kl, kh, kg = (torch.cat(x) if x else z for x in (kl, kh, kg))
+        if self.world > 1:
+            n_mine = pos.numel()
+            sizes = [m[0] for m in self.net.all_ints([n_mine])]
+            (pos,) = self.net.gather_all(pos)
+            # the bytes: variable-length rows, gathered as one flat column of known per-rank sizes
+            nb = [m[0] for m in self.net.all_ints([byts.numel()])]
+            byts = multi_gpu.alltoallv(self.net.dist, byts.repeat(self.world), [byts.numel()] * self.world, nb)
+            kl, kh, kg = self.net.gather_all(kl, kh, kg)
+            del sizes
+        pos, byts = pos.cpu().numpy(), byts.cpu().numpy()
+        # pieces arrive grouped by rank and part, each group in ascending segment position: place them by position
+        lens = plen[pos]
+        src_off = np.concatenate([[0], np.cumsum(lens)])
+        dst_off = np.concatenate([[0], np.cumsum(plen)])
+        flat = np.empty(int(dst_off[-1]), dtype=np.uint8)
+        for q, a in zip(pos.tolist(), range(pos.size)):
+            flat[dst_off[q]:dst_off[q + 1]] = byts[src_off[a]:src_off[a + 1]]
+        kmers = dict(zip(kg.cpu().numpy().tolist(), _dbg.decode_keys(kl.cpu().numpy().astype(np.uint64), self.k,
+                                                                        keys_hi=kh.cpu().numpy().astype(np.uint64))))
+        out = []
+        for ci, c in enumerate(which):
+            a, b = first[ci], first[ci + 1]
+            body = flat[dst_off[a] + 1:dst_off[b]].tobytes().decode("ascii")   # the start segment's first character is the start's own last base
+            # drop the entry character of no later segment: entering a node appends its last base
+            out.append(kmers[int(sg[ci])] + body)
+        return out
+
+
+class PartContigs:
+    """The contigs of a graph in parts, in the reference's order (dict order of the starts): ``lengths``, ``scores`` (getScore,
+    II_assembleFromReads.py:14-18), ``start_stamps``; ``texts(indices)`` spells any of them (collective: every rank asks for
+    the same ones).  At scale the contigs overlap massively -- 2e12 characters for 10 M reads -- so the text is on demand."""
+
+    def __init__(self, traversal, index):
+        self._t = traversal
+        self.start_stamps, self.lengths, self.scores = index["stamp"], index["length"], index["score"]
+
+    def __len__(self):
+        return int(self.start_stamps.size)
+
+    def texts(self, indices):
+        return self._t.contig_texts(indices)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.texts(range(*i.indices(len(self))))
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self.texts([i])[0]
+
+
+def construct_graph(g, k, threshold=3, dist=None):
+    """construct_graph (debruijn.py:206-285) after a build in parts (``g.build_multipass`` or, with ``dist``,
+    ``multi_gpu.sharded_build_multipass``), every rank calling it: -> (traversal, pull_out_read_flags, branch_kmer,
+    already_pull_out) with the reference's lists as str (dict order / append order; the same on every rank) and the
+    pull-out reads as uint8 flags over THIS rank's reads (the reference's list is the flagged reads of rank 0, 1, ... in order)."""
+    t = PartTraversal(g, k, dist)
+    b = t.prune(threshold)
+    flags = t.pull_out_reads()
+    p = t.remove_tips()
+    branch_kmer = _dbg.decode_keys(b["keys"].astype(np.uint64), t.k, keys_hi=b["keys_hi"].astype(np.uint64))
+    already_pull_out = _dbg.decode_keys(p["keys"], t.k, keys_hi=p["keys_hi"])
+    return t, flags, branch_kmer, already_pull_out
+
+
+def output_contigs(traversal):
+    """output_contigs (debruijn.py:326-347) for the branch list ``construct_graph`` above found (the non-final walk)."""
+    return PartContigs(traversal, traversal.walk_index(keep_skeleton=True))
 
 
 def traverse(g, k, threshold, dist=None):

@@ -269,3 +269,48 @@ def test_traversal_of_more_than_two_to_the_32_nodes():
         if e:
             assert by_stamp[int(s)] == (int(l), int(c))
     g.close()
+
+
+@pytest.mark.parametrize("k,n_passes,ranks", [(21, 4, 1), (63, 2, 1), (31, 1, 4)])
+def test_contig_texts_from_the_parts_equal_the_single_gpu_contigs(k, n_passes, ranks):
+    """Identical contig sets: every contig spelled from the parts (dbg_part_segment_text along the segment skeleton) equals
+    the text of the single-GPU walk, contig by contig in dict order of the starts."""
+    import contextlib
+    import io
+    import debruijn as prod
+    import inproc_dist
+    import multi_gpu
+    import part_traversal
+    n_reads, L = 4000, 120
+    per = n_reads // ranks
+    reads_of = lambda r: synth.reads_ascii(31, n_reads * L // 20, per, L, 0.01, first_read=r * per)  # noqa: E731
+    allr = np.concatenate([reads_of(r) for r in range(ranks)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        gg, pull, branch, pulled, ect = prod.construct_graph([row.tobytes().decode() for row in allr], k, threshold=2)
+        wc = prod.output_contigs(gg, branch, pulled)
+        want, want_scores = list(wc), prod.get_score_device(wc)
+    assert len(want) > 50
+
+    def one(dist, rank):
+        reads = reads_of(rank)
+        g = _dbg.Graph(device=0)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, L, dtype=np.uint64))
+        if dist is None:
+            g.build_multipass(k, n_passes)
+        else:
+            multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        t, flags, br, pu = part_traversal.construct_graph(g, k, 2, dist)      # the reference-shaped surface
+        ctg = part_traversal.output_contigs(t)
+        texts = ctg.texts(range(len(ctg)))
+        assert ctg[0] == texts[0] and ctg[-1] == texts[-1]
+        out = (ctg.lengths.tolist(), ctg.scores.tolist(), texts, br, pu, flags)
+        g.close()
+        return out
+
+    got = [one(None, 0)] if ranks == 1 else inproc_dist.run_ranks(ranks, one)
+    want_pull = [row.tobytes().decode() for row in allr[np.concatenate([r[5] for r in got]).astype(bool)]]
+    assert want_pull == list(pull)
+    for lengths, scores, texts, br, pu, _ in got:
+        assert texts == want and [len(x) for x in texts] == lengths
+        assert scores == want_scores
+        assert br == list(branch) and pu == list(pulled)
