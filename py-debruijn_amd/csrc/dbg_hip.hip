@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -142,6 +144,8 @@ struct dbg {
     SkGeom sk_geom{};            // hash -> bucket mapping of the last partitioned build (k_succ_resolve)
     void *shard_state = nullptr;  // ShardState (multi-GPU builds)
     void *multipass = nullptr;    // MultiPass (dbg_build_multipass): the parts of the graph, parked in HBM
+    bool dropping_parts = false;  // dbg_destroy / a build of another kind: nothing is parked
+    dbg *spare_part = nullptr;    // the part handle of the last ONE-pass sharded build: its arenas serve the next one (bench loops)
     bool wide_owner = false;      // a part of a multi-pass build: successor ids are (owner byte, 32-bit local id), not tagged
     bool borrowed_stream = false; // sub-handle of a multi-pass build: the stream belongs to the parent
     bool arena_freed = false;     // an arena buffer went back to the memory pool since the last trim
@@ -167,6 +171,7 @@ struct ShardState {
 };
 static ShardState &shard_of(dbg *h);
 static void multipass_free(dbg *h);
+static void drop_spare_part(dbg *h);
 
 // Arena buffers come from the device's stream-ordered memory pool (hipMallocAsync on the handle's stream) with the
 // pool told to keep what is freed: a hipMalloc / hipFree of several GB costs ~0.1 s each, and a multi-pass build
@@ -178,7 +183,13 @@ static int buf_ensure(dbg *h, dbg::Buf &b, uint64_t bytes) {
     if (b.p) { (void)hipFreeAsync(b.p, h->stream); h->arena_freed = true; }
     b.p = nullptr;
     b.bytes = 0;
+    static const bool trace = getenv("DBG_TRACE_ALLOC") != nullptr;  // diagnostic: arena allocations that take longer than 5 ms
+    const auto t_alloc = std::chrono::steady_clock::now();
     hipError_t e = hipMallocAsync(&b.p, bytes, h->stream);
+    if (trace) {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
+        if (ms > 5.0) fprintf(stderr, "[dbg] hipMallocAsync(%.3f GB) took %.1f ms (buffer %p of handle %p)\n", bytes / 1e9, ms, (void *)&b, (void *)h);
+    }
     if (e != hipSuccess) {
         // the pool may be holding freed blocks of the wrong sizes: give them back to the device and try once more
         (void)hipGetLastError();
@@ -1585,7 +1596,9 @@ extern "C" void dbg_destroy(dbg_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    h->dropping_parts = true;
     free_build(h);
+    if (h->spare_part) { dbg_destroy(h->spare_part); h->spare_part = nullptr; }
     free_reads(h);
     for (auto &lvl : h->ar_rec) for (auto &b : lvl) buf_free(h, b);
     for (auto &lvl : h->ar_q) for (auto &b : lvl) buf_free(h, b);
@@ -2226,7 +2239,10 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     if (k < 1 || k > 63) { h->err = "k must be in 1..63 (k-mers of at most two 64-bit words)"; return DBG_E_ARG; }
     if (!h->d_offsets) { h->err = "no reads set"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    h->dropping_parts = true;
     free_build(h);
+    h->dropping_parts = false;
+    drop_spare_part(h);
     h->k = k;
     h->stats = dbg_stats_t{};
     CHK(compute_alphabet(h));
@@ -4875,9 +4891,24 @@ static void multipass_free(dbg *h) {
     if (!mp) return;
     for (auto *o : mp->col_owner) if (o) (void)hipFreeAsync(o, h->stream);
     for (auto *o : mp->pflags) if (o) (void)hipFree(o);
-    for (dbg *sub : mp->part) if (sub) dbg_destroy(sub);
+    for (dbg *sub : mp->part) {
+        if (!sub) continue;
+        // A one-pass sharded build repeats on one handle (bench.py): its part handle is parked with its grow-only arenas,
+        // like the handle of a single-GPU build keeps its own.  (Freeing ~100 GB into the pool and asking for it again cost a
+        // 2 s hipMallocAsync per step at 40 M reads.)
+        if (mp->n_passes == 1 && mp->n_virtual <= 8 && !h->spare_part && !h->dropping_parts) { free_build(sub); h->spare_part = sub; }
+        else dbg_destroy(sub);
+    }
     delete mp;
     h->multipass = nullptr;
+}
+
+// the parked part handle of an earlier one-pass sharded build goes when the handle builds anything else
+static void drop_spare_part(dbg *h) {
+    if (!h->spare_part) return;
+    dbg_destroy(h->spare_part);
+    h->spare_part = nullptr;
+    h->arena_freed = true;
 }
 
 static int multipass_starts(dbg *h, uint64_t *total) {
@@ -4934,7 +4965,10 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
     uint64_t n_buckets = 0, n_queries = 0;
     std::vector<uint64_t> p_cnt((size_t)n_senders * bps), p_off(n_senders);
     for (int p = 0; p < n_passes; ++p) {
-        dbg *sub = new (std::nothrow) dbg();
+        dbg *sub = nullptr;
+        const bool reused = n_passes == 1 && h->spare_part;
+        if (reused) { sub = h->spare_part; h->spare_part = nullptr; }
+        else sub = new (std::nothrow) dbg();
         if (!sub) return DBG_E_NOMEM;
         mp->part[p] = sub;
         sub->device = h->device;
@@ -4946,7 +4980,7 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
         sub->count_kernel_u64 = h->count_kernel_u64;
         sub->target_distinct = h->target_distinct;
         sub->est_scale_pct = h->est_scale_pct;
-        HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));  // (small: the allocator answers from a cached block)
+        if (!sub->d_scalars) HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));
         sub->k = k;
         uint64_t n_rec_p = 0;
         for (int r = 0; r < n_senders; ++r) {
@@ -4995,6 +5029,7 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
             HIPCHK(h, hipMallocAsync((void **)&mp->col_owner[p], sub->n_edges, h->stream));
             HIPCHK(h, hipMemsetAsync(mp->col_owner[p], v_first + p, sub->n_edges, h->stream));
         }
+        (void)reused;
         ms_count += sub->stats.ms_count; ms_part += sub->stats.ms_partition; ms_succ += sub->stats.ms_succ;
         n_buckets += sub->stats.n_buckets >> shard_bits; n_queries += sub->stats.n_queries;
         h->stats.count_launches += sub->stats.count_launches;
@@ -5112,7 +5147,10 @@ extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     if (h->engine != 0) { h->err = "multi-pass builds use the super-k-mer engine"; return DBG_E_ARG; }
     if (h->bucket_bits && h->bucket_bits < 9) { h->err = "multi-pass builds split by 9 bits first: bucket_bits must be 0 or >= 9"; return DBG_E_ARG; }
     HIPCHK(h, hipSetDevice(h->device));
+    h->dropping_parts = true;
     free_build(h);
+    h->dropping_parts = false;
+    drop_spare_part(h);
     h->arena_freed = true;
     pool_trim(h);  // the parts of an earlier multi-pass build
     h->stats = dbg_stats_t{};
@@ -5156,7 +5194,7 @@ extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_s
     // (bench.py), and the freed blocks of the last one are exactly what this one asks for: they stay in the pool.
     // Several passes are the memory-tight case: everything goes back to the device first.
     h->arena_freed = true;
-    if (n_passes > 1) pool_trim(h);
+    if (n_passes > 1) { drop_spare_part(h); pool_trim(h); }
     h->stats = dbg_stats_t{};
     const int own_groups = 512 / n_shards;
     std::vector<uint64_t> off(n_shards), add(n_shards);
