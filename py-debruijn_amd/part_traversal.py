@@ -310,6 +310,8 @@ class PartTraversal:
         n = e["gid"].numel()
         if n == 0:
             z = np.empty(0, dtype=np.int64)
+            if keep_skeleton:
+                self.skeleton = {"gid": z, "next": z, "go_on": z.astype(bool), "hops": z, "emit": z}
             return {"stamp": z.astype(np.uint64), "length": z, "score": z}
         o = torch.argsort(e["gid"])
         e = {c: t[o] for c, t in e.items()}
@@ -350,6 +352,8 @@ class PartTraversal:
         node its chain appends (debruijn.py:296-299); every part spells the segments it holds (dbg_part_segment_text)."""
         sk, g, dev = self.skeleton, self.g, self.device
         which = [int(c) for c in which]
+        if not which:
+            return []
         seg, owner_of_seg, first = [], [], []
         for c in which:
             i = int(sk["emit"][c])
