@@ -5818,45 +5818,51 @@ __global__ __launch_bounds__(256) void k_scan_insert(const uint64_t *__restrict_
 }
 
 // every k-mer window of the reads (two words: any k <= 63) against the set; a hit marks its read and lowers the first
-// appearance of the edge (k-mer, next base) -- position of the k-mer in THIS handle's reads -- when the window has a successor
+// appearance of the edge (k-mer, next base) -- position of the k-mer in THIS handle's reads -- when the window has a successor.
+// A thread owns SCAN_SPAN consecutive positions: one binary search for its first read, then the window rolls base by base
+// (the set is small and almost every window misses on its first probe).
+constexpr int SCAN_SPAN = 32;
 __global__ __launch_bounds__(256) void k_scan_reads(const char *__restrict__ bases, uint64_t n_bytes, const uint64_t *__restrict__ offsets,
                                                     uint64_t n_reads, int k, const unsigned long long *__restrict__ tab_lo,
                                                     const unsigned long long *__restrict__ tab_hi, const uint32_t *__restrict__ tab_idx,
                                                     uint64_t cap_mask, uint8_t *read_flags, unsigned long long *first_seen) {
-    // one thread per read position; the k-mer is rebuilt from the bytes (the set is small and most windows miss on the
-    // first probe, so the pass is bound by reading the bases: k bytes per window out of L1)
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p + k > n_bytes) return;
-    // read of position p: last r with offsets[r] <= p
-    uint64_t rlo = 0, rhi = n_reads;
+    const uint64_t p0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * SCAN_SPAN;
+    if (p0 >= n_bytes) return;
+    uint64_t rlo = 0, rhi = n_reads;  // read of position p0: last r with offsets[r] <= p0
     while (rhi - rlo > 1) {
         const uint64_t mid = (rlo + rhi) >> 1;
-        if (offsets[mid] <= p) rlo = mid; else rhi = mid;
+        if (offsets[mid] <= p0) rlo = mid; else rhi = mid;
     }
-    const uint64_t r_end = offsets[rlo + 1];
-    if (p + k > r_end) return;  // the window crosses into the next read
+    uint64_t r = rlo, r_end = offsets[r + 1];
+    const unsigned long long lo_mask = k < 32 ? (1ull << (2 * k)) - 1 : ~0ull;
+    const unsigned long long hi_mask = k <= 32 ? 0ull : (1ull << (2 * k - 64)) - 1;
     unsigned long long lo = 0, hi = 0;
-    for (int q = 0; q < k; ++q) {
-        const uint32_t code = ((uint32_t)(uint8_t)bases[p + q] >> 1) & 3u;
-        hi = (hi << 2) | (lo >> 62);
-        lo = (lo << 2) | code;
-    }
-    if (k < 32) { lo &= (1ull << (2 * k)) - 1; hi = 0; }
-    else if (k == 32) hi = 0;
-    else hi &= (1ull << (2 * k - 64)) - 1;
-    uint64_t slot = scan_hash(lo, hi) & cap_mask;
-    for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
-        const uint32_t idx = tab_idx[slot];
-        if (idx == 0xFFFFFFFFu) return;
-        if (tab_lo[slot] == lo && tab_hi[slot] == hi) {
-            read_flags[rlo] = 1;
-            if (first_seen && p + k < r_end) {
-                const uint32_t nb = ((uint32_t)(uint8_t)bases[p + k] >> 1) & 3u;
-                atomicMin(&first_seen[(uint64_t)idx * 4 + nb], (unsigned long long)p);
+    int have = 0;  // bases of the current read in the window (the window ends at position p + k - 1)
+    const uint64_t p_end = min(p0 + SCAN_SPAN, n_bytes);
+    for (uint64_t q = p0; q < min(p_end + (uint64_t)k - 1, n_bytes); ++q) {  // q: the base that enters the window
+        while (q >= r_end && r + 1 < n_reads) { ++r; r_end = offsets[r + 1]; have = 0; }
+        if (q >= r_end) break;
+        const uint32_t code = ((uint32_t)(uint8_t)bases[q] >> 1) & 3u;
+        hi = ((hi << 2) | (lo >> 62)) & hi_mask;
+        lo = ((lo << 2) | code) & lo_mask;
+        if (++have < k) continue;
+        const uint64_t p = q + 1 - k;  // start of the window: inside this read by construction
+        if (p < p0) continue;          // (cannot happen: the window started at or after p0)
+        if (p >= p_end) break;
+        uint64_t slot = scan_hash(lo, hi) & cap_mask;
+        for (uint64_t probe = 0; probe <= cap_mask; ++probe) {
+            const uint32_t idx = tab_idx[slot];
+            if (idx == 0xFFFFFFFFu) break;
+            if (tab_lo[slot] == lo && tab_hi[slot] == hi) {
+                read_flags[r] = 1;
+                if (first_seen && q + 1 < r_end) {
+                    const uint32_t nb = ((uint32_t)(uint8_t)bases[q + 1] >> 1) & 3u;
+                    atomicMin(&first_seen[(uint64_t)idx * 4 + nb], (unsigned long long)p);
+                }
+                break;
             }
-            return;
+            slot = (slot + 1) & cap_mask;
         }
-        slot = (slot + 1) & cap_mask;
     }
 }
 
@@ -5895,7 +5901,7 @@ extern "C" int dbg_scan_reads_for_keys(dbg_t *h, int k, const uint64_t *keys, co
     if (e == hipSuccess) e = keys_hi ? hipMemcpyAsync(d_hi, keys_hi, n_keys * 8, hipMemcpyHostToDevice, h->stream) : hipMemsetAsync(d_hi, 0, n_keys * 8, h->stream);
     if (e != hipSuccess) { h->err = std::string("dbg_scan_reads_for_keys: ") + hipGetErrorString(e); return done(DBG_E_HIP); }
     hipLaunchKernelGGL(k_scan_insert, dim3(grid_for(n_keys, 256)), dim3(256), 0, h->stream, d_lo, d_hi, n_keys, t_lo, t_hi, t_idx, cap - 1);
-    hipLaunchKernelGGL(k_scan_reads, dim3(grid_for(h->n_bytes, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, h->d_offsets,
+    hipLaunchKernelGGL(k_scan_reads, dim3(grid_for((h->n_bytes + SCAN_SPAN - 1) / SCAN_SPAN, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, h->d_offsets,
                        h->n_reads, k, t_lo, t_hi, t_idx, cap - 1, d_rf, d_fs);
     e = hipGetLastError();
     if (e == hipSuccess && read_flags) e = hipMemcpyAsync(read_flags, d_rf, h->n_reads, hipMemcpyDeviceToHost, h->stream);

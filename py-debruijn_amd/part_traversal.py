@@ -233,7 +233,8 @@ class PartTraversal:
             assert np.all(found == (counts != 0)), "a kept successor inside the neighbourhood was not collected"
             succ = np.where(found, pos, NO_NODE).astype(np.uint32)
             # Counter order: exact for the branch nodes (the only nodes whose successor order the DFS can see)
-            order = self._order_bytes(counts, np.full((n, 4), np.iinfo(np.uint64).max, dtype=np.uint64))
+            # any permutation serves a node with at most one kept successor; the DFS sees the order at branch nodes only
+            order = np.full(n, 0xE4, dtype=np.uint8)
             b = self.branch
             bpos = np.searchsorted(m["gid"], b["gid"])
             order[bpos] = self._order_bytes(counts[bpos], self.first_seen)
@@ -338,13 +339,12 @@ class PartTraversal:
             hops[act], score[act], dead[act], done[act], jump[act] = h2, s2, d2, dn, j2
             act = act[~dn]
         emit = (e["start"] == 1) & (e["kind"] != K_PULLED) & done & ~dead   # not done after log2(n) doublings: a cycle across parts
-        st = e["stamp"][emit].cpu().numpy().astype(np.uint64)
-        ln = (hops[emit] + self.k).cpu().numpy()
-        sc = score[emit].cpu().numpy()
-        o2 = np.argsort(st, kind="stable")
+        em = torch.nonzero(emit).reshape(-1)
+        em = em[torch.argsort(e["stamp"][em])]           # dict order of the starts (stamps are distinct), sorted on the device
         if keep_skeleton:
-            self.skeleton["emit"] = torch.nonzero(emit).reshape(-1).cpu().numpy()[o2]   # skeleton index of contig i's start
-        return {"stamp": st[o2], "length": ln[o2], "score": sc[o2]}
+            self.skeleton["emit"] = em.cpu().numpy()     # skeleton index of contig i's start
+        return {"stamp": e["stamp"][em].cpu().numpy().astype(np.uint64), "length": (hops[em] + self.k).cpu().numpy(),
+                "score": score[em].cpu().numpy()}
 
     def contig_texts(self, which):
         """The text of the contigs ``which`` (positions in the index ``walk_index(keep_skeleton=True)`` returned) -- every rank

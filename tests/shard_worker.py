@@ -238,6 +238,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
+    if mode == "gpu_parts":  # ranks x passes on cuda:0 over gloo, then the traversal in parts: every rank writes what it ends with
+        import _dbg
+        import part_traversal
+        n_passes = int(os.environ.get("SHARD_PASSES", "2"))
+        g = _dbg.Graph(device=0)
+        g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        t, flags, br, pu = part_traversal.construct_graph(g, k, 2, dist)
+        ctg = part_traversal.output_contigs(t)
+        texts = ctg.texts(range(len(ctg)))
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), branch=np.array(br), pulled=np.array(pu), read_flags=flags,
+                 contigs=np.array(texts), scores=ctg.scores, lengths=ctg.lengths)
+        g.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if mode == "fake":
         g = NumpyShardGraph([row.tobytes().decode() for row in reads], k)
         multi_gpu.sharded_build(g, k, dist)

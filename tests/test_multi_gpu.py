@@ -250,6 +250,37 @@ def test_two_ranks_on_one_gpu(k, n_reads, read_len, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,world,n_passes", [(31, 2, 2), (63, 4, 1)])
+def test_traversal_in_parts_over_real_processes(k, world, n_passes, tmp_path):
+    """part_traversal with one PROCESS per rank (gloo; the ranks share the box's GPU): every rank ends with the same
+    branch_kmer / already_pull_out / contigs as the reference restatement on all reads, and the pull-out flags of the ranks,
+    in rank order, are the reference's pull_out_read."""
+    import contextlib
+    import io
+    from oracle import dbg_oracle as orc
+    n_reads, read_len = 4000, 120
+    os.environ["SHARD_PASSES"] = str(n_passes)
+    try:
+        files = run_ranks("gpu_parts", world, tmp_path, k, n_reads, read_len)
+    finally:
+        del os.environ["SHARD_PASSES"]
+    per = n_reads // world
+    reads = np.concatenate([synth.reads_ascii(77, max(4 * read_len, n_reads * read_len // 20), per, read_len, 0.01,
+                                              first_read=r * per) for r in range(world)])
+    strs = [row.tobytes().decode() for row in reads]
+    with contextlib.redirect_stdout(io.StringIO()):
+        og, opull, obranch, opulled, oect = orc.construct_graph(strs, k, threshold=2)
+        octg = orc.output_contigs(og, obranch, opulled)
+    assert len(obranch) > 0 and len(octg) > 0
+    flags = np.concatenate([f["read_flags"] for f in files]).astype(bool)
+    assert [s for s, fl in zip(strs, flags) if fl] == list(opull)
+    for f in files:
+        assert f["branch"].tolist() == list(obranch) and f["pulled"].tolist() == list(opulled)
+        assert f["contigs"].tolist() == list(octg)
+        assert f["scores"].tolist() == [orc.get_score(oect, c, k) for c in octg]
+
+
+@pytest.mark.gpu
 def test_four_ranks_on_one_gpu(tmp_path):
     """Two owner bits (the box allows at most six processes on its GPU, so eight ranks run only on the real node)."""
     shards = run_ranks("gpu", 4, tmp_path, 21, 8000, 100)
