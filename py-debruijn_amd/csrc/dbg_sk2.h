@@ -26,6 +26,11 @@
 #pragma once
 #include "dbg_sk.h"
 
+#ifndef DBG_SK2_LANEQUAD
+#define DBG_SK2_LANEQUAD 0   // 0: four lanes per quad, one k-mer each; 1: a lane walks the four k-mers of its quad (measured: 12.9 vs 12.0 ms,
+                             // and MORE instructions -- 3.95e9 vs 3.78e9 vector: what a lane saves on decoding the record it spends on the
+                             // bookkeeping of four steps)
+#endif
 #ifndef DBG_SK2_UNROLL
 #define DBG_SK2_UNROLL 8   // probe steps per unrolled body of the insert loop (4: 12.13, 8: 12.06, 16: 12.22 ms)
 #endif
@@ -295,7 +300,92 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                 __syncthreads();
                 CNT_TICK(3);
                 const uint32_t n_flat = s.n_flat;
-                uint32_t p_old = 1, p_mult = 0;  // what the previous iteration's counter add returned (looked at one iteration later)
+                uint32_t p_old = 1, p_mult = 0;  // what the previous counter add returned (looked at one step later)
+#if DBG_SK2_LANEQUAD
+                // One LANE per quad: it reads the record once and walks the quad's (up to) four k-mers one after the other, so the
+                // slot of k-mer i + 1 is in the same lane a step later, and only the quad's last k-mer asks the next lane (the
+                // record's next quad).  A wave-step still probes 64 k-mers, but record decode, list and staging reads are paid
+                // once per four k-mers: ~190 instead of ~300 instructions per 64 k-mers.
+                for (uint32_t f0 = 0; f0 < n_flat; f0 += NT) {
+                    const uint32_t f = f0 + threadIdx.x;
+                    const bool act = f < n_flat;
+                    const uint32_t e = act ? flat[f] : 0u;
+                    const uint32_t r = e >> 3;
+                    const int i0 = (int)(e & 7) * 4;
+                    const uint64_t w0 = s.q_key[r], w1 = s.q_meta[r];
+                    const int len = (int)((w1 >> 1) & 31) + 1;
+                    const ST st0 = s.st_stage[r];
+                    const uint32_t mult = (uint32_t)(w1 >> 6) & ((1u << SK_BUCKET_BITS) - 1u);
+                    const uint64_t hi = w1 & (~0ull << SK_META_BITS);
+                    const int nk = act ? min(4, len - i0) : 0;
+                    bool prev_edge = false;      // the previous k-mer of this lane has a successor and waits for its slot
+                    uint32_t prev_sb = 0, first_slot = 0xFFFFu;
+                    unsigned long long pq = 0;   // this lane's pending edges, 16 bits each
+                    uint32_t pc = 0;
+#pragma unroll 1
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = i0 + j;
+                        bool actj = j < nk;
+                        const uint64_t win = rec_window(w0, hi, i & 31);
+                        const uint64_t kmer = win >> (64 - 2 * k);
+                        if (cur_mask) actj = actj && (sub_hash(kmer) & cur_mask) == cur_val;
+                        const uint32_t b = (uint32_t)(win >> (62 - 2 * k)) & 3u;
+                        uint32_t slot = slot_of<CAP>(kmer);
+                        bool ok = false;
+                        uint32_t won = 0;
+                        if (actj) {
+#pragma unroll DBG_SK2_UNROLL
+                            for (int probe = 0; probe < CNT_PROBE_LIMIT; ++probe) {
+                                unsigned long long cur = s.keys[slot];
+                                if (cur == EMPTY_KEY) {
+                                    cur = atomicCAS(&s.keys[slot], EMPTY_KEY, (unsigned long long)kmer);
+                                    if (cur == EMPTY_KEY) { cur = kmer; won = 1; }
+                                }
+                                if (cur == kmer) { ok = true; break; }
+                                slot = (slot + 1) & (CAP - 1);
+                            }
+                            if (!ok) s.overflow = 1;
+                        }
+                        my_new += won + (((p_old & 0xFFFFu) == 0) ? 0x10000u : 0u);
+                        if (check16 && (p_old & 0xFFFFu) + p_mult > 0xFFFFu) s.fail = 2;
+                        const bool good = actj && ok;
+                        {   // the previous k-mer's edge ends here: hint, or (successor filtered out / record over) pending
+                            const bool in_lane = prev_edge && good;
+                            uint16_t *hp = in_lane ? reinterpret_cast<uint16_t *>(&s.ch[prev_sb]) + 1 : reinterpret_cast<uint16_t *>(&s.dummy[lane]);
+                            *hp = (uint16_t)(HINT_VALID | slot);
+                            if (prev_edge && !good) { pq |= (unsigned long long)prev_sb << (16 * pc); ++pc; }
+                        }
+                        if (j == 0) first_slot = good ? slot : 0xFFFFu;
+                        const bool edge = good && ((i < len - 1) || (w1 & 1));
+                        p_old = 1;
+                        p_mult = 0;
+                        if (edge) { p_old = atomicAdd(&s.ch[slot * 4 + b], mult); p_mult = mult; }
+                        if (good) atomicMin(&s.stamp[slot], i ? (ST)((st0 | (ST)1) + (ST)(2 * i)) : st0);
+                        prev_edge = edge;
+                        prev_sb = slot * 4 + b;
+                    }
+                    {   // the quad's fourth k-mer: its successor is the first k-mer of the record's next quad -- the next lane's
+                        const uint32_t nxt = from_next_lane(first_slot, 0xFFFFu);
+                        const bool in_wave = prev_edge && (i0 + 3 < len - 1) && nxt != 0xFFFFu;
+                        uint16_t *hp = in_wave ? reinterpret_cast<uint16_t *>(&s.ch[prev_sb]) + 1 : reinterpret_cast<uint16_t *>(&s.dummy[lane]);
+                        *hp = (uint16_t)(HINT_VALID | (nxt & (CAP - 1)));
+                        if (prev_edge && !in_wave) { pq |= (unsigned long long)prev_sb << (16 * pc); ++pc; }
+                    }
+                    // this lane's pending edges (at most four) go on the wave's own segment: no atomic, nothing to wait for
+                    {
+                        uint32_t at = pcur, total = 0;
+#pragma unroll
+                        for (int q = 1; q <= 4; ++q) {
+                            const unsigned long long mq = __ballot(pc >= (uint32_t)q);
+                            at += lanes_below(mq);
+                            total += (uint32_t)__popcll(mq);
+                        }
+                        for (uint32_t q = 0; q < pc; ++q)
+                            if (at + q < (uint32_t)PSEG) s.pend[wave * PSEG + at + q] = (uint16_t)(pq >> (16 * q));
+                        pcur += total;
+                    }
+                }
+#else
                 // every lane stays in the loop (predicated): the wave hands successor slots from lane to lane
                 for (uint32_t f0 = 0; f0 < n_flat; f0 += NT / 4) {
                     const uint32_t f = f0 + (threadIdx.x >> 2);
@@ -379,6 +469,7 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
                         pcur += (uint32_t)__popcll(m_pend);
                     }
                 }
+#endif
                 my_new += ((p_old & 0xFFFFu) == 0) ? 0x10000u : 0u;  // the last iteration's add
                 if (check16 && (p_old & 0xFFFFu) + p_mult > 0xFFFFu) s.fail = 2;
             }

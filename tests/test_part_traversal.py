@@ -226,10 +226,10 @@ def test_traversal_in_parts_at_the_baseline_size():
 
 def test_traversal_of_more_than_two_to_the_32_nodes():
     """BASELINE.json configs[3]'s per-rank size on one GPU: 4.4e9 nodes in 8 parts (45 M x 150 bp, 5 % substitutions).
-    pruningEdges on every part and the contig index through the segment skeleton (3.5e8 entries ranked on the device); the
-    index is checked against an independent step-by-step walk of sampled starts and through totals that hold at any size.
-    (The tip neighbourhoods are not collected here: at 5 % errors a third of all nodes is within five steps of a branch node,
-    so they are not the small graph the method assumes -- the BASELINE error rate is covered at full size above.)"""
+    The whole path in parts: pruningEdges (1.5e7 branch nodes), pull-out reads (6.75 GB of reads against their k-mers), tip
+    removal on the collected neighbourhoods (1.9e6 nodes pulled in 8 reservation rounds) and the contig index through the
+    segment skeleton (3.5e8 entries ranked on the device); the index is checked against an independent step-by-step walk of
+    sampled starts and through properties that hold at any size.  About a minute with the build."""
     import part_traversal
     import torch
     torch.zeros(1, device="cuda")
@@ -248,6 +248,15 @@ def test_traversal_of_more_than_two_to_the_32_nodes():
     assert np.all(keep.sum(axis=1) >= 2)
     mx = branch["counts"].max(axis=1)
     assert np.all(np.where(keep == 1, 2 * branch["counts"] >= mx[:, None], True))
+    flags = t.pull_out_reads()
+    assert flags.size == n and 0 < int(flags.sum()) < n
+    pulled = t.remove_tips()
+    assert pulled["gid"].size > 0 and np.unique(pulled["gid"]).size == pulled["gid"].size
+    assert np.intersect1d(pulled["gid"], branch["gid"]).size == 0          # a branch node is never pulled (debruijn.py:251)
+    for p in range(8):                                                      # the pulled nodes carry the flag in their parts
+        mine = pulled["gid"][(pulled["gid"] >> 32) == p] & 0xFFFFFFFF
+        got = g.part_select(p, 0x40, 0x40).cpu().numpy().view(np.uint32)
+        assert np.array_equal(np.sort(mine.astype(np.uint32)), got)
     idx = t.walk_index()
     n_starts = sz["n_starts"]
     assert 0 < idx["stamp"].size <= n_starts
