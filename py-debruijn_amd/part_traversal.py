@@ -40,6 +40,49 @@ def _u32(t):
     return t.to(torch.int64) & 0xFFFFFFFF
 
 
+def rank_skeleton(e, k, keep=False):
+    """The skeleton of segments -> the contig index.  ``e``: dict of equally long int64 tensors, one row per entry node:
+    gid (global id), kind (K_*), next (global id of the entry a REMOTE segment hands over to), hops, score, exit (count of the
+    leaving edge), stamp, start (1: indegree 0).  Entering a pulled node ends the path at the previous one (debruijn.py:
+    292-302); a chain that meets a cycle inside a part (K_CYCLE) or across parts (never resolves) emits nothing (:289-290), nor
+    does a start that is itself pulled.  -> (dict(stamp, length, score) numpy in dict order of the starts, skeleton or None)."""
+    n = e["gid"].numel()
+    if n == 0:
+        z = np.empty(0, dtype=np.int64)
+        sk = {"gid": z, "next": z, "go_on": z.astype(bool), "hops": z, "emit": z} if keep else None
+        return {"stamp": z.astype(np.uint64), "length": z, "score": z}, sk
+    o = torch.argsort(e["gid"])
+    e = {c: t[o] for c, t in e.items()}
+    remote = e["kind"] == K_REMOTE
+    want = torch.where(remote, e["next"], e["gid"])
+    j = torch.searchsorted(e["gid"], want).clamp_(max=n - 1)
+    assert bool((e["gid"][j] == want).all()), "a chain continues at a node that is no entry"
+    go_on = remote & (e["kind"][j] != K_PULLED)     # entering a pulled node ends the path at the previous one
+    sk = {"gid": e["gid"].cpu().numpy(), "next": j.cpu().numpy(), "go_on": go_on.cpu().numpy(), "hops": e["hops"].cpu().numpy()} if keep else None
+    hops = e["hops"] + go_on.to(torch.int64)
+    score = e["score"] + torch.where(go_on, e["exit"], torch.zeros_like(e["exit"]))
+    dead = e["kind"] == K_CYCLE
+    done = ~go_on
+    jump = torch.where(go_on, j, torch.arange(n, device=e["gid"].device))
+    # pointer jumping over the entries that are not resolved yet (the list shrinks fast: most chains are a few segments);
+    # a round reads the old values of its targets before anything is written
+    act = torch.nonzero(~done).reshape(-1)
+    for _ in range(max(1, math.ceil(math.log2(n + 1))) + 1):
+        if act.numel() == 0:
+            break
+        tj = jump[act]
+        h2, s2, d2, dn, j2 = hops[act] + hops[tj], score[act] + score[tj], dead[act] | dead[tj], done[tj], jump[tj]
+        hops[act], score[act], dead[act], done[act], jump[act] = h2, s2, d2, dn, j2
+        act = act[~dn]
+    emit = (e["start"] == 1) & (e["kind"] != K_PULLED) & done & ~dead   # not done after log2(n) doublings: a cycle across parts
+    em = torch.nonzero(emit).reshape(-1)
+    em = em[torch.argsort(e["stamp"][em])]           # dict order of the starts (stamps are distinct), sorted on the device
+    if keep:
+        sk["emit"] = em.cpu().numpy()                # skeleton index of contig i's start
+    return {"stamp": e["stamp"][em].cpu().numpy().astype(np.uint64), "length": (hops[em] + k).cpu().numpy(),
+            "score": score[em].cpu().numpy()}, sk
+
+
 class _Net:
     """How rows reach the rank that owns them: torch.distributed, or a single process (dist None)."""
 
@@ -307,44 +350,10 @@ class PartTraversal:
             mine = {c: torch.empty(0, dtype=torch.int64, device=dev) for c in ("gid", "kind", "next", "hops", "score", "exit", "stamp", "start")}
         cols = list(mine.keys())
         e = dict(zip(cols, self.net.gather_all(*[mine[c] for c in cols])))
-        # ---- the skeleton: entry -> the entry its segment hands over to; pointer jumping
-        n = e["gid"].numel()
-        if n == 0:
-            z = np.empty(0, dtype=np.int64)
-            if keep_skeleton:
-                self.skeleton = {"gid": z, "next": z, "go_on": z.astype(bool), "hops": z, "emit": z}
-            return {"stamp": z.astype(np.uint64), "length": z, "score": z}
-        o = torch.argsort(e["gid"])
-        e = {c: t[o] for c, t in e.items()}
-        remote = e["kind"] == K_REMOTE
-        j = torch.searchsorted(e["gid"], torch.where(remote, e["next"], e["gid"])).clamp_(max=n - 1)
-        assert bool((e["gid"][j] == torch.where(remote, e["next"], e["gid"])).all()), "a chain continues at a node that is no entry"
-        go_on = remote & (e["kind"][j] != K_PULLED)     # entering a pulled node ends the path at the previous one
+        index, skeleton = rank_skeleton(e, self.k, keep_skeleton)
         if keep_skeleton:
-            self.skeleton = {"gid": e["gid"].cpu().numpy(), "next": j.cpu().numpy(), "go_on": go_on.cpu().numpy(),
-                             "hops": e["hops"].cpu().numpy()}
-        hops = e["hops"] + go_on.to(torch.int64)
-        score = e["score"] + torch.where(go_on, e["exit"], torch.zeros_like(e["exit"]))
-        dead = e["kind"] == K_CYCLE
-        done = ~go_on
-        jump = torch.where(go_on, j, torch.arange(n, device=e["gid"].device))
-        # pointer jumping over the entries that are not resolved yet (the list shrinks fast: most chains are a few segments);
-        # a round reads the old values of its targets before anything is written
-        act = torch.nonzero(~done).reshape(-1)
-        for _ in range(max(1, math.ceil(math.log2(n + 1))) + 1):
-            if act.numel() == 0:
-                break
-            tj = jump[act]
-            h2, s2, d2, dn, j2 = hops[act] + hops[tj], score[act] + score[tj], dead[act] | dead[tj], done[tj], jump[tj]
-            hops[act], score[act], dead[act], done[act], jump[act] = h2, s2, d2, dn, j2
-            act = act[~dn]
-        emit = (e["start"] == 1) & (e["kind"] != K_PULLED) & done & ~dead   # not done after log2(n) doublings: a cycle across parts
-        em = torch.nonzero(emit).reshape(-1)
-        em = em[torch.argsort(e["stamp"][em])]           # dict order of the starts (stamps are distinct), sorted on the device
-        if keep_skeleton:
-            self.skeleton["emit"] = em.cpu().numpy()     # skeleton index of contig i's start
-        return {"stamp": e["stamp"][em].cpu().numpy().astype(np.uint64), "length": (hops[em] + self.k).cpu().numpy(),
-                "score": score[em].cpu().numpy()}
+            self.skeleton = skeleton
+        return index
 
     def contig_texts(self, which):
         """The text of the contigs ``which`` (positions in the index ``walk_index(keep_skeleton=True)`` returned) -- every rank

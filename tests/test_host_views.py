@@ -208,3 +208,51 @@ def test_support_score_table_cache_follows_the_dict_and_its_content():
     assert values(t) == ([1.5, 4.0, 1.0], [1, 1, 0])
     t["GGG"] = 1.0                                         # 1 == 1.0 and hash alike; the result type differs
     assert values(t) == ([1.5, 4.0, 1.0], [1, 1, 1])
+
+
+def test_skeleton_ranking_equals_a_step_by_step_walk():
+    """part_traversal.rank_skeleton (pointer jumping over the segment skeleton of a graph in parts; no GPU needed) against a
+    plain walk from every start, on random skeletons with chains, pulled entries, cycles inside a part and across parts."""
+    import torch
+    import part_traversal as pt
+    rng = np.random.default_rng(11)
+    for trial in range(60):
+        n = int(rng.integers(1, 400))
+        gid = np.sort(rng.choice(1 << 20, size=n, replace=False)).astype(np.int64) | (rng.integers(0, 8, size=n).astype(np.int64) << 32)
+        gid = np.unique(gid)
+        n = gid.size
+        kind = rng.choice([pt.K_EMIT, pt.K_PULLED, pt.K_REMOTE, pt.K_REMOTE, pt.K_REMOTE, pt.K_CYCLE, pt.K_NEXT_PULLED], size=n)
+        nxt = gid[rng.integers(0, n, size=n)]                       # any entry, cycles included
+        hops = rng.integers(0, 30, size=n).astype(np.int64)
+        score = rng.integers(0, 1000, size=n).astype(np.int64)
+        exit_cnt = rng.integers(1, 50, size=n).astype(np.int64)
+        start = (rng.random(n) < 0.3).astype(np.int64)
+        stamp = rng.permutation(n).astype(np.int64) * 2
+        perm = rng.permutation(n)                                    # rows arrive in any order
+        e = {"gid": gid[perm], "kind": kind[perm].astype(np.int64), "next": nxt[perm], "hops": hops[perm], "score": score[perm],
+             "exit": exit_cnt[perm], "stamp": stamp[perm], "start": start[perm]}
+        got, sk = pt.rank_skeleton({c: torch.from_numpy(v.copy()) for c, v in e.items()}, 21, keep=True)
+        pos = {int(g_): i for i, g_ in enumerate(gid)}
+        want = []
+        for s in np.nonzero(start)[0]:
+            if kind[s] == pt.K_PULLED:
+                continue
+            i, h, sc, seen, ok = int(s), 0, 0, set(), True
+            while True:
+                if i in seen or kind[i] == pt.K_CYCLE:
+                    ok = False
+                    break
+                seen.add(i)
+                h += int(hops[i]); sc += int(score[i])
+                if kind[i] != pt.K_REMOTE:
+                    break
+                j = pos[int(nxt[i])]
+                if kind[j] == pt.K_PULLED:
+                    break
+                h += 1; sc += int(exit_cnt[i])
+                i = j
+            if ok:
+                want.append((int(stamp[s]), h + 21, sc))
+        want.sort()
+        assert list(zip(got["stamp"].tolist(), got["length"].tolist(), got["score"].tolist())) == want
+        assert sk["emit"].size == len(want)

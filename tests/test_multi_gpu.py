@@ -363,3 +363,41 @@ def test_a_rank_without_reads(k, n_passes):
     allr = np.concatenate([reads_of(r) for r in range(4)])
     want = orc_c.build(allr.reshape(-1), np.arange(0, allr.size + 1, L, dtype=np.uint64), k, export=False)
     assert sum(got) == want["n_nodes"] and min(got) > 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_part_traversal_routing_on_cpu(world):
+    """part_traversal._Net -- how id lists and rows reach the rank that owns them -- on CPU tensors, `world` in-process
+    ranks: route() delivers every row to its destination and nothing else, gather_all() gives every rank the same
+    rank-ordered table (columns of several elements per row included), min_u64() is the element-wise minimum with the
+    all-ones sentinel for 'never seen'."""
+    import torch
+    import part_traversal as pt
+
+    def one(dist, rank):
+        net = pt._Net(dist, "cpu")
+        rng = np.random.default_rng(100 + rank)
+        n = int(rng.integers(0, 50))
+        dest = torch.from_numpy(rng.integers(0, world, size=n))
+        val = torch.arange(n, dtype=torch.int64) + 1000 * rank
+        got_dest, got_val = net.route(dest, dest.clone(), val)
+        assert bool((got_dest == rank).all())
+        rows = torch.arange(3, dtype=torch.int64) + 10 * rank
+        wide = (torch.arange(12, dtype=torch.int64) + 100 * rank)
+        a, b = net.gather_all(rows, wide, widths=[1, 4])
+        fs = np.full((5, 4), np.iinfo(np.uint64).max, dtype=np.uint64)
+        fs[rank % 5, rank % 4] = 7 + rank
+        fs[4, 3] = 100 - rank
+        return sorted(got_val.tolist()), (dest.tolist(), val.tolist()), a.tolist(), b.tolist(), net.min_u64(fs)
+
+    got = inproc_dist.run_ranks(world, one)
+    for r in range(world):
+        want = sorted(v for _, (dest, val), _, _, _ in got for d, v in zip(dest, val) if d == r)
+        assert got[r][0] == want
+        assert got[r][2] == [x + 10 * q for q in range(world) for x in range(3)]
+        assert got[r][3] == [x + 100 * q for q in range(world) for x in range(12)]
+        m = got[r][4]
+        assert m[4, 3] == 100 - (world - 1)
+        for q in range(world):
+            assert m[q % 5, q % 4] == min(7 + p for p in range(world) if (p % 5, p % 4) == (q % 5, q % 4))
+        assert int((m == np.iinfo(np.uint64).max).sum()) == 20 - len({(p % 5, p % 4) for p in range(world)} | {(4, 3)})
