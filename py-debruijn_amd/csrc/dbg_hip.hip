@@ -2245,7 +2245,45 @@ extern "C" int dbg_build(dbg_t *h, int k, uint64_t table_capacity_hint) {
     drop_spare_part(h);
     h->k = k;
     h->stats = dbg_stats_t{};
-    CHK(compute_alphabet(h));
+    // The first build on a read set has to know its alphabet.  Reads over ACGT -- the hot path -- are taken at their word:
+    // the extraction kernels check every byte anyway, so the separate pass over the reads (k_g_hist, 1.9 ms per 1.5 GB: 8 %
+    // of a build, paid again after every `sequences.extend(...)` of the multi-k driver) runs only when they object.
+    const bool tentative = !h->alpha_known && h->engine == 0 && h->n_bytes > 0;
+    if (tentative) h->is_dna = true;
+    else CHK(compute_alphabet(h));
+    if (tentative) {
+        Timer t_total(h->stream);
+        int rc;
+        if (k > 31) {
+            bool fallback = true;
+            rc = h->wide_engine == 1 ? build_wsk(h, k, &fallback) : DBG_E_CAPACITY;
+            if (fallback && rc != DBG_E_ALPHABET) {
+                free_build(h);
+                h->k = k;
+                h->stats = dbg_stats_t{};
+                CHK(compute_alphabet(h));  // the global-table engine does not validate the bytes itself
+                rc = h->is_dna ? build_wide(h, k, table_capacity_hint) : DBG_E_ALPHABET;
+            }
+        } else {
+            rc = build_sk(h, k, table_capacity_hint);
+        }
+        if (rc == DBG_OK) {
+            rc = finish_graph(h);
+            if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+            h->alpha_known = true;  // ACGT, confirmed byte by byte
+            h->is_dna = true;
+            h->stats.ms_build_total = t_total.stop();
+            if (k <= 31) pool_trim(h);
+            return DBG_OK;
+        }
+        if (rc != DBG_E_ALPHABET) { const std::string keep = h->err; free_build(h); h->err = keep; return rc; }
+        free_build(h);  // another alphabet: find out which, then the generic engine below
+        h->k = k;
+        h->stats = dbg_stats_t{};
+        h->err.clear();
+        CHK(compute_alphabet(h));
+        if (h->is_dna) { h->err = "internal: the extraction refused reads the alphabet scan calls ACGT"; return DBG_E_HIP; }
+    }
     if (!h->is_dna) {  // any other alphabet: generic 5-bit engine (peptides: the reference's real inputs)
         Timer t_total(h->stream);
         int rc = build_generic(h, k);
