@@ -184,12 +184,11 @@ class PartTraversal:
             rows.append(self._rows(p, ids))
         mine = self._cat(rows)
         cols = list(mine.keys())
-        got = self.net.gather_all(*[mine[c].reshape(-1) for c in cols], widths=[4 if c in ("counts", "succ") else 1 for c in cols])
-        b = {c: t.cpu().numpy() for c, t in zip(cols, got)}
-        n = b["gid"].size
-        b["counts"], b["succ"] = b["counts"].reshape(n, 4), b["succ"].reshape(n, 4)
-        o = np.argsort(b["stamps"].astype(np.uint64), kind="stable")
-        self.branch = {c: a[o] for c, a in b.items()}
+        got = dict(zip(cols, self.net.gather_all(*[mine[c].reshape(-1) for c in cols], widths=[4 if c in ("counts", "succ") else 1 for c in cols])))
+        n = got["gid"].numel()
+        got["counts"], got["succ"] = got["counts"].reshape(n, 4), got["succ"].reshape(n, 4)
+        o = torch.argsort(got["stamps"])   # dict order = ascending first-occurrence stamp (distinct, below 2^63); sorted on the device
+        self.branch = {c: t[o].cpu().numpy() for c, t in got.items()}
         return self.branch
 
     # ---- a9 + the Counter order of the branch nodes' successors
