@@ -203,8 +203,9 @@ def node_digest_gpu(g):
 
 
 def cpu_baseline(g, read_len, k, n_reads, gpu_sizes, gpu_digest):
-    """oracle/dbg_oracle.c, multi-threaded (hash-partitioned, one table per thread, no locks), on the FULL input
-    of the N = 1 workload and on every core this process may use; plus the Python restatement of the reference's
+    """oracle/dbg_oracle.c, multi-threaded (orc_build_mt_partitioned: every k-mer window is hashed once and handed to the
+    thread that owns its hash slice; one table per thread, no locks), on the FULL input of the N = 1 workload and on every
+    core this process may use; orc_build_mt (every thread scans all reads, round 2's baseline) beside it; plus the Python restatement of the reference's
     algorithm (oracle/dbg_oracle.py, one core: Python is single-threaded) timed at BASELINE.json configs[0]."""
     import numpy as np
     import synth
@@ -213,14 +214,17 @@ def cpu_baseline(g, read_len, k, n_reads, gpu_sizes, gpu_digest):
     reads, off = g.copy_reads()  # the very bytes the GPU built from (the device generator is bit-identical to synth.py)
     orc_c.lib()
     t0 = time.perf_counter()
-    res = orc_c.build_mt(reads, off, k, cores)
+    res = orc_c.build_mt(reads, off, k, cores, partition_once=True)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res_scan = orc_c.build_mt(reads, off, k, cores)
+    dt_scan = time.perf_counter() - t0
     with open("/proc/cpuinfo") as fh:
         model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "?")
-    same = (res["n_nodes"] == gpu_sizes["n_nodes"] and res["n_edges"] == gpu_sizes["n_edges"] and
+    same = (res == res_scan and res["n_nodes"] == gpu_sizes["n_nodes"] and res["n_edges"] == gpu_sizes["n_edges"] and
             res["n_kmer_instances"] == gpu_sizes["n_kmer_instances"] and
             (gpu_digest is None or res["digest"] == gpu_digest))
-    # one thread on a sixteenth of the reads: what a thread does when it keeps everything it hashes
+    # one thread on a sixteenth of the reads
     one = None
     try:
         n1 = max(1, n_reads // 16)
@@ -233,11 +237,14 @@ def cpu_baseline(g, read_len, k, n_reads, gpu_sizes, gpu_digest):
         one = {"error": f"{type(e).__name__}: {e}"}
     out = {"value": res["n_kmer_instances"] / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
            "sample": f"the full input of this run ({n_reads} reads, {res['n_kmer_instances']} k-mer instances, "
-                     f"{res['n_nodes']} distinct), oracle/dbg_oracle.c orc_build_mt with {cores} threads, {dt:.1f} s; "
-                     f"every thread rolls and hashes ALL k-mers and keeps its 1/{cores} of them (no pre-partition), so the "
-                     f"scan work grows with the thread count -- see one_thread for a thread that keeps all it hashes; "
+                     f"{res['n_nodes']} distinct), oracle/dbg_oracle.c orc_build_mt_partitioned with {cores} threads, {dt:.1f} s: "
+                     f"each thread rolls and hashes its share of the reads once and hands every k-mer to the thread owning "
+                     f"its hash slice, which builds that slice's table (16 B per instance held between the phases); "
                      f"{model}, {os.cpu_count()} cpus visible, {cores} usable (affinity / cgroup quota)",
            "one_thread": one,
+           "every_thread_scans_all_reads": {"value": res_scan["n_kmer_instances"] / dt_scan, "unit": "k-mers/s", "cores": cores,
+                                            "seconds": round(dt_scan, 1), "what": "orc_build_mt, round 2's baseline: no "
+                                            "list between the phases, the scan is repeated per thread"},
            "same_graph_as_gpu": bool(same),
            "compared": "node, edge and k-mer instance totals" + ("" if gpu_digest is None else
                                                                     " + 64-bit digest over (k-mer, stamp, 4 counts) of every node")}

@@ -283,3 +283,120 @@ int orc_build_mt(const char *bases, const uint64_t *offsets, uint64_t n_reads, i
     free(th);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The same multi-threaded build with the k-mers partitioned ONCE (what a tuned CPU builder does; orc_build_mt above
+ * lets every thread roll and hash every window and keep 1/T of them).  Phase 1: thread t scans ITS share of the reads
+ * and appends every window as (key, stamp | next base) to the list of the thread that owns the key's hash slice.
+ * Phase 2: thread d builds its table from the T lists addressed to it, in reader order (ascending positions: the first
+ * instance inserts the first-occurrence stamp).  Same slices, same per-node results, same digest as orc_build_mt.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t key, meta; } orc_tuple;   /* meta: stamp | (next base code + 1) << 61, 0 in the top bits = no successor */
+typedef struct { orc_tuple *p; uint64_t n, cap; } orc_vec;
+typedef struct {
+    const char *bases;
+    const uint64_t *offsets;
+    uint64_t r_beg, r_end;
+    int k, t, n_threads, rc;
+    orc_vec *lists;   /* [n_threads][n_threads]: lists[t * T + d] = what reader t found for owner d */
+    uint64_t out[5];
+} orc_p_job;
+
+static int vec_push(orc_vec *v, uint64_t key, uint64_t meta) {
+    if (v->n == v->cap) {
+        const uint64_t nc = v->cap ? v->cap * 2 : 4096;
+        orc_tuple *np = (orc_tuple *)realloc(v->p, nc * sizeof(orc_tuple));
+        if (!np) return -1;
+        v->p = np; v->cap = nc;
+    }
+    v->p[v->n].key = key; v->p[v->n].meta = meta; ++v->n;
+    return 0;
+}
+
+static void *p_scan(void *arg) {
+    orc_p_job *jb = (orc_p_job *)arg;
+    const int k = jb->k;
+    const uint64_t kmask = (k == 32) ? ~0ULL : ((1ULL << (2 * k)) - 1), T = (uint64_t)jb->n_threads;
+    orc_vec *mine = jb->lists + (uint64_t)jb->t * T;
+    for (uint64_t r = jb->r_beg; r < jb->r_end; ++r) {
+        const uint64_t beg = jb->offsets[r], len = jb->offsets[r + 1] - beg;
+        if (len <= (uint64_t)k) continue; /* debruijn.py:126 */
+        const unsigned char *s = (const unsigned char *)jb->bases + beg;
+        uint64_t key = 0;
+        for (uint64_t i = 0; i <= len; ++i) {
+            const unsigned char c = i < len ? s[i] : 0;
+            if (i < len && c != 'A' && c != 'C' && c != 'G' && c != 'T') { jb->rc = -1; return NULL; }
+            if (i >= (uint64_t)k) {
+                const uint64_t h = hash_narrow(key), pos = i - k;
+                const uint64_t d = ((h >> 32) * T) >> 32;
+                const uint64_t stamp = ((beg + pos) << 1) | (pos != 0);
+                if (stamp >> 61) { jb->rc = -3; return NULL; }
+                if (vec_push(&mine[d], key, stamp | (i < len ? (uint64_t)(((c >> 1) & 3) + 1) << 61 : 0))) { jb->rc = -2; return NULL; }
+            }
+            key = ((key << 2) | ((c >> 1) & 3)) & kmask;
+        }
+    }
+    return NULL;
+}
+
+static void *p_build(void *arg) {
+    orc_p_job *jb = (orc_p_job *)arg;
+    const uint64_t T = (uint64_t)jb->n_threads, me = (uint64_t)jb->t;
+    uint64_t cap = 1 << 16, n = 0, n_inst = 0, n_einst = 0;
+    orc_slot *tab = (orc_slot *)malloc(cap * sizeof(orc_slot));
+    if (!tab) { jb->rc = -2; return NULL; }
+    memset(tab, 0xFF, cap * sizeof(orc_slot));
+    for (uint64_t t = 0; t < T; ++t) {
+        orc_vec *v = jb->lists + t * T + me;
+        for (uint64_t q = 0; q < v->n; ++q) {
+            const uint64_t key = v->p[q].key, meta = v->p[q].meta;
+            orc_slot *e = mt_find(&tab, &cap, &n, key, hash_narrow(key));
+            if (!e) { jb->rc = -2; free(tab); return NULL; }
+            if (e->key == ~0ULL) {
+                e->key = key;
+                e->stamp = meta & ((1ULL << 61) - 1);
+                e->cnt[0] = e->cnt[1] = e->cnt[2] = e->cnt[3] = 0;
+                ++n;
+            }
+            ++n_inst;
+            if (meta >> 61) { e->cnt[(meta >> 61) - 1]++; ++n_einst; }
+        }
+        free(v->p); v->p = NULL; v->n = v->cap = 0;   /* consumed: only this thread reads list (t, me) */
+    }
+    uint64_t edges = 0, dig = 0;
+    for (uint64_t i = 0; i < cap; ++i) {
+        if (tab[i].key == ~0ULL) continue;
+        for (int b = 0; b < 4; ++b) edges += tab[i].cnt[b] != 0;
+        dig += orc_node_digest(tab[i].key, tab[i].stamp, tab[i].cnt);
+    }
+    free(tab);
+    jb->out[0] = n; jb->out[1] = edges; jb->out[2] = n_inst; jb->out[3] = n_einst; jb->out[4] = dig;
+    return NULL;
+}
+
+/* as orc_build_mt; 16 bytes of list per k-mer instance are held between the phases */
+int orc_build_mt_partitioned(const char *bases, const uint64_t *offsets, uint64_t n_reads, int k, int n_threads, uint64_t *out5) {
+    if (k < 1 || k > 31 || n_threads < 1 || n_threads > 1024 || !out5) return -3;
+    const uint64_t T = (uint64_t)n_threads;
+    orc_p_job *jobs = (orc_p_job *)calloc(T, sizeof(orc_p_job));
+    pthread_t *th = (pthread_t *)calloc(T, sizeof(pthread_t));
+    orc_vec *lists = (orc_vec *)calloc(T * T, sizeof(orc_vec));
+    int rc = 0;
+    if (!jobs || !th || !lists) rc = -2;
+    for (int phase = 0; phase < 2 && !rc; ++phase) {
+        int started = 0;
+        for (uint64_t t = 0; t < T; ++t) {
+            jobs[t].bases = bases; jobs[t].offsets = offsets; jobs[t].k = k; jobs[t].t = (int)t; jobs[t].n_threads = n_threads;
+            jobs[t].r_beg = n_reads * t / T; jobs[t].r_end = n_reads * (t + 1) / T; jobs[t].lists = lists;
+            if (pthread_create(&th[t], NULL, phase ? p_build : p_scan, &jobs[t])) { rc = -2; break; }
+            ++started;
+        }
+        for (int t = 0; t < started; ++t) pthread_join(th[t], NULL);
+        for (uint64_t t = 0; t < T && !rc; ++t) rc = jobs[t].rc;
+    }
+    for (int i = 0; i < 5; ++i) out5[i] = 0;
+    if (!rc) for (uint64_t t = 0; t < T; ++t) for (int i = 0; i < 5; ++i) out5[i] += jobs[t].out[i];
+    if (lists) for (uint64_t i = 0; i < T * T; ++i) free(lists[i].p);
+    free(lists); free(jobs); free(th);
+    return rc;
+}

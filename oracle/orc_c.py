@@ -26,6 +26,8 @@ def lib():
         l.orc_export2.argtypes = [C.c_void_p] * 5
         l.orc_build_mt.restype = C.c_int
         l.orc_build_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p]
+        l.orc_build_mt_partitioned.restype = C.c_int
+        l.orc_build_mt_partitioned.argtypes = l.orc_build_mt.argtypes
         _lib = l
     return _lib
 
@@ -75,13 +77,16 @@ def digest(keys, stamps, counts):
         return int(_mix64(keys ^ _mix64(stamps) ^ _mix64(w)).sum(dtype=np.uint64))
 
 
-def build_mt(bases, offsets, k, n_threads):
-    """Multi-threaded build (k <= 31): totals and the node digest only -- bench.py's cpu_baseline on all host cores."""
+def build_mt(bases, offsets, k, n_threads, partition_once=False):
+    """Multi-threaded build (k <= 31): totals and the node digest only -- bench.py's cpu_baseline on all host cores.
+    partition_once: orc_build_mt_partitioned (every window is rolled and hashed by ONE thread and handed to the owner of its
+    hash slice; 16 bytes per k-mer instance between the phases) instead of orc_build_mt (every thread scans everything)."""
     l = lib()
     b = np.ascontiguousarray(np.frombuffer(bases, dtype=np.uint8) if not isinstance(bases, np.ndarray) else bases)
     o = np.ascontiguousarray(offsets, dtype=np.uint64)
     out = np.zeros(5, dtype=np.uint64)
-    rc = l.orc_build_mt(b.ctypes.data, o.ctypes.data, o.size - 1, int(k), int(n_threads), out.ctypes.data)
+    fn = l.orc_build_mt_partitioned if partition_once else l.orc_build_mt
+    rc = fn(b.ctypes.data, o.ctypes.data, o.size - 1, int(k), int(n_threads), out.ctypes.data)
     if rc:
         raise ValueError(f"orc_build_mt failed ({rc})")
     return {"n_nodes": int(out[0]), "n_edges": int(out[1]), "n_kmer_instances": int(out[2]),

@@ -331,7 +331,8 @@ def test_bench_line_contract_at_a_small_size(tmp_path):
     assert c["kind"] == "port" and c["cores"] >= 1 and c["same_graph_as_gpu"] is True and c["value"] > 0
     assert d["extras"]["fasta_ingest"]["same_reads_and_graph"] is True
     assert d["extras"]["traversal_in_parts_sizes"]["same_as_single_graph"] is True
-    assert d["first_build_ms"] > 0 and c["one_thread"]["value"] > 0
+    assert d["first_build_ms"] > 0 and c["one_thread"]["value"] > 0 and c["every_thread_scans_all_reads"]["value"] > 0
+    assert "orc_build_mt_partitioned" in c["sample"]
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])

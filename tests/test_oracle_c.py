@@ -44,7 +44,7 @@ def test_c_oracle_matches_python_oracle(name):
 
 
 def test_multithreaded_build_equals_the_single_threaded_one():
-    """bench.py's cpu_baseline (orc_build_mt: hash-partitioned over threads) must build the same graph as orc_build."""
+    """bench.py's cpu_baseline (orc_build_mt_partitioned, and orc_build_mt beside it: hash slices over threads) must build the same graph as orc_build."""
     import numpy as np
     import synth
     reads = synth.reads_ascii(5, 30000, 6000, 100, 0.01)
@@ -52,7 +52,8 @@ def test_multithreaded_build_equals_the_single_threaded_one():
     for k in (5, 21, 31):
         a = orc_c.build(reads.reshape(-1), off, k)
         for threads in (1, 3, 8):
-            b = orc_c.build_mt(reads.reshape(-1), off, k, threads)
-            assert b["n_nodes"] == a["n_nodes"] and b["n_kmer_instances"] == a["n_kmer_instances"]
-            assert b["n_edge_instances"] == a["n_edge_instances"] and b["n_edges"] == int((a["counts"] != 0).sum())
-            assert b["digest"] == orc_c.digest(a["keys"], a["stamps"], a["counts"])
+            for once in (False, True):  # every thread scans everything / k-mers partitioned once (bench.py uses the latter)
+                b = orc_c.build_mt(reads.reshape(-1), off, k, threads, partition_once=once)
+                assert b["n_nodes"] == a["n_nodes"] and b["n_kmer_instances"] == a["n_kmer_instances"]
+                assert b["n_edge_instances"] == a["n_edge_instances"] and b["n_edges"] == int((a["counts"] != 0).sum())
+                assert b["digest"] == orc_c.digest(a["keys"], a["stamps"], a["counts"])
