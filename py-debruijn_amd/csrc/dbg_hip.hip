@@ -25,6 +25,7 @@
 #include "dbg_device.h"
 #include "dbg_sk.h"
 #include "dbg_sk2.h"
+#include "dbg_wsk2.h"
 #include "dbg_generic.h"
 #include "dbg_genref.h"
 #include "dbg_wide.h"
@@ -126,6 +127,7 @@ struct dbg {
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
     int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
     int count_kernel_u64 = 1; // option "count_kernel_u64": the same choice for 64-bit stamps (measured: 1)
+    int wcount_kernel = 2;   // 32 <= k <= 63, 32-bit stamps: 2 = k_wsk_count2 (one successor hint per slot, deferred lookups), 1 = k_wsk_count
     int count_kernel = 2;    // k <= 31, 4096 slots: 2 = k_sk_count2 (successor hints, 16-bit counters; falls back to 1 on counter overflow), 1 = k_sk_count
 
     // grow-only device arena of the super-k-mer engine: hipMalloc of tens of GB costs seconds,
@@ -2123,6 +2125,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
     if (n == "count_kernel" && (value == 1 || value == 2)) { h->count_kernel = (int)value; return DBG_OK; }
+    if (n == "wcount_kernel" && (value == 1 || value == 2)) { h->wcount_kernel = (int)value; return DBG_OK; }
     if (n == "count_kernel_u64" && (value == 1 || value == 2)) { h->count_kernel_u64 = (int)value; return DBG_OK; }
     if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
@@ -4056,7 +4059,10 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
         WSkCountOut out{h->d_keys, h->d_keys_hi, h->d_stamps_st, h->d_flags, node_cap, h->d_rowptr32, h->d_col, h->d_ecnt, edge_cap,
                         q_lo, q_hi, q_col, q_cap, ranges, n_buckets, range_cap, dirs, own_lo, own_cnt, sc_dev, id_tag};
         auto kern = k_wsk_count<ST>;
-        const size_t lds = sizeof(WCntLds<ST>);
+        size_t lds = sizeof(WCntLds<ST>);
+        if constexpr (sizeof(ST) == 4) {
+            if (h->wcount_kernel == 2) { kern = k_wsk_count2<ST>; lds = sizeof(WCnt2Lds); }
+        }
         HIPCHK(h, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (n_rec) {
             int n_cu = 256;
@@ -4075,7 +4081,7 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
         h->stats.count_launches = n_rec ? (uint64_t)(attempt + 1) : 0;
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 64, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_count = t.stop();
-        if (sc[0] & (8 | 32 | 512)) break;
+        if (sc[0] & (8 | 32 | 512 | 2048)) break;
         bool again = false;
         if ((sc[0] & 16) && (node_cap < node_cap_max || edge_cap < edge_cap_max)) { node_cap = node_cap_max; edge_cap = edge_cap_max; again = true; }
         if ((sc[0] & 64) && q_cap < n_edge_inst + 1024) { q_cap = n_edge_inst + 1024; again = true; }
@@ -4083,6 +4089,7 @@ static int wsk_count(dbg *h, int k, const uint64_t *pk, const uint64_t *seg_star
     }
     if (sc[0] & 1024) { h->err = "two-word count kernel: an LDS slot claim never completed"; return DBG_E_HIP; }
     if (sc[0] & 512) { h->err = "16-bit successor counter overflow"; return DBG_E_CAPACITY; }
+    if (sc[0] & 2048) { h->err = "internal: k_wsk_count2 counted a bucket's nodes or edges inconsistently"; return DBG_E_HIP; }  // (after 512: a wrapped counter reads 0 twice)
     if (sc[0] & 8) { h->err = "a bucket could not be split to fit the LDS table"; return DBG_E_CAPACITY; }
     if (sc[0] & 16) { h->err = "node/edge capacity exceeded"; return DBG_E_CAPACITY; }
     if (sc[0] & (32 | 64)) { h->err = "range/query list overflow"; return DBG_E_CAPACITY; }
@@ -5016,6 +5023,7 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
         sub->bucket_bits = h->bucket_bits;
         sub->count_kernel = h->count_kernel;
         sub->count_kernel_u64 = h->count_kernel_u64;
+        sub->wcount_kernel = h->wcount_kernel;
         sub->target_distinct = h->target_distinct;
         sub->est_scale_pct = h->est_scale_pct;
         if (!sub->d_scalars) HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));

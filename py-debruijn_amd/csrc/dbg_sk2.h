@@ -388,6 +388,7 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
 #else
                 // every lane stays in the loop (predicated): the wave hands successor slots from lane to lane
                 for (uint32_t f0 = 0; f0 < n_flat; f0 += NT / 4) {
+                    if (f0 + wave * 16 >= n_flat) break;  // wave-uniform: nothing left for this wave (the list is dealt out in lane order)
                     const uint32_t f = f0 + (threadIdx.x >> 2);
                     bool act = f < n_flat;
                     const uint32_t e = act ? flat[f] : 0u;

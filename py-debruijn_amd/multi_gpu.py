@@ -70,19 +70,23 @@ def _alltoallv_once(dist, tensor, send_counts, recv_counts):
     return out
 
 
-def alltoallv(dist, tensor, send_counts, recv_counts):
+def alltoallv(dist, tensor, send_counts, recv_counts, biggest=None):
     """Variable all-to-all of a 1-D tensor laid out contiguously in destination order
     (all_to_all_single with split sizes; staged through the host for gloo).
 
     A large (source, destination) message is not safe with every backend (observed over nccl: a 7 GB
     self-copy arrived truncated, a 2 GiB one damaged), so pairs above MAX_MESSAGE_BYTES are moved in rounds of that
-    size; the number of rounds is agreed on with one all-reduce.
+    size.  Every rank must run the same number of rounds: ``biggest`` = the largest message (elements) between ANY pair
+    of ranks, when the caller knows it (the ranks of a sharded build know every pair's count from their one
+    all-gather); None: agreed on with an all-reduce and a host sync here.
     """
     limit = max(1, MAX_MESSAGE_BYTES // tensor.element_size())
-    biggest = max(list(send_counts) + list(recv_counts) + [0])
-    t = torch.tensor([biggest], dtype=torch.int64, device="cpu" if _is_gloo(dist) else tensor.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    rounds = max(1, -(-int(t.item()) // limit))
+    if biggest is None:
+        t = torch.tensor([max(list(send_counts) + list(recv_counts) + [0])], dtype=torch.int64,
+                         device="cpu" if _is_gloo(dist) else tensor.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        biggest = int(t.item())
+    rounds = max(1, -(-int(biggest) // limit))
     if rounds == 1:
         return _alltoallv_once(dist, tensor, send_counts, recv_counts)
     w = len(send_counts)
@@ -127,50 +131,41 @@ def message_digests(t, counts):
 class ExchangeCheck:
     """Integrity check of the all-to-alls of one sharded step.  An all-to-all has no checksum of its own: a damaged or
     truncated message would come back as a wrong graph with rc 0 (seen once: messages above 2 GiB, see
-    MAX_MESSAGE_BYTES).  Every sender therefore digests each message it sends (message_digests), the digests travel
-    in a second, tiny all-to-all, and the receiver compares them with the digests of what arrived.  The comparisons
-    stay on the device; ``verify`` does the one host sync and raises."""
+    MAX_MESSAGE_BYTES).  Every sender digests each message it sends and every receiver each message that arrived
+    (message_digests, on the device, no host sync); ``verify`` moves ALL of them -- every array exchanged since the last
+    verify -- in ONE all-gather, after which every rank holds every pair's two digests and reaches the same verdict: one
+    collective and one host sync per group of exchanges, and no rank leaves the protocol alone."""
 
     def __init__(self, dist):
-        self.dist, self.bad = dist, []
+        self.dist, self.pending = dist, []
 
-    def alltoallv(self, tensor, send_counts, recv_counts, what):
-        dist = self.dist
-        out = alltoallv(dist, tensor, send_counts, recv_counts)
-        send = message_digests(tensor, send_counts)
-        if _is_gloo(dist):
-            recv = torch.empty(len(recv_counts), dtype=torch.int64)
-            dist.all_to_all_single(recv, send.cpu())
-            recv = recv.to(out.device)
-        else:
-            recv = torch.empty(len(recv_counts), dtype=torch.int64, device=send.device)
-            dist.all_to_all_single(recv, send)
-        self.bad.append((what, message_digests(out, recv_counts) != recv))
+    def alltoallv(self, tensor, send_counts, recv_counts, what, biggest=None):
+        out = alltoallv(self.dist, tensor, send_counts, recv_counts, biggest)
+        self.pending.append((what, message_digests(tensor, send_counts), message_digests(out, recv_counts)))
         return out
 
     def verify(self):
-        """Collective: every rank calls it at the same point.  A rank that received a damaged message must not be the only
-        one to leave the protocol -- the others would block in the next collective until the watchdog fires -- so the
-        per-rank findings travel in one small all-gather and EVERY rank raises, naming (receiver, senders, array)."""
+        """Collective: every rank calls it at the same point, after the same sequence of alltoallv calls.  Raises on EVERY
+        rank, naming (receiver, senders, array) of each damaged message."""
         dist = self.dist
         w = dist.get_world_size()
-        mine = torch.zeros(max(1, len(self.bad)), dtype=torch.int64)
-        for i, (what, flags) in enumerate(self.bad):
-            if flags.numel() and bool(flags.any().item()):
-                mine[i] = sum(1 << r for r, f in enumerate(flags.tolist()) if f)  # bit r: the message from rank r
-        names = [what for what, _ in self.bad]
-        self.bad = []
+        if not self.pending:
+            return
+        names = [what for what, _, _ in self.pending]
+        mine = torch.stack([torch.stack([snd, rcv]) for _, snd, rcv in self.pending])  # [arrays, 2, w]
+        self.pending = []
         if w > 1:
-            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu"
-            send = mine.to(dev)
+            send = mine.cpu() if _is_gloo(dist) else mine
             got = [torch.empty_like(send) for _ in range(w)]
             dist.all_gather(got, send)
-            table = [t.cpu().tolist() for t in got]
+            table = torch.stack(got).cpu()                                               # [rank, arrays, 2, w]
         else:
-            table = [mine.tolist()]
-        found = [(recv, names[i] if i < len(names) else "?", [r for r in range(w) if (mask >> r) & 1])
-                 for recv, row in enumerate(table) for i, mask in enumerate(row) if mask]
-        if found:
+            table = mine.cpu().unsqueeze(0)
+        sent, arrived = table[:, :, 0, :], table[:, :, 1, :]     # sent[s, a, r]: s's digest of its message to r; arrived[r, a, s]
+        bad = sent.permute(2, 1, 0) != arrived                   # [r, a, s]
+        if bool(bad.any()):
+            found = [(r, names[a], [x for x in range(w) if bool(bad[r, a, x])]) for r in range(w) for a in range(len(names))
+                     if bool(bad[r, a].any())]
             text = "; ".join(f"rank {recv} received damaged '{what}' messages from ranks {senders}" for recv, what, senders in found)
             raise RuntimeError(f"sharded build (seen from rank {dist.get_rank()}): {text} "
                                f"(digest of the received bytes != digest the sender computed)")
@@ -180,8 +175,8 @@ class _NoCheck:
     def __init__(self, dist):
         self.dist = dist
 
-    def alltoallv(self, tensor, send_counts, recv_counts, what):
-        return alltoallv(self.dist, tensor, send_counts, recv_counts)
+    def alltoallv(self, tensor, send_counts, recv_counts, what, biggest=None):
+        return alltoallv(self.dist, tensor, send_counts, recv_counts, biggest)
 
     def verify(self):
         pass
@@ -220,9 +215,15 @@ def sharded_build(g, k, dist, check=True):
         recv_counts = [sum(row) for row in sender_buckets]
     else:
         recv_counts = [m_r[3 + me] for m_r in metas]
-    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0")
-    r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1")
-    r_st = xc.alltoallv(st, send_counts, recv_counts, "records st")
+    # every rank knows every pair's record count from the all-gather above: the number of rounds of the exchange is a
+    # local computation (no all-reduce, no host sync between the three arrays)
+    if presplit:
+        big = max(sum(m_r[3 + d * bps: 3 + (d + 1) * bps]) for m_r in metas for d in range(w))
+    else:
+        big = max(m_r[3 + d] for m_r in metas for d in range(w))
+    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0", words * big)
+    r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1", big)
+    r_st = xc.alltoallv(st, send_counts, recv_counts, "records st", big)
     xc.verify()  # before anything is built from them
     if not _is_gloo(dist) and device.type == "cuda":
         torch.cuda.synchronize(device)  # the library works on its own stream
@@ -233,19 +234,20 @@ def sharded_build(g, k, dist, check=True):
 
     # successors owned by other shards: keys out, node ids back.  The library lists the queries
     # grouped by owner with its own group in between: pack the remote groups for the wire.
-    q_recv = exchange_counts(dist, q_counts, device)
-    # every rank must take the same branch (the exchange below is collective): decide on the total over all ranks
-    total_q = torch.tensor([sum(q_counts)], dtype=torch.int64, device="cpu" if _is_gloo(dist) else device)
-    dist.all_reduce(total_q, op=dist.ReduceOp.SUM)
-    if int(total_q.item()):
+    # one all-gather of the query counts: every rank learns what it is asked, whether anybody asks at all (every rank must
+    # take the same branch: the exchange below is collective) and the largest message of the two exchanges
+    q_table = _all_gather_ints(dist, list(q_counts), device)   # q_table[s][d]: rank s asks rank d about that many k-mers
+    q_recv = [row[me] for row in q_table]
+    if sum(sum(row) for row in q_table):
         qw = g.query_words() if hasattr(g, "query_words") else 1  # two-word k-mers: a query is a (lo, hi) pair
+        q_big = max(max(row) for row in q_table)
         groups = [q_keys[qw * s:qw * (s + c)] for s, c in zip(q_starts, q_counts)]
         packed = torch.cat(groups) if groups else q_keys[:0]
-        keys_in = xc.alltoallv(packed, [qw * c for c in q_counts], [qw * c for c in q_recv], "successor queries")
+        keys_in = xc.alltoallv(packed, [qw * c for c in q_counts], [qw * c for c in q_recv], "successor queries", qw * q_big)
         if not _is_gloo(dist) and device.type == "cuda":
             torch.cuda.synchronize(device)
         answers_out = g.shard_answer(keys_in)
-        back = xc.alltoallv(answers_out, q_recv, q_counts, "successor answers")
+        back = xc.alltoallv(answers_out, q_recv, q_counts, "successor answers", q_big)
         xc.verify()
         answers = torch.empty(q_keys.numel() // qw, dtype=torch.int32, device=device)
         off = 0
@@ -281,9 +283,10 @@ def _exchange_records(g, k, dist, xc):
     bps = 512 // w
     sender_buckets = [m_r[3 + me * bps: 3 + (me + 1) * bps] for m_r in metas]
     recv_counts = [sum(row) for row in sender_buckets]
-    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0")
-    r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1")
-    r_st = xc.alltoallv(st, send_counts, recv_counts, "records st")
+    big = max(sum(m_r[3 + d * bps: 3 + (d + 1) * bps]) for m_r in metas for d in range(w))  # largest message of any pair
+    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "records w0", words * big)
+    r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "records w1", big)
+    r_st = xc.alltoallv(st, send_counts, recv_counts, "records st", big)
     xc.verify()
     if not _is_gloo(dist) and device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -301,20 +304,19 @@ def sharded_build_multipass(g, k, dist, n_passes, check=True):
     r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records(g, k, dist, xc)
     device = r_w0.device
     g.shard_build_multipass(k, w, me, P, r_w0, r_w1, r_st, recv_counts, bases, sender_buckets)
-    cdev = "cpu" if _is_gloo(dist) else device
     for p in range(P):
         q_starts, q_counts, q_keys = g.part_queries(p)
         qw = g.query_words() if hasattr(g, "query_words") else 1  # two-word k-mers: a query is a (lo, hi) pair
-        # what I ask every (rank, part) about; the owner learns the split of my message over its parts
-        mine = torch.tensor(q_counts, dtype=torch.int64, device=cdev)
-        theirs = torch.empty_like(mine)
-        dist.all_to_all_single(theirs, mine)          # theirs[s * P + q]: rank s asks my part q about that many k-mers
-        theirs = [int(x) for x in theirs.tolist()]
+        # what I ask every (rank, part) about: one all-gather, after which every rank knows the split of every message over
+        # the owner's parts and the largest message of this pass's two exchanges (no all-reduce inside them)
+        q_table = _all_gather_ints(dist, list(q_counts), device)      # q_table[s][d * P + q]: rank s asks part q of rank d
+        theirs = [q_table[s][me * P + q] for s in range(w) for q in range(P)]   # theirs[s * P + q]: rank s asks my part q
         send = [sum(q_counts[d * P:(d + 1) * P]) for d in range(w)]
         recv = [sum(theirs[s * P:(s + 1) * P]) for s in range(w)]
+        q_big = max(sum(row[d * P:(d + 1) * P]) for row in q_table for d in range(w))
         groups = [q_keys[qw * q_starts[v]:qw * (q_starts[v] + q_counts[v])] for v in range(w * P) if q_counts[v]]
         packed = torch.cat(groups) if groups else q_keys[:0]
-        keys_in = xc.alltoallv(packed, [qw * c for c in send], [qw * c for c in recv], "successor queries")
+        keys_in = xc.alltoallv(packed, [qw * c for c in send], [qw * c for c in recv], "successor queries", qw * q_big)
         if not _is_gloo(dist) and device.type == "cuda":
             torch.cuda.synchronize(device)
         out, pos = [], 0
@@ -325,7 +327,7 @@ def sharded_build_multipass(g, k, dist, n_passes, check=True):
                     out.append(g.part_answer(q, keys_in[qw * pos:qw * (pos + n)]))
                 pos += n
         answers_out = torch.cat(out) if out else torch.empty(0, dtype=torch.int32, device=device)
-        back = xc.alltoallv(answers_out, recv, send, "successor answers")
+        back = xc.alltoallv(answers_out, recv, send, "successor answers", q_big)
         xc.verify()
         if not _is_gloo(dist) and device.type == "cuda":
             torch.cuda.synchronize(device)

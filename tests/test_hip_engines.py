@@ -206,8 +206,10 @@ def test_edge_order_and_pull_reads_from_bucket_records_equal_the_pass_over_the_r
 
 @pytest.mark.parametrize("k", [32, 40, 63])
 @pytest.mark.parametrize("opts", [
-    dict(),                                   # the super-k-mer / LDS engine of dbg_wsk.h, automatic geometry
+    dict(),                                   # the super-k-mer / LDS engine of dbg_wsk.h, automatic geometry; k_wsk_count2 (one hint per slot)
     dict(bucket_bits=3),                      # 8 buckets: every table overflows and is counted in hash sub-ranges
+    dict(wcount_kernel=1),                    # k_wsk_count: successor lookups after the insert (what 64-bit stamps run)
+    dict(wcount_kernel=1, bucket_bits=3),
     dict(bucket_bits=9),
     dict(bucket_bits=14),
     dict(bucket_bits=21),                     # three multisplit levels

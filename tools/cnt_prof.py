@@ -14,6 +14,8 @@ g = _dbg.Graph()
 CK = int(os.environ.get("COUNT_KERNEL", "2"))
 if K <= 31:
     g.set_option("count_kernel", CK)
+else:
+    g.set_option("wcount_kernel", CK)
 g.synth_reads(1, reads * 5, reads, 150, 0.01)
 lib = _dbg.load_library()
 out = (C.c_ulonglong * 64)()
@@ -31,6 +33,12 @@ if K <= 31 and CK == 2:  # k_sk_count2 (dbg_sk2.h)
              5: "barrier after insert", 13: "prefetch of the next bucket", 14: "reservation issue", 6: "pending lookups", 7: "dense list",
              9: "reservation wait + range (thread 0)", 10: "barrier after list", 11: "node write", 12: "barrier after write"}
     main = [0, 1, 3, 4, 5, 13, 14, 6, 7, 9, 10, 11, 12]
+if K > 31 and CK == 2:  # k_wsk_count2 (dbg_wsk2.h)
+    names = {0: "sub-range setup", 13: "top barrier + query atomics + clear", 14: "(first round staged before)", 15: "stage stores", 1: "barrier after stage",
+             3: "dedupe + quad list + query flush + barrier", 4: "insert (+hint) + wave sum", 5: "barrier after insert",
+             6: "reservation issue + prefetch + dense list", 9: "reservation wait + range (thread 0)", 10: "barrier after list",
+             11: "node write (+ next bucket staged)", 12: "deferred lookups"}
+    main = [0, 13, 14, 15, 1, 3, 4, 5, 6, 9, 10, 11, 12]
 tot = sum(out[i] for i in main)
 st = g.stats()
 print(f"{out[31]} workgroups, {tot / out[31]:.0f} clocks each; count {st['ms_count']:.2f} ms, {st['n_buckets']} buckets")
@@ -40,5 +48,5 @@ sub = {20: "(since previous subtick)", 13: "u0 find loop / wide: clear", 14: "u0
 for i, n in sub.items():
     print(f"    sub {n:28s} {100.0 * out[i] / tot:5.1f} %  = {st['ms_count'] * out[i] / tot:6.2f} ms")
 print(f"  events: staged rounds {out[21]}, rounds staged at the top {out[22]}")
-print("  insert clocks per wave (share of wave 0):", " ".join(f"{out[32 + w] / max(1, out[32]):.2f}" for w in range(16)))
+print("  insert (or, -DDBG_CNT_PROF=2 and k_wsk_count2: node write + deferred lookups) clocks per wave (share of wave 0):", " ".join(f"{out[32 + w] / max(1, out[32]):.2f}" for w in range(16)))
 print(f"  quads per round {out[48] / max(1, out[21] + out[22]):.0f}, records per round {out[49] / max(1, out[21] + out[22]):.0f}")

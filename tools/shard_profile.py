@@ -38,8 +38,9 @@ for it in range(3):
     lap("meta_all_gather", t0)
     xc = mg.ExchangeCheck(dist) if os.environ.get("CHECK", "1") == "1" else mg._NoCheck(dist)
     t0 = time.perf_counter()
-    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "w0"); r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "w1")
-    r_st = xc.alltoallv(st, send_counts, recv_counts, "st"); xc.verify(); lap("alltoallv_records(+digests)", t0)
+    big = max(max(send_counts), max(recv_counts))  # (one rank: every pair is this pair)
+    r_w0 = xc.alltoallv(w0, [words * c for c in send_counts], [words * c for c in recv_counts], "w0", words * big); r_w1 = xc.alltoallv(w1, send_counts, recv_counts, "w1", big)
+    r_st = xc.alltoallv(st, send_counts, recv_counts, "st", big); xc.verify(); lap("alltoallv_records(+digests)", t0)
     pre = sender_buckets if os.environ.get("PRESPLIT", "1") == "1" else None
     t0 = time.perf_counter(); q_starts, q_counts, q_keys = g.shard_build(k, w, me, r_w0, r_w1, r_st, recv_counts, bases, pre); lap("shard_build", t0)
     st_ = g.stats()
