@@ -631,7 +631,12 @@ __global__ __launch_bounds__(1024) void k_sk_count2(const SkCount2Args *__restri
 #pragma unroll
                 for (int u = 0; u < NPT; ++u) {
                     if ((uint32_t)(u * NT) >= n_local) break;  // uniform
-                    const uint32_t li = threadIdx.x + u * NT;
+                    // The thread index goes through an opaque move: &s.list[li] and &s.eoff[li] are then computed here.  Hoisted
+                    // out of the bucket loop as induction pointers they lived across all phases and, at the 128-register limit of
+                    // 1024 threads, were spilled to scratch: two memory round trips per round of this loop to reload two additions.
+                    uint32_t tw = threadIdx.x;
+                    asm volatile("" : "+v"(tw));
+                    const uint32_t li = tw + u * NT;
                     uint32_t qmask = 0, e0 = 0, pres = 0, slot_i = 0;
                     unsigned long long key = 0;
                     if (li < n_local) {

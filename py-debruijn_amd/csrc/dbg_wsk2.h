@@ -165,7 +165,12 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
             uint32_t parts = 2;
             while (parts < 16 && (uint64_t)parts * split_recs < r_n) parts <<= 1;
             __syncthreads();
-            if (threadIdx.x < parts) { s.stk_mask[threadIdx.x] = parts - 1; s.stk_val[threadIdx.x] = threadIdx.x; }
+            if (threadIdx.x < parts) {
+                uint32_t td = threadIdx.x;
+                asm volatile("" : "+v"(td));  // (see the directory write below)
+                s.stk_mask[td] = parts - 1;
+                s.stk_val[td] = td;
+            }
             stk_n = parts;
             root = false;
             __syncthreads();
@@ -176,7 +181,20 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
             --stk_n;
             if (!root) { cur_mask = s.stk_mask[stk_n]; cur_val = s.stk_val[stk_n]; }
             root = false;
+#if defined(DBG_CNT_PROF) && DBG_CNT_PROF == 3
+            if (lane == 0) s.prof[32 + wave] = clock64();  // arrival at the top barrier: who is last, and by how much
+#endif
             __syncthreads();
+#if defined(DBG_CNT_PROF) && DBG_CNT_PROF == 3
+            if (threadIdx.x == 0) {
+                unsigned long long mx = 0, mine = s.prof[32];
+                int who = 0;
+                for (int w2 = 0; w2 < WCNT_NT / 64; ++w2) if (s.prof[32 + w2] > mx) { mx = s.prof[32 + w2]; who = w2; }
+                s.prof[50] += mx - mine;
+                s.prof[52 + who / 2] += 1;  // (pairs of waves)
+                s.prof[51] += 1;
+            }
+#endif
             flush_issue();
             if (!clean) {
                 for (int i = threadIdx.x; i < WCAP; i += WCNT_NT) {
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
                     if (!small_bucket && was + p_mult > 0xFFFFu) atomicOr(&wfresh_args(outp)->scalars[0], 512ull);
                 }
 #ifdef DBG_CNT_PROF
-#if DBG_CNT_PROF != 2
+#if DBG_CNT_PROF == 1
                 if ((threadIdx.x & 63) == 0) s.prof[32 + (threadIdx.x >> 6)] += clock64() - wt0_;
 #endif
                 if (threadIdx.x == 0) { s.prof[48] += n_flat; s.prof[49] += n_st; }
@@ -469,12 +487,17 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
 #endif
             const auto &ow = *wfresh_args(outp);  // loaded here, not kept in SGPRs across the whole bucket loop
             if (threadIdx.x < WCAP / 64) {
+                // (the index goes through an opaque move: &s.dir_mask[tid] and &s.dir_base[tid] are then computed here; hoisted out
+                // of the bucket loop they were kept across all phases and, at the 128-register limit, spilled to scratch --
+                // two memory round trips per pass to reload two additions)
+                uint32_t td = threadIdx.x;
+                asm volatile("" : "+v"(td));
                 SkDirEnt de;
-                de.mask = s.dir_mask[threadIdx.x];
-                de.base = (uint32_t)(gbase + s.dir_base[threadIdx.x]);
+                de.mask = s.dir_mask[td];
+                de.base = (uint32_t)(gbase + s.dir_base[td]);
                 de.pad = s.ri < ow.n_buckets ? 1u : 0u;
                 const uint64_t di = s.ri < ow.n_buckets ? s.ri - ow.own_lo : ow.own_cnt + (s.ri - ow.n_buckets);
-                ow.dirs[di * (WCAP / 64) + threadIdx.x] = de;
+                ow.dirs[di * (WCAP / 64) + td] = de;
             }
             // successor of the k-mer in slot `sl` by base b, CSR position e: table lookup; a miss becomes a query
             auto resolve = [&](uint32_t sl, uint32_t b, uint64_t e) {

@@ -230,9 +230,12 @@ def test_traversal_of_more_than_two_to_the_32_nodes():
     removal on the collected neighbourhoods (1.9e6 nodes pulled in 8 reservation rounds) and the contig index through the
     segment skeleton (3.5e8 entries ranked on the device); the index is checked against an independent step-by-step walk of
     sampled starts and through properties that hold at any size.  About a minute with the build."""
+    import gc
     import part_traversal
     import torch
     torch.zeros(1, device="cuda")
+    gc.collect()                # the build below needs most of the card: handles earlier tests dropped, and the blocks torch's
+    torch.cuda.empty_cache()    # caching allocator still holds for them, go back to the driver first
     n, L, k, G = 45_000_000, 150, 31, 225_000_000
     g = _dbg.Graph()
     g.synth_reads(1, G, n, L, 0.05)

@@ -50,3 +50,6 @@ for i, n in sub.items():
 print(f"  events: staged rounds {out[21]}, rounds staged at the top {out[22]}")
 print("  insert (or, -DDBG_CNT_PROF=2 and k_wsk_count2: node write + deferred lookups) clocks per wave (share of wave 0):", " ".join(f"{out[32 + w] / max(1, out[32]):.2f}" for w in range(16)))
 print(f"  quads per round {out[48] / max(1, out[21] + out[22]):.0f}, records per round {out[49] / max(1, out[21] + out[22]):.0f}")
+if out[51]:
+    print(f"  -DDBG_CNT_PROF=3: wave 0 waits at the top barrier {st['ms_count'] * out[50] / tot:.2f} ms for the last wave; the last wave was one of "
+          + ", ".join(f"{2 * i}-{2 * i + 1}: {100.0 * out[52 + i] / out[51]:.0f} %" for i in range(8)))

@@ -12,7 +12,7 @@ import torch  # noqa: E402
 torch.zeros(1, device="cuda")
 import _dbg  # noqa: E402
 
-CASES = ((1000000, 5000000, 150, 0.01, 63), (10000000, 50000000, 150, 0.01, 63), (10000000, 50000000, 150, 0.01, 47))
+CASES = ((1000000, 5000000, 150, 0.01, 63), (10000000, 50000000, 150, 0.01, 63), (10000000, 50000000, 150, 0.01, 47), (10000000, 50000000, 150, 0.01, 32))
 for (n, glen, L, err, k) in CASES:
     g = _dbg.Graph()
     g.synth_reads(1, glen, n, L, err)
