@@ -282,6 +282,8 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange-check", action="store_true", help="sharded builds: skip the per-message digests")
+    ap.add_argument("--chunks", type=int, default=1, help="sharded builds, k <= 31: cut and send the records in this many parts, the "
+                    "exchange of one under the extraction of the next (multi_gpu._exchange_records_in_parts); 1 = one exchange")
     ap.add_argument("--table-hint", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (rest of the path, error-free variant)")
     args = ap.parse_args()
@@ -343,7 +345,7 @@ def main():
             g.build(k, args.table_hint)
             return g
         # one pass per rank: the plain sharded build with (owner byte, 32-bit local id) successors
-        return multi_gpu.sharded_build_multipass(g, k, dist, 1, check=not args.no_exchange_check)
+        return multi_gpu.sharded_build_multipass(g, k, dist, 1, check=not args.no_exchange_check, chunks=args.chunks)
 
     def sync():
         torch.cuda.synchronize()
@@ -392,8 +394,10 @@ def main():
     achieved_step = n_k_rank * b_alg(L, k) / (dt / args.steps) / 1e9
 
     if rank == 0:
-        # 32-bit stamps (a single GPU below 2 GiB of reads): k_sk_count2; 64-bit stamps (shards): k_sk_count; k > 31: k_wsk_count
-        kernel = ("k_sk_count2" if not sharded and reads_per_rank * L < (1 << 31) else "k_sk_count") if k <= 31 else "k_wsk_count"
+        # 32-bit stamps (a single GPU below 2 GiB of reads): k_sk_count2 / k_wsk_count2 (k > 31); 64-bit stamps (shards):
+        # k_sk_count / k_wsk_count
+        narrow = not sharded and reads_per_rank * L < (1 << 31)
+        kernel = ("k_sk_count2" if narrow else "k_sk_count") if k <= 31 else ("k_wsk_count2" if narrow else "k_wsk_count")
         phases = {key: round(sum(p[key] for p in ms_phases) / len(ms_phases), 3)
                   for key in ("ms_extract", "ms_partition", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total")}
         traffic, traffic_src = (pmc_traffic(kernel) if (not sharded and reads_per_rank == 10_000_000 and args.err == 0.01 and
@@ -405,7 +409,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "k": k, "reads_per_gpu": reads_per_rank, "reads_total": n_total, "read_len": L,
                        "err_rate": args.err,
-                       "parallelism": "single table" if not sharded else f"hash-prefix shard x{world} (RCCL alltoallv)"},
+                       "parallelism": "single table" if not sharded else f"hash-prefix shard x{world} (RCCL alltoallv)" + (f", records in {args.chunks} parts" if args.chunks > 1 else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "frac_kernel": achieved / HBM_PEAK_GBS,
                          "frac_step": achieved_step / HBM_PEAK_GBS, "achieved_step": achieved_step,

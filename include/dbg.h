@@ -47,7 +47,7 @@ typedef struct dbg dbg_t;
 #define DBG_E_CAPACITY (-4) /* hash table or an output limit was exceeded */
 #define DBG_E_NOMEM (-5)    /* host or device allocation failed */
 
-#define DBG_ABI_VERSION 4
+#define DBG_ABI_VERSION 5
 
 /* node flag bits (dbg_export_nodes: flags[]) */
 #define DBG_F_INDEG 0x01u    /* Node.indegree (0 or 1), debruijn.py:134,141-142 */
@@ -187,6 +187,12 @@ int dbg_part_keys_hi(dbg_t *h, int part, uint64_t *keys_hi, const void **d_keys_
 int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_shard, int n_passes, const void *d_w0, const void *d_w1,
                               const void *d_st, int stamp_bytes, const uint64_t *recv_counts, const uint64_t *stamp_base,
                               const uint64_t *sender_bucket_counts);
+/* The same with n_senders (1..64) messages in the received arrays: recv_counts[n_senders], stamp_base[n_senders],
+ * sender_bucket_counts[n_senders][512 / n_shards].  A rank that sends its records in parts (dbg_shard_extract_part, so that
+ * the exchange of one part runs while the next is cut) counts as several senders with one stamp base. */
+int dbg_shard_build_multipass_from(dbg_t *h, int k, int n_shards, int my_shard, int n_passes, int n_senders, const void *d_w0,
+                                   const void *d_w1, const void *d_st, int stamp_bytes, const uint64_t *recv_counts,
+                                   const uint64_t *stamp_base, const uint64_t *sender_bucket_counts);
 int dbg_part_queries(dbg_t *h, int part, uint64_t *q_starts, uint64_t *q_counts, const void **d_q_keys);
 int dbg_part_answer(dbg_t *h, int part, const void *d_q_keys, uint64_t n, void *d_answers);
 int dbg_part_apply(dbg_t *h, int part, int owner, const void *d_answers);
@@ -321,6 +327,13 @@ int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const
  * each owner, contiguous and in owner order */
 int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
                       const void **d_st);
+/* dbg_shard_extract for part `part` of n_parts (1..4) slices of this rank's reads, k <= 31: slices of the position space cut at
+ * tile borders -- a k-mer belongs to the slice its first base lies in, so the parts' records together are exactly those of
+ * dbg_shard_extract; the stamps are positions in ALL of the rank's reads either way.  The arrays of part p stay valid until
+ * part p is extracted again (own buffers per part): multi_gpu.sharded_build_multipass(chunks=...) has part p on the wire
+ * while part p + 1 is cut.  dbg_shard_bucket_counts / dbg_shard_record_layout describe the last part extracted. */
+int dbg_shard_extract_part(dbg_t *h, int k, int n_shards, int part, int n_parts, uint64_t *send_counts, const void **d_w0,
+                           const void **d_w1, const void **d_st);
 /* What the last dbg_shard_extract handed out: *w0_words = 64-bit words per record in d_w0 (1: super-k-mer records of
  * k <= 31, or the low key word of the k-mer instances of k > 31 with "wide_engine" 0; 4: the aligned bases of a
  * super-k-mer record of k > 31), *stamp_bytes = bytes per entry of d_st (4; 8 for the instance tuples and for

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DBG_LIB") or os.path.join(_HERE, "libdbg_hip.so")  # 
 DBG_OK, DBG_E_ARG, DBG_E_HIP, DBG_E_ALPHABET, DBG_E_CAPACITY, DBG_E_NOMEM = 0, -1, -2, -3, -4, -5
 F_INDEG, F_KEEP_MASK, F_KEEP_SHIFT, F_BRANCH, F_PULLED = 0x01, 0x1E, 1, 0x20, 0x40
 NO_NODE = 0xFFFFFFFF
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # symbols declared in include/dbg.h; tests check that the library exports every one of them
 SYMBOLS = (
@@ -32,7 +32,7 @@ SYMBOLS = (
     "dbg_export_contig_index", "dbg_export_contig_text", "dbg_device_views", "dbg_shard_extract", "dbg_shard_bucket_counts", "dbg_shard_record_layout", "dbg_shard_build", "dbg_shard_answer", "dbg_shard_apply",
     "dbg_import_graph", "dbg_device_keys_hi",
     "dbg_support_read_scores", "dbg_export_sorted_fasta", "dbg_build_multipass", "dbg_part_count", "dbg_part_sizes", "dbg_export_part", "dbg_part_device_views",
-    "dbg_shard_build_multipass", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
+    "dbg_shard_build_multipass", "dbg_shard_build_multipass_from", "dbg_shard_extract_part", "dbg_part_queries", "dbg_part_answer", "dbg_part_apply", "dbg_multipass_finish",
     "dbg_export_marked", "dbg_part_keys_hi", "dbg_take_reads",
     "dbg_part_prune", "dbg_part_select", "dbg_part_gather", "dbg_part_mark", "dbg_part_clear", "dbg_part_cross_targets",
     "dbg_part_segments", "dbg_part_pflags", "dbg_scan_reads_for_keys", "dbg_set_orders", "dbg_part_segment_text",
@@ -136,6 +136,8 @@ def load_library():
         "dbg_support_read_scores": (C.c_int, [H, vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp, vp]),
         "dbg_part_count": (C.c_int, [H, C.POINTER(C.c_int)]),
         "dbg_shard_build_multipass": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, u64p, u64p, u64p]),
+        "dbg_shard_build_multipass_from": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, u64p, u64p, u64p]),
+        "dbg_shard_extract_part": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int, u64p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
         "dbg_part_queries": (C.c_int, [H, C.c_int, u64p, u64p, C.POINTER(vp)]),
         "dbg_part_answer": (C.c_int, [H, C.c_int, vp, C.c_uint64, vp]),
         "dbg_part_apply": (C.c_int, [H, C.c_int, C.c_int, vp]),
@@ -453,18 +455,21 @@ class Graph:
     # ---- ranks x passes: a rank of a sharded build that builds its shard in parts (multi_gpu.sharded_build_multipass)
     def shard_build_multipass(self, k, n_shards, my_shard, n_passes, w0, w1, st, recv_counts, stamp_base, sender_bucket_counts):
         """Received records (torch tensors, split by the senders' level-1 groups) -> n_passes parts on this handle; part p
-        is virtual shard my_shard * n_passes + p.  Successors owned by other ranks stay open (part_queries)."""
+        is virtual shard my_shard * n_passes + p.  Successors owned by other ranks stay open (part_queries).  The arrays hold
+        len(recv_counts) messages (n_shards, or a multiple when the ranks sent their records in parts: shard_extract_part)."""
         self.generation += 1
-        rc = (C.c_uint64 * n_shards)(*[int(x) for x in recv_counts])
-        sb = (C.c_uint64 * n_shards)(*[int(x) for x in stamp_base])
+        n_senders = len(recv_counts)
+        rc = (C.c_uint64 * n_senders)(*[int(x) for x in recv_counts])
+        sb = (C.c_uint64 * n_senders)(*[int(x) for x in stamp_base])
         flat = [int(x) for row in sender_bucket_counts for x in row]
-        assert len(flat) == 512, "one count per (sender, owned level-1 group)"
-        sbc = (C.c_uint64 * 512)(*flat)
+        if n_shards < 1 or len(stamp_base) != n_senders or len(flat) != n_senders * (512 // n_shards):
+            raise DbgError(-1, "shard_build_multipass: one stamp base per sender and one count per (sender, owned level-1 group)")
+        sbc = (C.c_uint64 * len(flat))(*flat)
         self._keep = [w0, w1, st]
         self._mp_virtual = n_shards * n_passes
-        self._chk(self._lib.dbg_shard_build_multipass(self._h, int(k), int(n_shards), int(my_shard), int(n_passes),
-                                                      C.c_void_p(w0.data_ptr()), C.c_void_p(w1.data_ptr()),
-                                                      C.c_void_p(st.data_ptr()), int(st.element_size()), rc, sb, sbc))
+        self._chk(self._lib.dbg_shard_build_multipass_from(self._h, int(k), int(n_shards), int(my_shard), int(n_passes), n_senders,
+                                                           C.c_void_p(w0.data_ptr()), C.c_void_p(w1.data_ptr()),
+                                                           C.c_void_p(st.data_ptr()), int(st.element_size()), rc, sb, sbc))
         self._keep = []
 
     def part_queries(self, part):
@@ -649,6 +654,21 @@ class Graph:
         words, st_bytes = self.shard_record_layout()
         # k <= 31: super-k-mer records (w0, w1, 32-bit stamp); k > 31: records by value (4 words of bases, meta, 32-bit stamp)
         # or, with "wide_engine" 0, k-mer instances (lo, hi | next << 62, 64-bit meta)
+        return counts, (device_tensor(p0.value, words * n, "int64", dev), device_tensor(p1.value, n, "int64", dev),
+                        device_tensor(p2.value, n, "int32" if st_bytes == 4 else "int64", dev))
+
+    def shard_extract_part(self, k, n_shards, part, n_parts):
+        """shard_extract for slice ``part`` of ``n_parts`` of this rank's reads (k <= 31); the tensors of a part stay valid
+        until that part is extracted again."""
+        counts = (C.c_uint64 * n_shards)()
+        p0, p1, p2 = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.generation += 1
+        self._chk(self._lib.dbg_shard_extract_part(self._h, int(k), int(n_shards), int(part), int(n_parts), counts, C.byref(p0),
+                                                   C.byref(p1), C.byref(p2)))
+        counts = [int(c) for c in counts]
+        n = sum(counts)
+        dev = self.sizes_device()
+        words, st_bytes = self.shard_record_layout()
         return counts, (device_tensor(p0.value, words * n, "int64", dev), device_tensor(p1.value, n, "int64", dev),
                         device_tensor(p2.value, n, "int32" if st_bytes == 4 else "int64", dev))
 

@@ -136,7 +136,7 @@ struct dbg {
         void *p = nullptr;
         uint64_t bytes = 0;
     };
-    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_l2, ar_scan, ar_shard[6], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4];
+    Buf ar_rec[2][3], ar_q[2][3], ar_node[8], ar_misc[9], ar_csr[4], ar_dir, ar_l2, ar_scan, ar_shard[6], ar_walk[3], ar_wide[6], ar_refine[4], ar_tips[4], ar_part[4][3] /* records of dbg_shard_extract_part, per part */;
     int sk_T = 0, sk_l1 = 0, sk_l2 = 0, sk_nb2 = 0 /* scaled second level, 0 = power of two */, sk_cap = 0;
     bool refine_streaming = false;  // option (tests): dbg_refine_edge_order always takes the pass over the reads
     int target_distinct = 0;  // option: mean distinct k-mers per bucket the auto geometry aims at (0 = default)
@@ -1614,6 +1614,7 @@ extern "C" void dbg_destroy(dbg_t *h) {
     for (auto &b : h->ar_wide) buf_free(h, b);
     for (auto &b : h->ar_refine) buf_free(h, b);
     for (auto &b : h->ar_tips) buf_free(h, b);
+    for (auto &lvl : h->ar_part) for (auto &b : lvl) buf_free(h, b);
     buf_free(h, h->ar_scan);
     dev_free(h->d_scalars);
     delete (ShardState *)h->shard_state;
@@ -3291,10 +3292,13 @@ static int multisplit_level(dbg *h, const uint64_t *p_start, const uint64_t *p_c
 // ---- stage 1: K1 extraction into one private segment per persistent workgroup (arena set 0)
 template <class ST>
 static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], uint64_t **seg_start_out,
-                      uint64_t **seg_cnt_out, uint32_t *n_seg_out, uint64_t *n_rec_out) {
+                      uint64_t **seg_cnt_out, uint32_t *n_seg_out, uint64_t *n_rec_out, int part = 0, int n_parts = 1) {
     const int m = sk_m_for_k(k), w = k - m + 1;
     unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
-    const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+    // part p of n_parts: the k-mers whose first base lies in the tiles [T p / n, T (p + 1) / n) (dbg_shard_extract_part)
+    const uint64_t all_tiles = (h->n_bytes + TILE - 1) / TILE;
+    const uint64_t tile_first = all_tiles * (uint64_t)part / (uint64_t)n_parts;
+    const uint64_t tiles = all_tiles * (uint64_t)(part + 1) / (uint64_t)n_parts - tile_first;
     uint64_t sc[8] = {0};
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), 2048);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
@@ -3329,7 +3333,7 @@ static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2]
             if (m == SK_MAX_M && !h->extract_generic) {
 #define DBG_EXW_CASE(W_) case W_: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract_w<ST, W_>), dim3(n_wg), dim3(256), 0, h->stream, \
                                                       h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, \
-                                                      seg_nk, seg_ne, sc_dev); launched = true; break;
+                                                      seg_nk, seg_ne, sc_dev, tile_first); launched = true; break;
                 switch (w) {
                     DBG_EXW_CASE(1) DBG_EXW_CASE(2) DBG_EXW_CASE(3) DBG_EXW_CASE(4) DBG_EXW_CASE(5) DBG_EXW_CASE(6) DBG_EXW_CASE(7)
                     DBG_EXW_CASE(8) DBG_EXW_CASE(9) DBG_EXW_CASE(10) DBG_EXW_CASE(11) DBG_EXW_CASE(12) DBG_EXW_CASE(13)
@@ -3341,7 +3345,7 @@ static int sk_extract(dbg *h, int k, uint64_t *w0[2], uint64_t *w1[2], ST *st[2]
             if (!launched)
                 hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sk_extract<ST>), dim3(n_wg), dim3(256), 0, h->stream, h->d_bases,
                                    h->n_bytes, h->d_startbits, k, m, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk,
-                                   seg_ne, sc_dev);
+                                   seg_ne, sc_dev, tile_first);
             HIPCHK(h, hipGetLastError());
         }
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -4511,13 +4515,21 @@ extern "C" int dbg_shard_record_layout(dbg_t *h, int *w0_words, int *stamp_bytes
 // one-word k-mers: records split by the 512 level-1 groups; ST = width of the rank-local stamps
 template <class ST>
 static int shard_extract_sk(dbg *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
-                            const void **d_st) {
+                            const void **d_st, int part = 0, int n_parts = 1) {
     free_build(h);
     h->stats = dbg_stats_t{};
     uint64_t *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
     ST *st[2];
     uint32_t n_seg = 0;
-    CHK(sk_extract<ST>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    CHK(sk_extract<ST>(h, k, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec, part, n_parts));
+    if (n_parts > 1) {  // the grouped records of every part keep buffers of their own: part p travels while part p + 1 is cut
+        CHK(buf_ensure(h, h->ar_part[part][0], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_part[part][1], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_part[part][2], (n_rec + 16) * sizeof(ST)));
+        w0[1] = (uint64_t *)h->ar_part[part][0].p;
+        w1[1] = (uint64_t *)h->ar_part[part][1].p;
+        st[1] = (ST *)h->ar_part[part][2].p;
+    }
     // group by the 9 top bits of the bucket hash: owners are contiguous ranges of those 512 groups
     const int nb1 = 512;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
@@ -4539,11 +4551,26 @@ static int shard_extract_sk(dbg *h, int k, int n_shards, uint64_t *send_counts, 
     ShardState &sh = shard_of(h);
     sh.n_shards = n_shards;
     sh.k = k;
-    sh.n_kmer_inst_local = h->n_kmer_inst;
+    sh.n_kmer_inst_local = (part ? sh.n_kmer_inst_local : 0) + h->n_kmer_inst;
     sh.l1_counts = cnt;
     sh.rec_words = 1;
     sh.rec_stamp_bytes = (int)sizeof(ST);
     return DBG_OK;
+}
+
+// dbg_shard_extract on one of n_parts slices of this rank's reads (k <= 31): slices of the position space cut at tile
+// borders -- a k-mer belongs to the slice its first base lies in, so the parts' records together are exactly the records of
+// dbg_shard_extract.  The arrays of part p are its own until the next extraction of part p.
+extern "C" int dbg_shard_extract_part(dbg_t *h, int k, int n_shards, int part, int n_parts, uint64_t *send_counts,
+                                      const void **d_w0, const void **d_w1, const void **d_st) {
+    CHK(shard_args_ok(h, k, n_shards));
+    if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
+    if (k > 31) { h->err = "dbg_shard_extract_part: k <= 31 (two-word records travel whole: dbg_shard_extract)"; return DBG_E_ARG; }
+    if (n_parts < 1 || n_parts > 4 || part < 0 || part >= n_parts) { h->err = "dbg_shard_extract_part: 1 <= n_parts <= 4, 0 <= part < n_parts"; return DBG_E_ARG; }
+    const bool st64 = h->n_bytes >= (1ull << 31) || h->shard_stamp64;
+    HIPCHK(h, hipSetDevice(h->device));
+    return st64 ? shard_extract_sk<uint64_t>(h, k, n_shards, send_counts, d_w0, d_w1, d_st, part, n_parts)
+                : shard_extract_sk<uint32_t>(h, k, n_shards, send_counts, d_w0, d_w1, d_st, part, n_parts);
 }
 
 extern "C" int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0,
@@ -5222,7 +5249,18 @@ extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
 extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_shard, int n_passes, const void *d_w0,
                                          const void *d_w1, const void *d_st, int stamp_bytes, const uint64_t *recv_counts,
                                          const uint64_t *stamp_base, const uint64_t *sender_bucket_counts) {
+    return dbg_shard_build_multipass_from(h, k, n_shards, my_shard, n_passes, n_shards, d_w0, d_w1, d_st, stamp_bytes, recv_counts,
+                                          stamp_base, sender_bucket_counts);
+}
+
+// the same with n_senders messages in the received arrays (a rank that sends its records in parts -- dbg_shard_extract_part --
+// is several senders with one stamp base)
+extern "C" int dbg_shard_build_multipass_from(dbg_t *h, int k, int n_shards, int my_shard, int n_passes, int n_senders,
+                                              const void *d_w0, const void *d_w1, const void *d_st, int stamp_bytes,
+                                              const uint64_t *recv_counts, const uint64_t *stamp_base,
+                                              const uint64_t *sender_bucket_counts) {
     CHK(shard_args_ok(h, k, n_shards));
+    if (n_senders < 1 || n_senders > 64) { h->err = "1 <= n_senders <= 64"; return DBG_E_ARG; }
     if (k > 31 && (h->wide_engine != 1 || stamp_bytes != 4)) {
         h->err = "ranks x passes of two-word k-mers: the LDS engine's records by value (\"wide_engine\" 1), 4-byte stamps";
         return DBG_E_ARG;
@@ -5243,9 +5281,9 @@ extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_s
     if (n_passes > 1) { drop_spare_part(h); pool_trim(h); }
     h->stats = dbg_stats_t{};
     const int own_groups = 512 / n_shards;
-    std::vector<uint64_t> off(n_shards), add(n_shards);
+    std::vector<uint64_t> off(n_senders), add(n_senders);
     uint64_t n_rec = 0;
-    for (int r = 0; r < n_shards; ++r) {
+    for (int r = 0; r < n_senders; ++r) {
         uint64_t tot = 0;
         for (int g = 0; g < own_groups; ++g) tot += sender_bucket_counts[(size_t)r * own_groups + g];
         if (tot != recv_counts[r]) { h->err = "sender_bucket_counts do not add up to recv_counts"; return DBG_E_ARG; }
@@ -5262,14 +5300,14 @@ extern "C" int dbg_shard_build_multipass(dbg_t *h, int k, int n_shards, int my_s
         uint64_t *pos = (uint64_t *)h->ar_shard[2].p;
         if (n_rec) hipLaunchKernelGGL(k_wsk_iota128, dim3(grid_for(n_rec, 256)), dim3(256), 0, h->stream, n_rec, pos);
         HIPCHK(h, hipGetLastError());
-        rc = multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
+        rc = multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_senders, sender_bucket_counts,
                                                  off.data(), add.data(), pos, (const uint64_t *)d_w1, (const uint32_t *)d_st,
                                                  (const uint64_t *)d_w0);
     } else
     rc = stamp_bytes == 8
-                 ? multipass_parts<uint64_t, uint64_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
+                 ? multipass_parts<uint64_t, uint64_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_senders, sender_bucket_counts,
                                                        off.data(), add.data(), (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint64_t *)d_st)
-                 : multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_shards, sender_bucket_counts,
+                 : multipass_parts<uint64_t, uint32_t>(h, k, n_shards * n_passes, my_shard * n_passes, n_passes, n_senders, sender_bucket_counts,
                                                        off.data(), add.data(), (const uint64_t *)d_w0, (const uint64_t *)d_w1, (const uint32_t *)d_st);
     if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->arena_freed = true; pool_trim(h); h->err = keep; return rc; }
     // the instance counters describe this rank's parts

@@ -72,10 +72,11 @@ __global__ __launch_bounds__(256) void k_sk_extract(const char *__restrict__ bas
                                                     const uint32_t *__restrict__ startbits, int k, int m,
                                                     uint64_t n_tiles, uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st,
                                                     uint64_t seg_cap, uint64_t *seg_cnt, uint64_t *seg_nk,
-                                                    uint64_t *seg_ne, unsigned long long *scalars /* [0] err */) {
+                                                    uint64_t *seg_ne, unsigned long long *scalars /* [0] err */,
+                                                    uint64_t tile_first /* the n_tiles tiles from here on (dbg_shard_extract_part) */) {
     __shared__ SkLds s;
     __shared__ uint64_t red[8];
-    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t t_beg = tile_first + n_tiles * blockIdx.x / gridDim.x, t_end = tile_first + n_tiles * (blockIdx.x + 1) / gridDim.x;
     const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
     uint64_t cursor = 0;  // records written by this workgroup (uniform)
     const int w = k - m + 1;
@@ -222,13 +223,13 @@ __global__ __launch_bounds__(256, DBG_EXW_WAVES) void k_sk_extract_w(const char 
                                                       const uint32_t *__restrict__ startbits, uint64_t n_tiles,
                                                       uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
                                                       uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
-                                                      unsigned long long *scalars /* [0] err */) {
+                                                      unsigned long long *scalars /* [0] err */, uint64_t tile_first) {
     constexpr int M = SK_MAX_M, K = W + M - 1, NV = 32 + W - 1;
     static_assert(TILE == 256 * 32, "one lane per 32 positions");
     static_assert(K <= 31 && NV + M - 1 <= 64, "window must fit the two 32-base registers");
     __shared__ SkLdsW s;
     __shared__ uint64_t red[8];
-    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t t_beg = tile_first + n_tiles * blockIdx.x / gridDim.x, t_end = tile_first + n_tiles * (blockIdx.x + 1) / gridDim.x;
     const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
     uint64_t cursor = 0;
     constexpr uint32_t mid_mask = (1u << (K - 1)) - 1u;

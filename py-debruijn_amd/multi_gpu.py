@@ -137,12 +137,36 @@ class ExchangeCheck:
     collective and one host sync per group of exchanges, and no rank leaves the protocol alone."""
 
     def __init__(self, dist):
-        self.dist, self.pending = dist, []
+        self.dist, self.pending, self.posted = dist, [], []
 
     def alltoallv(self, tensor, send_counts, recv_counts, what, biggest=None):
         out = alltoallv(self.dist, tensor, send_counts, recv_counts, biggest)
         self.pending.append((what, message_digests(tensor, send_counts), message_digests(out, recv_counts)))
         return out
+
+    def post(self, tensor, send_counts, out, recv_counts, what, biggest):
+        """alltoallv into ``out`` (a 1-D view with room for sum(recv_counts) elements) that does not wait: over nccl the
+        exchange runs on the communicator's stream while the caller goes on (the next part of the records is cut meanwhile);
+        ``wait`` joins all posted exchanges and digests what arrived.  ``tensor`` must stay untouched until then."""
+        dist = self.dist
+        send_counts, recv_counts = list(send_counts), list(recv_counts)
+        work = None
+        if len(send_counts) == 1:
+            out.copy_(tensor[:send_counts[0]])    # one rank: a device copy
+        elif not _is_gloo(dist) and biggest * tensor.element_size() <= MAX_MESSAGE_BYTES:
+            work = dist.all_to_all_single(out, tensor.contiguous(), recv_counts, send_counts, async_op=True)
+        else:                                     # gloo (staged through the host) or messages that go in rounds
+            out.copy_(alltoallv(dist, tensor, send_counts, recv_counts, biggest))
+        self.posted.append((what, work, tensor, out, recv_counts, self._digest(tensor, send_counts)))
+
+    def wait(self):
+        for what, work, _tensor, out, recv_counts, sent in self.posted:
+            if work is not None:
+                work.wait()
+            self.pending.append((what, sent, self._digest(out, recv_counts)))
+        self.posted = []
+
+    _digest = staticmethod(message_digests)
 
     def verify(self):
         """Collective: every rank calls it at the same point, after the same sequence of alltoallv calls.  Raises on EVERY
@@ -173,7 +197,20 @@ class ExchangeCheck:
 
 class _NoCheck:
     def __init__(self, dist):
-        self.dist = dist
+        self.dist, self.posted = dist, []
+
+    def post(self, tensor, send_counts, out, recv_counts, what, biggest):
+        ExchangeCheck.post(self, tensor, send_counts, out, recv_counts, what, biggest)
+
+    def wait(self):
+        for _what, work, _tensor, _out, _rc, _sent in self.posted:
+            if work is not None:
+                work.wait()
+        self.posted = []
+
+    @staticmethod
+    def _digest(t, counts):
+        return None
 
     def alltoallv(self, tensor, send_counts, recv_counts, what, biggest=None):
         return alltoallv(self.dist, tensor, send_counts, recv_counts, biggest)
@@ -293,15 +330,72 @@ def _exchange_records(g, k, dist, xc):
     return r_w0, r_w1, r_st, recv_counts, bases, sender_buckets
 
 
-def sharded_build_multipass(g, k, dist, n_passes, check=True):
+def _exchange_records_in_parts(g, k, dist, xc, chunks):
+    """_exchange_records with the rank's records cut and sent in ``chunks`` parts (dbg_shard_extract_part, k <= 31): part c
+    is on the wire -- three posted all-to-alls on the communicator's stream -- while part c + 1 is extracted and split on
+    the library's stream.  The receiver sees chunks x world senders: sender c * world + r = part c of rank r, all parts of a
+    rank with that rank's stamp base.  The receive buffers are sized from the first part (parts are equal slices of the
+    reads) with 15 % to spare and grown by a copy if a later part turns out larger."""
+    w, me = dist.get_world_size(), dist.get_rank()
+    bps = 512 // w
+    bufs, cap, cursor = None, 0, 0
+    recv_all, rows_all, bases = [], [], None
+    for c in range(chunks):
+        send_counts, (w0, w1, st) = g.shard_extract_part(k, w, c, chunks)
+        device = w0.device
+        words = g.shard_record_layout()[0]
+        st_bytes = st.element_size()
+        metas = _all_gather_ints(dist, [g.sizes()["n_bytes"], words, st_bytes] + g.shard_bucket_counts(), device)
+        if any(m_r[1] != words for m_r in metas):
+            raise RuntimeError("sharded build: the ranks disagree about the record layout (different engines or input sizes)")
+        if max(m_r[2] for m_r in metas) > st_bytes:
+            st = widen_stamps(st)
+        if bases is None:
+            bases, acc = [], 0
+            for m_r in metas:
+                bases.append(acc)
+                acc += m_r[0]
+        rows = [m_r[3 + me * bps: 3 + (me + 1) * bps] for m_r in metas]
+        recv_counts = [sum(row) for row in rows]
+        big = max(sum(m_r[3 + d * bps: 3 + (d + 1) * bps]) for m_r in metas for d in range(w))
+        n_in = sum(recv_counts)
+        if bufs is None or cursor + n_in > cap:
+            new_cap = cursor + (int(n_in * (chunks - c) * 1.15) + 4096 if c + 1 < chunks else n_in)
+            xc.wait()  # (growing: the posted exchanges write into the old buffers)
+            new = [torch.empty(words * new_cap, dtype=torch.int64, device=device), torch.empty(new_cap, dtype=torch.int64, device=device),
+                   torch.empty(new_cap, dtype=st.dtype, device=device)]
+            if bufs is not None:
+                for old_b, new_b, mult in zip(bufs, new, (words, 1, 1)):
+                    new_b[:mult * cursor] = old_b[:mult * cursor]
+            bufs, cap = new, new_cap
+        xc.post(w0, [words * x for x in send_counts], bufs[0][words * cursor: words * (cursor + n_in)], [words * x for x in recv_counts],
+                f"records w0, part {c}", words * big)
+        xc.post(w1, send_counts, bufs[1][cursor: cursor + n_in], recv_counts, f"records w1, part {c}", big)
+        xc.post(st, send_counts, bufs[2][cursor: cursor + n_in], recv_counts, f"records st, part {c}", big)
+        cursor += n_in
+        recv_all += recv_counts
+        rows_all += rows
+    xc.wait()
+    xc.verify()
+    if not _is_gloo(dist) and device.type == "cuda":
+        torch.cuda.synchronize(device)
+    return bufs[0][:words * cursor], bufs[1][:cursor], bufs[2][:cursor], recv_all, bases * chunks, rows_all
+
+
+def sharded_build_multipass(g, k, dist, n_passes, check=True, chunks=1):
     """Ranks x passes (BASELINE.json configs[3]: shards that outgrow one 32-bit id space): every rank builds its shard
     as ``n_passes`` parts (dbg_shard_build_multipass); part p of rank r is virtual shard r * n_passes + p.  Successors
     owned by another rank are resolved pass by pass -- the same p on every rank at a time: keys out, part-local node ids
     back (two all-to-alls per pass).  Afterwards ``g.export_part(p)`` / ``g.part_tensors(p)`` hold the rank's parts with
-    ``col_part`` = the virtual shard of every successor."""
+    ``col_part`` = the virtual shard of every successor.
+    chunks > 1 (k <= 31): the records are cut and sent in that many parts, the exchange of one part under the extraction of the
+    next (_exchange_records_in_parts); the graph is the same."""
     w, me, P = dist.get_world_size(), dist.get_rank(), int(n_passes)
     xc = ExchangeCheck(dist) if check else _NoCheck(dist)
-    r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records(g, k, dist, xc)
+    if chunks > 1 and k <= 31 and hasattr(g, "shard_extract_part"):
+        r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records_in_parts(g, k, dist, xc, int(chunks))
+    else:
+        r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records(g, k, dist, xc)
     device = r_w0.device
     g.shard_build_multipass(k, w, me, P, r_w0, r_w1, r_st, recv_counts, bases, sender_buckets)
     for p in range(P):

@@ -42,7 +42,13 @@ class InProcDist:
         if t.is_cuda:
             torch.cuda.synchronize(t.device)
 
-    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
+    class _Done:
+        """What an asynchronous collective returns (torch.distributed's Work): here the exchange has already happened."""
+
+        def wait(self):
+            return True
+
+    def all_to_all_single(self, out, inp, out_splits=None, in_splits=None, async_op=False):
         w, n = self._w, self._w.n
         if in_splits is None:
             in_splits = [inp.numel() // n] * n
@@ -61,6 +67,7 @@ class InProcDist:
             pos += c
         self._sync(out)
         w.barrier.wait()
+        return self._Done() if async_op else None
 
     def all_reduce(self, t, op=None):
         w = self._w

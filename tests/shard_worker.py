@@ -143,6 +143,21 @@ class NumpyMultipassGraph(NumpyShardGraph):
         idx = torch.tensor(order, dtype=torch.int64)
         return counts, (w0[idx], w1[idx], st[idx])
 
+    def shard_extract_part(self, k, n, part, n_parts):
+        """Model of dbg_shard_extract_part: the records whose first base lies in slice ``part`` of the rank's position space."""
+        _, (w0, w1, st) = self.shard_extract(k, n)
+        total = max(1, self.sizes()["n_bytes"])
+        stl = st.numpy().view(np.uint64 if st.dtype == torch.int64 else np.uint32)
+        keep = [i for i in range(w0.numel()) if min(n_parts - 1, (int(stl[i]) >> 1) * n_parts // total) == part]
+        keys = [int(x) for x in w0.numpy().view(np.uint64)[keep]] if keep else []
+        self.l1 = [0] * 512
+        counts = [0] * n
+        for key in keys:
+            self.l1[self.group(key)] += 1
+            counts[self.owner(key, n)] += 1
+        idx = torch.tensor(keep, dtype=torch.int64)
+        return counts, (w0[idx], w1[idx], st[idx])
+
     def shard_record_layout(self):
         return 1, 8 if self.stamp64 else 4
 
@@ -228,7 +243,7 @@ def main():
     if mode == "fake_mp":  # ranks x passes over gloo: the parts of this rank, one npz entry per array and part
         n_passes = int(os.environ.get("SHARD_PASSES", "2"))
         g = NumpyMultipassGraph([row.tobytes().decode() for row in reads], k, stamp64=(rank == 0))
-        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes, chunks=int(os.environ.get("SHARD_CHUNKS", "1")))
         out = {}
         for p, d in enumerate(g.parts):
             out[f"keys{p}"] = np.array(d["keys"], dtype=np.uint64)
@@ -244,7 +259,7 @@ def main():
         n_passes = int(os.environ.get("SHARD_PASSES", "2"))
         g = _dbg.Graph(device=0)
         g.set_reads(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64))
-        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes, chunks=int(os.environ.get("SHARD_CHUNKS", "1")))
         t, flags, br, pu = part_traversal.construct_graph(g, k, 2, dist)
         ctg = part_traversal.output_contigs(t)
         texts = ctg.texts(range(len(ctg)))

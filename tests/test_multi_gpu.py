@@ -26,7 +26,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_ranks(mode, world, tmp_path, k, n_reads, read_len, max_msg=None):
+def run_ranks(mode, world, tmp_path, k, n_reads, read_len, max_msg=None, chunks=None):
     port = free_port()
     procs = []
     for rank in range(world):
@@ -34,6 +34,8 @@ def run_ranks(mode, world, tmp_path, k, n_reads, read_len, max_msg=None):
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
         if max_msg:
             env["SHARD_MAX_MSG"] = str(max_msg)
+        if chunks:
+            env["SHARD_CHUNKS"] = str(chunks)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "shard_worker.py"), mode, str(tmp_path), str(k),
                                        str(n_reads), str(read_len)], env=env))
     for p in procs:
@@ -97,11 +99,12 @@ def test_exchange_logic_on_cpu_gloo(world, max_msg, tmp_path):
         assert np.all(m["succ"][~has, code] == 0xFFFFFFFF)
 
 
-def test_ranks_times_passes_on_cpu_gloo(tmp_path):
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_ranks_times_passes_on_cpu_gloo(tmp_path, chunks):
     """multi_gpu.sharded_build_multipass with real torch.distributed (gloo, 2 processes x 2 passes; rank 0 hands out
-    64-bit stamps): same checks as the in-process run below."""
+    64-bit stamps): same checks as the in-process run below.  chunks = 2: the records cut and sent in two parts."""
     world, n_passes, k, n_reads, read_len = 2, 2, 9, 64, 40
-    files = run_ranks("fake_mp", world, tmp_path, k, n_reads, read_len)
+    files = run_ranks("fake_mp", world, tmp_path, k, n_reads, read_len, chunks=chunks)
     parts = [{key: f[f"{key}{p}"] for key in ("keys", "stamps", "counts", "succ_part", "succ_id")} for f in files for p in range(n_passes)]
     reads = np.concatenate([rank_reads(world, r, n_reads, read_len) for r in range(world)])
     want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
@@ -143,8 +146,10 @@ def test_eight_ranks_in_process_exchange_logic_on_cpu(wide_stamp_ranks):
     check(inproc_dist.run_ranks(8, one), 8, k, n_reads, read_len)
 
 
-@pytest.mark.parametrize("ranks,n_passes,wide_stamp_ranks", [(4, 2, ()), (2, 4, (1,)), (8, 1, ()), (1, 4, ())])
-def test_ranks_times_passes_exchange_logic_on_cpu(ranks, n_passes, wide_stamp_ranks):
+@pytest.mark.parametrize("ranks,n_passes,wide_stamp_ranks,chunks", [(4, 2, (), 1), (2, 4, (1,), 1), (8, 1, (), 1), (1, 4, (), 1),
+                                                                   # the records cut and sent in parts (dbg_shard_extract_part)
+                                                                   (8, 1, (), 2), (4, 2, (2,), 3), (1, 1, (), 4)])
+def test_ranks_times_passes_exchange_logic_on_cpu(ranks, n_passes, wide_stamp_ranks, chunks):
     """multi_gpu.sharded_build_multipass (BASELINE.json configs[3]: ranks x passes) around the numpy model of
     dbg_shard_build_multipass / dbg_part_*: the parts of all ranks together hold every k-mer of the reads once, with
     the counts of a single table, and every successor -- same part, another part of the rank, another rank -- names
@@ -156,7 +161,7 @@ def test_ranks_times_passes_exchange_logic_on_cpu(ranks, n_passes, wide_stamp_ra
     def one(dist, rank):
         g = shard_worker.NumpyMultipassGraph([row.tobytes().decode() for row in rank_reads(ranks, rank, n_reads, read_len)], k,
                                              stamp64=rank in wide_stamp_ranks)
-        multi_gpu.sharded_build_multipass(g, k, dist, n_passes)
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes, chunks=chunks)
         return g.parts
 
     parts = [d for rank_parts in inproc_dist.run_ranks(ranks, one) for d in rank_parts]  # index = virtual shard
@@ -182,22 +187,32 @@ def test_ranks_times_passes_exchange_logic_on_cpu(ranks, n_passes, wide_stamp_ra
     assert ranks == 1 or crossing > 0
 
 
-def test_damaged_exchange_is_detected():
-    """multi_gpu.ExchangeCheck: a message that arrives with one wrong word must raise, not build a wrong graph."""
+@pytest.mark.parametrize("posted", [False, True])
+def test_damaged_exchange_is_detected(posted):
+    """multi_gpu.ExchangeCheck: a message that arrives with one wrong word must raise, not build a wrong graph.
+    posted: the exchange that does not wait (ExchangeCheck.post / wait: records sent in parts)."""
     import multi_gpu
     import torch
 
     class Corrupting(inproc_dist.InProcDist):
-        def all_to_all_single(self, out, inp, out_splits=None, in_splits=None):
-            super().all_to_all_single(out, inp, out_splits, in_splits)
+        def all_to_all_single(self, out, inp, out_splits=None, in_splits=None, async_op=False):
+            work = super().all_to_all_single(out, inp, out_splits, in_splits, async_op)
             if out_splits is not None and self.get_rank() == 1 and out.numel() > 3:
                 out[3] += 1  # one flipped value in what rank 1 received
+            return work
 
     def one(dist, rank):
         dist.__class__ = Corrupting
         xc = multi_gpu.ExchangeCheck(dist)
         t = torch.arange(10, dtype=torch.int64) + 100 * rank
-        xc.alltoallv(t, [5, 5], [5, 5], "test")
+        if posted:
+            out = torch.empty(10, dtype=torch.int64)
+            xc.post(t, [5, 5], out, [5, 5], "test", 5)
+            xc.wait()
+            if rank == 0:
+                assert out.tolist() == [0, 1, 2, 3, 4, 100, 101, 102, 103, 104]
+        else:
+            xc.alltoallv(t, [5, 5], [5, 5], "test")
         try:
             xc.verify()
         except RuntimeError as e:
@@ -250,8 +265,8 @@ def test_two_ranks_on_one_gpu(k, n_reads, read_len, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,world,n_passes", [(31, 2, 2), (63, 4, 1)])
-def test_traversal_in_parts_over_real_processes(k, world, n_passes, tmp_path):
+@pytest.mark.parametrize("k,world,n_passes,chunks", [(31, 2, 2, 1), (63, 4, 1, 1), (31, 2, 1, 2)])
+def test_traversal_in_parts_over_real_processes(k, world, n_passes, chunks, tmp_path):
     """part_traversal with one PROCESS per rank (gloo; the ranks share the box's GPU): every rank ends with the same
     branch_kmer / already_pull_out / contigs as the reference restatement on all reads, and the pull-out flags of the ranks,
     in rank order, are the reference's pull_out_read."""
@@ -261,7 +276,7 @@ def test_traversal_in_parts_over_real_processes(k, world, n_passes, tmp_path):
     n_reads, read_len = 4000, 120
     os.environ["SHARD_PASSES"] = str(n_passes)
     try:
-        files = run_ranks("gpu_parts", world, tmp_path, k, n_reads, read_len)
+        files = run_ranks("gpu_parts", world, tmp_path, k, n_reads, read_len, chunks=chunks)  # chunks = 2: records sent in two parts
     finally:
         del os.environ["SHARD_PASSES"]
     per = n_reads // world

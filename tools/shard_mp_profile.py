@@ -23,7 +23,9 @@ check = os.environ.get("CHECK", "1") == "1"
 g = _dbg.Graph(device=0)
 g.synth_reads(1, n * 5, n, 150, 0.01)
 for name, fn in (("sharded_build (tagged ids)", lambda: mg.sharded_build(g, k, dist, check=check)),
-                 (f"sharded_build_multipass P={P} (owner bytes)", lambda: mg.sharded_build_multipass(g, k, dist, P, check=check))):
+                 (f"sharded_build_multipass P={P} (owner bytes)", lambda: mg.sharded_build_multipass(g, k, dist, P, check=check)),
+                 (f"sharded_build_multipass P={P}, records in 2 parts", lambda: mg.sharded_build_multipass(g, k, dist, P, check=check, chunks=2)),
+                 (f"sharded_build_multipass P={P}, records in 4 parts", lambda: mg.sharded_build_multipass(g, k, dist, P, check=check, chunks=4))):
     ts = []
     for it in range(4):
         torch.cuda.synchronize()
