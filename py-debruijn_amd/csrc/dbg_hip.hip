@@ -5846,9 +5846,13 @@ extern "C" int dbg_part_segment_text(dbg_t *h, int part, const void *d_entries, 
     return DBG_OK;
 }
 
-__global__ __launch_bounds__(256) void k_part_clear(uint64_t n_words, uint32_t keep4, uint32_t *pflags_words) {
+__global__ __launch_bounds__(256) void k_part_clear(uint64_t n_words, uint32_t keep4, uint32_t *pflags_words, uint32_t rest) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) pflags_words[i] &= keep4;
+    else if (i == n_words) {  // the last partial word, byte by byte
+        uint8_t *tail = reinterpret_cast<uint8_t *>(pflags_words + n_words);
+        for (uint32_t q = 0; q < rest; ++q) tail[q] &= (uint8_t)keep4;
+    }
 }
 
 // clears flag bits on every node of the part (a mark of one phase, before the next phase uses the bit)
@@ -5859,17 +5863,10 @@ extern "C" int dbg_part_clear(dbg_t *h, int part, uint32_t bits) {
     if (!sub->n_nodes || !mp->pflags[part]) return DBG_OK;
     HIPCHK(h, hipSetDevice(h->device));
     const uint32_t keep = ~bits & 0xFFu, keep4 = keep * 0x01010101u;
-    const uint64_t n_words = sub->n_nodes / 4;  // hipMalloc'd: whole words up to the last partial one, which goes byte by byte
-    if (n_words) hipLaunchKernelGGL(k_part_clear, dim3(grid_for(n_words, 256)), dim3(256), 0, h->stream, n_words, keep4, (uint32_t *)mp->pflags[part]);
+    const uint64_t n_words = sub->n_nodes / 4;
+    hipLaunchKernelGGL(k_part_clear, dim3(grid_for(n_words + 1, 256)), dim3(256), 0, h->stream, n_words, keep4, (uint32_t *)mp->pflags[part],
+                       (uint32_t)(sub->n_nodes - n_words * 4));
     HIPCHK(h, hipGetLastError());
-    const uint64_t rest = sub->n_nodes - n_words * 4;
-    if (rest) {
-        uint8_t tail[4] = {0, 0, 0, 0};
-        HIPCHK(h, hipMemcpyAsync(tail, mp->pflags[part] + n_words * 4, rest, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        for (uint64_t q = 0; q < rest; ++q) tail[q] &= (uint8_t)keep;
-        HIPCHK(h, hipMemcpyAsync(mp->pflags[part] + n_words * 4, tail, rest, hipMemcpyHostToDevice, h->stream));
-    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return DBG_OK;
 }

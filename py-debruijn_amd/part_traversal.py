@@ -262,35 +262,35 @@ class PartTraversal:
         o = torch.argsort(got["gid"])                      # sorted by global id on the device: the join below is a binary search
         got = {c: t[o] for c, t in got.items()}
         pos_t = torch.searchsorted(got["gid"], torch.where(got["succ"] >= 0, got["succ"], torch.zeros_like(got["succ"]))).clamp_(max=max(n - 1, 0))
-        m = {c: t.cpu().numpy() for c, t in got.items()}
-        assert n == 0 or np.all(m["gid"][1:] != m["gid"][:-1]), "a node was collected twice"
         pulled_gid = np.empty(0, dtype=np.int64)
-        ranks = np.empty(0, dtype=np.uint64)
         if n:
-            keep = ((m["pflags"][:, None] >> (F_KEEP_SHIFT + np.arange(4)[None, :])) & 1).astype(bool)
-            full = (m["dist"] < TIP_REACH)[:, None]
-            counts = np.where(keep & full, m["counts"], 0).astype(np.uint32)   # pruned edges and the outermost ring: no successors
-            pos = pos_t.cpu().numpy()
-            found = (m["gid"][pos] == m["succ"]) & (counts != 0)
-            assert np.all(found == (counts != 0)), "a kept successor inside the neighbourhood was not collected"
-            succ = np.where(found, pos, NO_NODE).astype(np.uint32)
-            # Counter order: exact for the branch nodes (the only nodes whose successor order the DFS can see)
-            # any permutation serves a node with at most one kept successor; the DFS sees the order at branch nodes only
-            order = np.full(n, 0xE4, dtype=np.uint8)
+            # the mini-graph stays on the device: masked counts, successors as positions in the sorted list, rank bytes
+            dev = self.device
+            ar4 = torch.arange(4, device=dev)
+            keep = ((got["pflags"][:, None] >> (F_KEEP_SHIFT + ar4[None, :])) & 1) == 1
+            full = (got["dist"] < TIP_REACH)[:, None]
+            counts = torch.where(keep & full, got["counts"], torch.zeros_like(got["counts"]))  # pruned edges and the outermost ring: no successors
+            found = (got["gid"][pos_t] == got["succ"]) & (counts != 0)
+            dup = (got["gid"][1:] == got["gid"][:-1]).any() if n > 1 else torch.zeros((), dtype=torch.bool, device=dev)
+            ok = torch.stack([~dup, (found == (counts != 0)).all()]).cpu().tolist()   # one host sync for both checks
+            assert ok[0], "a node was collected twice"
+            assert ok[1], "a kept successor inside the neighbourhood was not collected"
+            succ = torch.where(found, pos_t, torch.full_like(pos_t, -1))
+            # Counter order: exact for the branch nodes (the only nodes whose successor order the DFS can see);
+            # any permutation serves a node with at most one kept successor
+            order = torch.full((n,), 0xE4, dtype=torch.uint8, device=dev)
             b = self.branch
-            bpos = np.searchsorted(m["gid"], b["gid"])
-            order[bpos] = self._order_bytes(counts[bpos], self.first_seen)
+            if b["gid"].size:
+                bpos = torch.searchsorted(got["gid"], torch.from_numpy(b["gid"].astype(np.int64)).to(dev))
+                order[bpos] = torch.from_numpy(self._order_bytes(counts[bpos].cpu().numpy(), self.first_seen)).to(dev)
             helper = _dbg.Graph(device=g.sizes_device())
             try:
                 helper.set_reads(np.frombuffer(b"A", dtype=np.uint8), np.array([0, 1], dtype=np.uint64))  # import wants a read set
-                dev = self.device
-                tk = torch.from_numpy(m["keys"].astype(np.int64)).to(dev)
-                th = torch.from_numpy(m["keys_hi"].astype(np.int64)).to(dev)
-                ts = torch.from_numpy(m["stamps"].astype(np.int64)).to(dev)
-                tc = torch.from_numpy(counts.view(np.int32).reshape(-1).copy()).to(dev)
-                tsu = torch.from_numpy(succ.view(np.int32).reshape(-1).copy()).to(dev)
-                helper.import_graph(self.k, [n], tk, ts, tc, tsu, th if self.k > 31 else None)
-                helper.set_orders(order)
+                tc = counts.to(torch.int32).reshape(-1).contiguous()     # (the uint32 counts in int32 / int64 clothes)
+                tsu = succ.to(torch.int32).reshape(-1).contiguous()      # -1 = NO_NODE
+                helper.import_graph(self.k, [n], got["keys"].contiguous(), got["stamps"].contiguous(), tc, tsu,
+                                    got["keys_hi"].contiguous() if self.k > 31 else None)
+                helper.set_orders(order.cpu().numpy())
                 helper.prune(self.threshold)
                 helper.remove_tips()
                 _, _, _, hflags = helper.export_nodes(keys=False, stamps=False, counts=False)
@@ -300,8 +300,10 @@ class PartTraversal:
                 helper.close()
             sel = np.nonzero(hflags & F_PULLED)[0]
             sel = sel[np.argsort(hr[sel], kind="stable")]
-            pulled_gid, ranks = m["gid"][sel], hr[sel]
-            self.pulled = {"gid": pulled_gid, "keys": m["keys"][sel].astype(np.uint64), "keys_hi": m["keys_hi"][sel].astype(np.uint64)}
+            st = torch.from_numpy(sel.astype(np.int64)).to(dev)
+            pulled_gid = got["gid"][st].cpu().numpy()
+            self.pulled = {"gid": pulled_gid, "keys": got["keys"][st].cpu().numpy().astype(np.uint64),
+                           "keys_hi": got["keys_hi"][st].cpu().numpy().astype(np.uint64)}
         else:
             self.pulled = {"gid": pulled_gid, "keys": np.empty(0, np.uint64), "keys_hi": np.empty(0, np.uint64)}
         # every rank computed the same list: it marks its own nodes
