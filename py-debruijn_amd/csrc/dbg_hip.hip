@@ -127,6 +127,7 @@ struct dbg {
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
     int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
     int count_kernel_u64 = 1; // option "count_kernel_u64": the same choice for 64-bit stamps (measured: 1)
+    int resolve_sorted = 0;  // option "resolve_sorted" 1: cross-bucket queries grouped by the 512 level-1 groups of their target before k_succ_resolve.  Measured (tools/resolve_ab.py, 10 M reads): 3.09 ms with the grouping against 2.05 ms in the askers' order -- off
     int wcount_kernel = 2;   // 32 <= k <= 63, 32-bit stamps: 2 = k_wsk_count2 (one successor hint per slot, deferred lookups), 1 = k_wsk_count
     int count_kernel = 2;    // k <= 31, 4096 slots: 2 = k_sk_count2 (successor hints, 16-bit counters; falls back to 1 on counter overflow), 1 = k_sk_count
 
@@ -2126,6 +2127,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
     if (n == "count_kernel" && (value == 1 || value == 2)) { h->count_kernel = (int)value; return DBG_OK; }
+    if (n == "resolve_sorted" && value >= 0 && value <= 2) { h->resolve_sorted = (int)value; return DBG_OK; }
     if (n == "wcount_kernel" && (value == 1 || value == 2)) { h->wcount_kernel = (int)value; return DBG_OK; }
     if (n == "count_kernel_u64" && (value == 1 || value == 2)) { h->count_kernel_u64 = (int)value; return DBG_OK; }
     if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
@@ -3609,11 +3611,11 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         for (int set = 0; set < 2; ++set) {
             CHK(buf_ensure(h, h->ar_q[set][0], q_cap * 8));
             CHK(buf_ensure(h, h->ar_q[set][2], q_cap * 4));
-            if (shard_bits) CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
+            if (shard_bits || h->resolve_sorted) CHK(buf_ensure(h, h->ar_q[set][1], q_cap * 8));
             qk[set] = (uint64_t *)h->ar_q[set][0].p;
             qm[set] = (uint64_t *)h->ar_q[set][1].p;
             qc[set] = (uint32_t *)h->ar_q[set][2].p;
-            if (!shard_bits) break;  // the second set is the owner split's output
+            if (!shard_bits && !h->resolve_sorted) break;  // the second set is the output of the owner split / the target grouping
         }
         Timer t(h->stream);
         HIPCHK(h, hipMemsetAsync(h->d_scalars, 0, 64 * 8, h->stream));
@@ -3736,10 +3738,29 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
             n_q = root[1];
             qset = 1;
         }
+        const uint64_t *q_meta = nullptr;
+        if (!shard_bits && h->resolve_sorted && (n_q >= (1u << 20) || (h->resolve_sorted == 2 && n_q))) {  // 2: at any size (tests)
+            // (experiment, off by default) The queries leave the count kernel in the ASKERS' bucket order and their targets are
+            // anywhere: two dependent random lines of HBM each (directory entry, key run).  Grouped by the 512 level-1 groups of
+            // the TARGET, the queries in flight at any time look into a few groups' directories and keys (6 MB a group).  The
+            // bucket hash is computed once, for the split, and handed to the resolver.  The split (20 B per query read and
+            // written, a histogram pass) costs more than the resolver gains: 3.09 vs 2.05 ms at 3.7e7 queries.
+            hipLaunchKernelGGL(k_q_bucket, dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream, qk[0], qm[0], n_q, k, m);
+            HIPCHK(h, hipGetLastError());
+            CHK(buf_ensure(h, h->ar_misc[7], 1024 * 16 + 16));
+            uint64_t *q_seg = (uint64_t *)h->ar_misc[7].p;
+            HIPCHK(h, hipMemcpyAsync(q_seg, root, 16, hipMemcpyHostToDevice, h->stream));
+            uint64_t *o_start = q_seg + 2, *o_cnt = o_start + 512;
+            CHK((multisplit_level<uint32_t, true>(h, q_seg, q_seg + 1, 1, 1, n_q, qk[0], qm[0], qc[0], qk[1], qm[1], qc[1],
+                                                  40 + SK_BUCKET_BITS - 9, 512, o_start, o_cnt, h->ar_misc[2], h->ar_misc[3],
+                                                  h->ar_misc[4])));
+            qset = 1;
+            q_meta = qm[1];
+        }
         if (n_q) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_succ_resolve<CAP>), dim3(grid_for(n_q, 256)), dim3(256), 0, h->stream,
                                qk[qset] + root[0], qc[qset] + root[0], n_q, geom, ranges, n_buckets, n_ranges, dirs, h->d_keys,
-                               h->n_nodes, h->d_col, id_tag, sc_dev);
+                               h->n_nodes, h->d_col, id_tag, sc_dev, q_meta);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -4726,7 +4747,7 @@ extern "C" int dbg_shard_answer(dbg_t *h, const void *d_q_keys, uint64_t n, void
     } else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_succ_resolve<4096>), dim3(grid_for(n, 256)), dim3(256), 0, h->stream,
                        (const uint64_t *)d_q_keys, (const uint32_t *)nullptr, n, h->sk_geom, ranges, h->sk_n_buckets,
-                       h->sk_n_ranges, dirs, h->d_keys, h->n_nodes, (uint32_t *)d_answers, 0u, sc_dev);
+                       h->sk_n_ranges, dirs, h->d_keys, h->n_nodes, (uint32_t *)d_answers, 0u, sc_dev, (const uint64_t *)nullptr);
     HIPCHK(h, hipGetLastError());
     uint64_t sc0 = 0;
     HIPCHK(h, hipMemcpyAsync(&sc0, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -5051,6 +5072,7 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
         sub->count_kernel = h->count_kernel;
         sub->count_kernel_u64 = h->count_kernel_u64;
         sub->wcount_kernel = h->wcount_kernel;
+        sub->resolve_sorted = h->resolve_sorted;
         sub->target_distinct = h->target_distinct;
         sub->est_scale_pct = h->est_scale_pct;
         if (!sub->d_scalars) HIPCHK(h, hipMalloc((void **)&sub->d_scalars, 128 * sizeof(uint64_t)));

@@ -1342,11 +1342,12 @@ __global__ __launch_bounds__(256) void k_succ_resolve(const uint64_t *__restrict
                                                       uint64_t n_buckets, uint64_t n_ranges,
                                                       const SkDirEnt *__restrict__ dirs, const uint64_t *__restrict__ keys,
                                                       uint64_t n_nodes, uint32_t *out, uint32_t id_tag,
-                                                      unsigned long long *scalars) {
+                                                      unsigned long long *scalars,
+                                                      const uint64_t *__restrict__ q_meta /* NULL, or k_q_bucket's words: the bucket hash in bits 40.. */) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t key = q_key[i];
-    const uint64_t bucket = sk_bucket_of(kmer_bucket22(key, g.k, g.m), g);
+    const uint64_t bucket = sk_bucket_of(q_meta ? (uint32_t)(q_meta[i] >> 40) : kmer_bucket22(key, g.k, g.m), g);
     uint32_t id = NO_NODE;
     if (bucket >= g.own_lo && bucket < g.own_lo + g.own_cnt) {
         // common case: the bucket is one range and its directory says so -- two dependent reads (directory entry, key

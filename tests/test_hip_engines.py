@@ -342,6 +342,19 @@ def test_count_kernel_16_bit_counters_fall_back_to_32_bit(k):
     assert g1.stats()["count_launches"] == 1 and np.array_equal(table(g1, k)[2], want["counts"])
 
 
+@pytest.mark.parametrize("k,opts", [(31, dict()), (21, dict(bucket_bits=9)), (31, dict(bucket_bits=3)), (13, dict(bucket_bits=14))])
+def test_resolver_with_queries_grouped_by_target(k, opts):
+    """Option "resolve_sorted" (off by default: measured slower): the cross-bucket queries are split by the 512
+    level-1 groups of their target and the resolver takes the bucket hash from the split's key words -- same graph."""
+    reads = synth.reads_ascii(23, 60000, 6000, 100, 0.01)
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, 100, dtype=np.uint64), k)
+    g = build(reads, k, resolve_sorted=2, **opts)
+    assert g.stats()["n_queries"] > 0
+    keys, stamps, counts, flags, succ, keys_raw = table(g, k)
+    assert np.array_equal(keys, want["keys"]) and np.array_equal(stamps, want["stamps"]) and np.array_equal(counts, want["counts"])
+    check_succ(keys_raw, g.export_nodes()[2], g.export_succ(), k)
+
+
 @pytest.mark.parametrize("opts", [dict(), dict(bucket_bits=9), dict(bucket_bits=3), dict(bucket_bits=14)])
 def test_both_count_kernels_write_the_same_graph(opts):
     """k_sk_count (lookups after the insert) and k_sk_count2 (successor hints, pending list) on the same reads and geometry:
