@@ -200,7 +200,7 @@ class Graph:
         self.generation = 0  # bumped whenever the handle's graph or reads are replaced (debruijn.output_contigs checks it)
         self.walks = 0       # bumped by every walk: the device contigs of an earlier walk are gone (ContigList.sorted_fasta checks it)
         for var, opt in (("DBG_ENGINE", "engine"), ("DBG_BUCKET_BITS", "bucket_bits"), ("DBG_LDS_SLOTS", "lds_slots"),
-                         ("DBG_WALK_JUMP_MIN", "walk_jump_min_nodes")):
+                         ("DBG_WALK_JUMP_MIN", "walk_jump_min_nodes"), ("DBG_STAMP64", "stamp64")):
             if os.environ.get(var, "") != "":
                 self.set_option(opt, int(os.environ[var]))
 

@@ -127,6 +127,7 @@ struct dbg {
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
     int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
     int count_kernel_u64 = 1; // option "count_kernel_u64": the same choice for 64-bit stamps (measured: 1)
+    int stamp64 = 0;         // option "stamp64" 1: dbg_build keeps 64-bit stamps even for reads below 2 GiB (what reads of 2 GiB and more get by themselves; tests)
     int resolve_sorted = 0;  // option "resolve_sorted" 1: cross-bucket queries grouped by the 512 level-1 groups of their target before k_succ_resolve.  Measured (tools/resolve_ab.py, 10 M reads): 3.09 ms with the grouping against 2.05 ms in the askers' order -- off
     int wcount_kernel = 2;   // 32 <= k <= 63, 32-bit stamps: 2 = k_wsk_count2 (one successor hint per slot, deferred lookups), 1 = k_wsk_count
     int count_kernel = 2;    // k <= 31, 4096 slots: 2 = k_sk_count2 (successor hints, 16-bit counters; falls back to 1 on counter overflow), 1 = k_sk_count
@@ -2127,6 +2128,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
     if (n == "count_kernel" && (value == 1 || value == 2)) { h->count_kernel = (int)value; return DBG_OK; }
+    if (n == "stamp64" && (value == 0 || value == 1)) { h->stamp64 = (int)value; return DBG_OK; }
     if (n == "resolve_sorted" && value >= 0 && value <= 2) { h->resolve_sorted = (int)value; return DBG_OK; }
     if (n == "wcount_kernel" && (value == 1 || value == 2)) { h->wcount_kernel = (int)value; return DBG_OK; }
     if (n == "count_kernel_u64" && (value == 1 || value == 2)) { h->count_kernel_u64 = (int)value; return DBG_OK; }
@@ -4203,12 +4205,12 @@ static int build_wsk_t(dbg *h, int k) {
                              0, 0, nullptr);
 }
 
-// 32-bit stamps only (reads below 2 GiB: with 64-bit stamps the 4096-slot table does not fit the LDS); larger inputs and
-// graphs with an edge seen more than 65 535 times (16-bit LDS counters) take the global-table engine
+// Reads of 2 GiB and more keep 64-bit stamps (k_wsk_count<uint64_t>: 128 staged records per round beside the wider stamp
+// array; round 2 sent them to the global-table engine).  Graphs with an edge seen more than 65 535 times (16-bit LDS
+// counters) take the global-table engine.
 static int build_wsk(dbg *h, int k, bool *fallback) {
     *fallback = false;
-    if (h->n_bytes >= (1ull << 31)) { *fallback = true; return DBG_E_CAPACITY; }
-    int rc = build_wsk_t<uint32_t>(h, k);
+    int rc = (h->n_bytes >= (1ull << 31) || h->stamp64) ? build_wsk_t<uint64_t>(h, k) : build_wsk_t<uint32_t>(h, k);
     if (rc == DBG_E_CAPACITY && h->err == "16-bit successor counter overflow") *fallback = true;
     return rc;
 }
@@ -4224,7 +4226,7 @@ static int build_sk_t(dbg *h, int k, uint64_t node_capacity_hint) {
 }
 
 static int build_sk(dbg *h, int k, uint64_t node_capacity_hint) {
-    const bool small = (h->n_bytes < (1ull << 31));
+    const bool small = (h->n_bytes < (1ull << 31)) && !h->stamp64;
     // 64-bit stamps (inputs of 2 GiB and more, or a sharded build) use the smaller record staging
     if (!small) return build_sk_t<uint64_t, 4096>(h, k, node_capacity_hint);
     if (h->lds_slots == 2048) return build_sk_t<uint32_t, 2048>(h, k, node_capacity_hint);
@@ -5106,10 +5108,8 @@ static int multipass_parts(dbg *h, int k, int n_virtual, int v_first, int n_pass
         pre.in_st = in_st;
         int rc = DBG_OK;
         if (n_rec_p && pk) {
-            if constexpr (sizeof(STI) == 4)
-                rc = wsk_count<ST, uint32_t>(sub, k, pk, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w, in_w0,
-                                             in_w1, (const ST *)nullptr, pw0, pw1, pst, shard_bits, v_first + p, &pre);
-            else { sub->err = "two-word records carry 32-bit rank-local stamps"; rc = DBG_E_ARG; }
+            rc = wsk_count<ST, STI>(sub, k, pk, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w, in_w0,
+                                    in_w1, (const ST *)nullptr, pw0, pw1, pst, shard_bits, v_first + p, &pre);
         } else if (n_rec_p)
             rc = sk_count_from_segments<ST, 4096, STI>(sub, k, nullptr, nullptr, 0, n_rec_p, n_rec_p * (uint64_t)w, n_rec_p * (uint64_t)w,
                                                        in_w0, in_w1, (const ST *)nullptr, pw0, pw1, pst, 0, shard_bits, v_first + p, &pre);
@@ -5204,27 +5204,28 @@ static int build_multipass_t(dbg *h, int k, int n_passes) {
 }
 
 // two-word k-mers (k = 32..63, reads below 2 GiB): records by position into the packed reads, split by the 512 level-1 groups
+template <class ST>  // uint32_t; uint64_t for reads of 2 GiB and more
 static int build_multipass_wsk(dbg *h, int k, int n_passes) {
     uint64_t *pk = nullptr, *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
-    uint32_t *st[2];
+    ST *st[2];
     uint32_t n_seg = 0;
-    CHK(wsk_extract<uint32_t>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    CHK(wsk_extract<ST>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
     const int nb1 = 512;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
     std::vector<uint64_t> cnt(nb1), start(nb1);
     {
         Timer t(h->stream);
-        CHK((multisplit_level<uint32_t, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
-                                              6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3],
-                                              h->ar_misc[4], 0, nullptr, nullptr, h->host_seg_cnt.data())));
+        CHK((multisplit_level<ST, true>(h, seg_start, seg_cnt, n_seg, n_seg, n_rec, w0[0], w1[0], st[0], w0[1], w1[1], st[1],
+                                        6 + SK_BUCKET_BITS - 9, nb1, c1_start, c1_cnt, h->ar_misc[2], h->ar_misc[3],
+                                        h->ar_misc[4], 0, nullptr, nullptr, h->host_seg_cnt.data())));
         HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipMemcpyAsync(start.data(), c1_start, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
         h->stats.ms_partition = t.stop();
         for (auto &b : h->ar_rec[0]) buf_free(h, b);
     }
     const uint64_t off0 = start[0], add0 = 0;
-    int rc = multipass_parts<uint32_t, uint32_t>(h, k, n_passes, 0, n_passes, 1, cnt.data(), &off0, &add0, w0[1], w1[1], st[1], pk);
+    int rc = multipass_parts<ST, ST>(h, k, n_passes, 0, n_passes, 1, cnt.data(), &off0, &add0, w0[1], w1[1], st[1], pk);
     for (auto &b : h->ar_rec[1]) buf_free(h, b);
     buf_free(h, h->ar_wide[0]);
     return rc;
@@ -5233,8 +5234,8 @@ static int build_multipass_wsk(dbg *h, int k, int n_passes) {
 extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     if (!h) return DBG_E_ARG;
     if (k < 1 || k > 63) { h->err = "multi-pass builds take k in 1..63"; return DBG_E_ARG; }
-    if (k > 31 && (h->wide_engine != 1 || h->n_bytes >= (1ull << 31))) {
-        h->err = "multi-pass builds of two-word k-mers use the LDS engine (\"wide_engine\" 1) on reads below 2 GiB";
+    if (k > 31 && h->wide_engine != 1) {
+        h->err = "multi-pass builds of two-word k-mers use the LDS engine (\"wide_engine\" 1)";
         return DBG_E_ARG;
     }
     if (n_passes < 1 || n_passes > 64 || (n_passes & (n_passes - 1))) { h->err = "n_passes must be a power of two up to 64"; return DBG_E_ARG; }
@@ -5253,8 +5254,9 @@ extern "C" int dbg_build_multipass(dbg_t *h, int k, int n_passes) {
     if (!h->is_dna) { h->err = "multi-pass builds take ACGT reads"; return DBG_E_ALPHABET; }
     h->k = k;
     Timer t_total(h->stream);
-    int rc = k > 31 ? build_multipass_wsk(h, k, n_passes)
-                    : (h->n_bytes < (1ull << 31)) ? build_multipass_t<uint32_t>(h, k, n_passes) : build_multipass_t<uint64_t>(h, k, n_passes);
+    const bool narrow = h->n_bytes < (1ull << 31) && !h->stamp64;
+    int rc = k > 31 ? (narrow ? build_multipass_wsk<uint32_t>(h, k, n_passes) : build_multipass_wsk<uint64_t>(h, k, n_passes))
+                    : narrow ? build_multipass_t<uint32_t>(h, k, n_passes) : build_multipass_t<uint64_t>(h, k, n_passes);
     if (rc != DBG_OK) { const std::string keep = h->err; free_build(h); h->arena_freed = true; pool_trim(h); h->err = keep; return rc; }
     h->stats.ms_build_total = t_total.stop();
     h->arena_freed = true;

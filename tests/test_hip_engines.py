@@ -51,6 +51,8 @@ def build(reads2d, k, **opts):
     dict(engine=0, bucket_bits=18),
     dict(engine=0, bucket_bits=22),                  # three multisplit levels: 10 + 10 + 2 bits, all 22 of the bucket hash
     dict(engine=0, bucket_bits=1, lds_slots=2048),   # forces LDS overflow splits
+    dict(engine=0, stamp64=1),                       # 64-bit stamps (reads of 2 GiB and more): k_sk_count<uint64_t>
+    dict(engine=0, stamp64=1, bucket_bits=3),
 ])
 def test_engine_matches_c_oracle(k, opts):
     reads = synth.reads_ascii(7, 60000, 6000, 100, 0.01)
@@ -210,6 +212,8 @@ def test_edge_order_and_pull_reads_from_bucket_records_equal_the_pass_over_the_r
     dict(bucket_bits=3),                      # 8 buckets: every table overflows and is counted in hash sub-ranges
     dict(wcount_kernel=1),                    # k_wsk_count: successor lookups after the insert (what 64-bit stamps run)
     dict(wcount_kernel=1, bucket_bits=3),
+    dict(stamp64=1),                          # 64-bit stamps: what reads of 2 GiB and more get (k_wsk_count<uint64_t>)
+    dict(stamp64=1, bucket_bits=3),
     dict(bucket_bits=9),
     dict(bucket_bits=14),
     dict(bucket_bits=21),                     # three multisplit levels

@@ -82,6 +82,20 @@ def test_golden_case(name):
         assert_same(got, ref, inp["final"], name + " (reference)")
 
 
+@pytest.mark.parametrize("name", [n for n in golden_case_names() if n.startswith("dna_")])
+def test_golden_case_with_64_bit_stamps(name, monkeypatch):
+    """What reads of 2 GiB and more run (64-bit stamps in the records, the LDS tables and the node arrays: k_sk_count<uint64_t>,
+    k_wsk_count<uint64_t> -- the two-word engine took the global-table fallback there before round 3), forced at the size of the
+    reference's vectors: the whole path must give the same dictionaries, orders and contigs."""
+    monkeypatch.setenv("DBG_STAMP64", "1")
+    case = load_golden(name)
+    reads = case_reads(case)
+    inp = case["inputs"]
+    got = run_product(reads, inp["k"], inp["threshold"], inp["final"])
+    want = run_oracle(reads, inp["k"], inp["threshold"], inp["final"])
+    assert_same(got, want, inp["final"], name)
+
+
 @pytest.mark.parametrize("family,n_min", [("fuzz_small", 400), ("fuzz_peptide", 240), ("fuzz_wide", 160), ("fuzz_peptide_wide", 120)])
 def test_fuzz_family_against_reference_vectors(family, n_min):
     """fuzz_small: sub-alphabets of ACGT (2-bit path); fuzz_peptide: amino acids (generic 5-bit path);
