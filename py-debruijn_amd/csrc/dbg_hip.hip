@@ -25,6 +25,7 @@
 #include "dbg_device.h"
 #include "dbg_sk.h"
 #include "dbg_sk2.h"
+#include "dbg_sk3.h"
 #include "dbg_wsk2.h"
 #include "dbg_generic.h"
 #include "dbg_genref.h"
@@ -126,7 +127,7 @@ struct dbg {
     int phase_limit = 0;     // ablation of k_sk_count (timing only; the build then fails on purpose)
     int est_scale_pct = 100; // test hook: scales the distinct-k-mer estimate (a low one exercises the capacity retry)
     int wide_engine = 1;     // k = 32..63: 1 = super-k-mer / LDS engine (dbg_wsk.h), 0 = global reference-keyed table (dbg_wide.h)
-    int count_kernel_u64 = 1; // option "count_kernel_u64": the same choice for 64-bit stamps (measured: 1)
+    int count_kernel_u64 = 3; // option "count_kernel_u64": the count kernel of 64-bit stamps (shards, reads of 2 GiB and more): 3 = k_sk_count3 (one hint per slot; 12.2 ms on a 10 M-read shard), 1 = k_sk_count (13.4), 2 = k_sk_count2 (15.5: 320 staged records)
     int stamp64 = 0;         // option "stamp64" 1: dbg_build keeps 64-bit stamps even for reads below 2 GiB (what reads of 2 GiB and more get by themselves; tests)
     int resolve_sorted = 0;  // option "resolve_sorted" 1: cross-bucket queries grouped by the 512 level-1 groups of their target before k_succ_resolve.  Measured (tools/resolve_ab.py, 10 M reads): 3.09 ms with the grouping against 2.05 ms in the askers' order -- off
     int wcount_kernel = 2;   // 32 <= k <= 63, 32-bit stamps: 2 = k_wsk_count2 (one successor hint per slot, deferred lookups), 1 = k_wsk_count
@@ -2131,7 +2132,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "stamp64" && (value == 0 || value == 1)) { h->stamp64 = (int)value; return DBG_OK; }
     if (n == "resolve_sorted" && value >= 0 && value <= 2) { h->resolve_sorted = (int)value; return DBG_OK; }
     if (n == "wcount_kernel" && (value == 1 || value == 2)) { h->wcount_kernel = (int)value; return DBG_OK; }
-    if (n == "count_kernel_u64" && (value == 1 || value == 2)) { h->count_kernel_u64 = (int)value; return DBG_OK; }
+    if (n == "count_kernel_u64" && value >= 1 && value <= 3) { h->count_kernel_u64 = (int)value; return DBG_OK; }
     if (n == "shard_node_limit" && value >= 0 && value < (1ll << 29)) { h->shard_node_limit = (uint64_t)value; return DBG_OK; }
     h->err = "unknown option or value out of range: " + n;
     return DBG_E_ARG;
@@ -3606,7 +3607,9 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
     // k_sk_count2 for 32-bit stamps; with 64-bit stamps (sharded builds, reads of 2 GiB and more) its LDS leaves room for
     // 320 staged records where the first kernel stages 640, and it loses: 15.4 vs 13.9 ms on a 10 M-read shard
-    bool use_count2 = CAP == 4096 && h->count_kernel == 2 && !h->phase_limit && (sizeof(ST) == 4 || h->count_kernel_u64 == 2);
+    bool use_count2 = CAP == 4096 && h->count_kernel == 2 && !h->phase_limit && (sizeof(ST) == 4 || h->count_kernel_u64 >= 2);
+    // 64-bit stamps: k_sk_count3 (one hint per slot, 768 staged records) where k_sk_count2's layout leaves room for 320
+    const bool use_count3 = use_count2 && sizeof(ST) == 8 && h->count_kernel_u64 == 3;
     int extra_attempts = 0;
     for (int attempt = 0; attempt < 3 + extra_attempts; ++attempt) {
         CHK(ensure_node_arrays());
@@ -3633,8 +3636,8 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (est_distinct > 0.0 && n_rec)
             split_recs = (uint32_t)std::min<double>(1e9, std::max<double>(64.0, (CAP * 0.80) / (est_distinct / (double)n_rec)));
         if (use_count2 && n_rec) {
-            auto kern2 = k_sk_count2<ST>;
-            const size_t lds2 = sizeof(Cnt2Lds<ST>);
+            auto kern2 = use_count3 ? k_sk_count3<ST> : k_sk_count2<ST>;
+            const size_t lds2 = use_count3 ? sizeof(Cnt3Lds<ST>) : sizeof(Cnt2Lds<ST>);
             HIPCHK(h, hipFuncSetAttribute((const void *)kern2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             int n_cu = 256;
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -3676,7 +3679,8 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
         if (sc[0] & (8 | 32)) break;  // not a sizing problem
         bool again = false;
         if (use_count2 && (sc[0] & (512 | 2048))) {
-            if (sc[0] & 2048) { h->err = "internal: k_sk_count2 counted a bucket's nodes, edges or queries inconsistently"; return DBG_E_HIP; }
+            // (a wrapped 16-bit counter reads 0 twice: k_sk_count3 then reports the overflow AND a mismatch of its two counts)
+            if ((sc[0] & 2048) && !(sc[0] & 512)) { h->err = "internal: k_sk_count2 / k_sk_count3 counted a bucket's nodes, edges or queries inconsistently"; return DBG_E_HIP; }
             use_count2 = false;  // an edge seen more than 65 535 times: the kernel with 32-bit counters
             ++extra_attempts;
             again = true;

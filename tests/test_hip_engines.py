@@ -51,8 +51,13 @@ def build(reads2d, k, **opts):
     dict(engine=0, bucket_bits=18),
     dict(engine=0, bucket_bits=22),                  # three multisplit levels: 10 + 10 + 2 bits, all 22 of the bucket hash
     dict(engine=0, bucket_bits=1, lds_slots=2048),   # forces LDS overflow splits
-    dict(engine=0, stamp64=1),                       # 64-bit stamps (reads of 2 GiB and more): k_sk_count<uint64_t>
+    dict(engine=0, stamp64=1),                       # 64-bit stamps (reads of 2 GiB and more, shards)
     dict(engine=0, stamp64=1, bucket_bits=3),
+    dict(engine=0, stamp64=1, count_kernel_u64=1),   # ... on k_sk_count (lookups after the insert)
+    dict(engine=0, stamp64=1, count_kernel_u64=3),   # ... on k_sk_count3 (one hint per slot, deferred lookups)
+    dict(engine=0, stamp64=1, count_kernel_u64=3, bucket_bits=3),
+    dict(engine=0, stamp64=1, count_kernel_u64=3, bucket_bits=9),
+    dict(engine=0, stamp64=1, count_kernel_u64=2),   # ... on k_sk_count2 (320 staged records)
 ])
 def test_engine_matches_c_oracle(k, opts):
     reads = synth.reads_ascii(7, 60000, 6000, 100, 0.01)
@@ -344,6 +349,10 @@ def test_count_kernel_16_bit_counters_fall_back_to_32_bit(k):
     check_succ(keys_raw, counts_raw, succ, k)
     g1 = build(reads, k, count_kernel=1)   # the first kernel needs one launch
     assert g1.stats()["count_launches"] == 1 and np.array_equal(table(g1, k)[2], want["counts"])
+    g3 = build(reads, k, stamp64=1, count_kernel_u64=3)   # k_sk_count3 (64-bit stamps) has 16-bit counters too
+    assert g3.stats()["count_launches"] == 2
+    t3 = table(g3, k)
+    assert np.array_equal(t3[0], want["keys"]) and np.array_equal(t3[1], want["stamps"]) and np.array_equal(t3[2], want["counts"])
 
 
 @pytest.mark.parametrize("k,opts", [(31, dict()), (21, dict(bucket_bits=9)), (31, dict(bucket_bits=3)), (13, dict(bucket_bits=14))])

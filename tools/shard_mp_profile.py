@@ -22,6 +22,8 @@ n, k, P = int(float(os.environ.get("READS", "10")) * 1e6), int(os.environ.get("K
 check = os.environ.get("CHECK", "1") == "1"
 g = _dbg.Graph(device=0)
 g.synth_reads(1, n * 5, n, 150, 0.01)
+if os.environ.get("CK64"):
+    g.set_option("count_kernel_u64", int(os.environ["CK64"]))  # 1 = k_sk_count, 2 = k_sk_count2, 3 = k_sk_count3 for the shards' 64-bit stamps
 for name, fn in (("sharded_build (tagged ids)", lambda: mg.sharded_build(g, k, dist, check=check)),
                  (f"sharded_build_multipass P={P} (owner bytes)", lambda: mg.sharded_build_multipass(g, k, dist, P, check=check)),
                  (f"sharded_build_multipass P={P}, records in 2 parts", lambda: mg.sharded_build_multipass(g, k, dist, P, check=check, chunks=2)),
