@@ -395,9 +395,9 @@ def main():
 
     if rank == 0:
         # 32-bit stamps (a single GPU below 2 GiB of reads): k_sk_count2 / k_wsk_count2 (k > 31); 64-bit stamps (shards):
-        # k_sk_count / k_wsk_count
+        # k_sk_count3 / k_wsk_count
         narrow = not sharded and reads_per_rank * L < (1 << 31)
-        kernel = ("k_sk_count2" if narrow else "k_sk_count") if k <= 31 else ("k_wsk_count2" if narrow else "k_wsk_count")
+        kernel = ("k_sk_count2" if narrow else "k_sk_count3") if k <= 31 else ("k_wsk_count2" if narrow else "k_wsk_count")
         phases = {key: round(sum(p[key] for p in ms_phases) / len(ms_phases), 3)
                   for key in ("ms_extract", "ms_partition", "ms_count", "ms_compact", "ms_succ", "ms_csr", "ms_build_total")}
         traffic, traffic_src = (pmc_traffic(kernel) if (not sharded and reads_per_rank == 10_000_000 and args.err == 0.01 and
