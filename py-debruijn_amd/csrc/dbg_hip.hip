@@ -2128,7 +2128,7 @@ extern "C" int dbg_set_option(dbg_t *h, const char *name, int64_t value) {
     if (n == "refine_streaming" && (value == 0 || value == 1)) { h->refine_streaming = value != 0; return DBG_OK; }
     if (n == "walk_jump_min_nodes" && value >= 0) { h->walk_jump_min = (uint64_t)value; return DBG_OK; }
     if (n == "wide_engine" && (value == 0 || value == 1)) { h->wide_engine = (int)value; return DBG_OK; }
-    if (n == "count_kernel" && (value == 1 || value == 2)) { h->count_kernel = (int)value; return DBG_OK; }
+    if (n == "count_kernel" && value >= 1 && value <= 3) { h->count_kernel = (int)value; return DBG_OK; }
     if (n == "stamp64" && (value == 0 || value == 1)) { h->stamp64 = (int)value; return DBG_OK; }
     if (n == "resolve_sorted" && value >= 0 && value <= 2) { h->resolve_sorted = (int)value; return DBG_OK; }
     if (n == "wcount_kernel" && (value == 1 || value == 2)) { h->wcount_kernel = (int)value; return DBG_OK; }
@@ -3607,9 +3607,10 @@ static int sk_count_from_segments(dbg *h, int k, const uint64_t *seg_start, cons
     SkDirEnt *dirs = (SkDirEnt *)h->ar_dir.p;
     // k_sk_count2 for 32-bit stamps; with 64-bit stamps (sharded builds, reads of 2 GiB and more) its LDS leaves room for
     // 320 staged records where the first kernel stages 640, and it loses: 15.4 vs 13.9 ms on a 10 M-read shard
-    bool use_count2 = CAP == 4096 && h->count_kernel == 2 && !h->phase_limit && (sizeof(ST) == 4 || h->count_kernel_u64 >= 2);
-    // 64-bit stamps: k_sk_count3 (one hint per slot, 768 staged records) where k_sk_count2's layout leaves room for 320
-    const bool use_count3 = use_count2 && sizeof(ST) == 8 && h->count_kernel_u64 == 3;
+    bool use_count2 = CAP == 4096 && h->count_kernel >= 2 && !h->phase_limit && (sizeof(ST) == 4 || h->count_kernel_u64 >= 2);
+    // 64-bit stamps: k_sk_count3 (one hint per slot, 768 staged records) where k_sk_count2's layout leaves room for 320;
+    // "count_kernel" 3 runs it for 32-bit stamps too (A/B: tools/sweep.py)
+    const bool use_count3 = use_count2 && ((sizeof(ST) == 8 && h->count_kernel_u64 == 3) || h->count_kernel == 3);
     int extra_attempts = 0;
     for (int attempt = 0; attempt < 3 + extra_attempts; ++attempt) {
         CHK(ensure_node_arrays());
