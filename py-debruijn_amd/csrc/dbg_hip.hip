@@ -5713,29 +5713,46 @@ __device__ inline uint32_t pf_kept_col(uint32_t flags_present, uint32_t pf, uint
 // pass 0: counts per owner; pass 1: the targets, grouped by owner (cursor[v] starts at the group's offset).  A workgroup
 // counts its edges per owner in LDS and takes ONE global atomic per owner it met: per-edge atomics on 64 cursors are
 // same-address atomics, ~12 ns each and serialised chip-wide (0.35 s per pass for the 2.9e7 cross edges of a 10 M-read graph).
+constexpr int PART_CROSS_TILES = 64;  // tiles of 256 nodes per workgroup
 __global__ __launch_bounds__(256) void k_part_cross(uint64_t n, int me, const uint8_t *__restrict__ flags, const uint8_t *__restrict__ pflags,
                                                     const uint32_t *__restrict__ rowptr, const uint32_t *__restrict__ col,
                                                     const uint8_t *__restrict__ col_owner, unsigned long long *cursor /* [64] */,
                                                     uint32_t *targets) {
+    // A workgroup owns 64 tiles: it counts their cross edges per owner in LDS, reserves ONE range per owner it met, and (fill
+    // pass) walks the tiles again with LDS cursors.  One reservation per tile was 3.5e5 workgroups x 3 owners of same-address
+    // atomics per pass and part: 6 ms of a 13 ms call at 9e7 nodes.
     __shared__ uint32_t bin[64];
     __shared__ unsigned long long base[64];
     if (threadIdx.x < 64) bin[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int ow = -1;
-    uint32_t tgt = 0, rank = 0;
-    if (i < n) {
+    const uint64_t i0 = (uint64_t)blockIdx.x * (256 * PART_CROSS_TILES);
+    auto cross = [&](uint64_t i, uint32_t *tgt) -> int {
+        if (i >= n) return -1;
         const uint32_t pf = pflags[i];
-        if (pf_chain(pf)) {
-            const uint32_t e = pf_kept_col(flags[i], pf, rowptr[i]);
-            const int o = col_owner[e];
-            if (o != me) { ow = o & 63; tgt = col[e]; rank = atomicAdd(&bin[ow], 1u); }
-        }
+        if (!pf_chain(pf)) return -1;
+        const uint32_t e = pf_kept_col(flags[i], pf, rowptr[i]);
+        const int o = col_owner[e];
+        if (o == me) return -1;
+        *tgt = col[e];
+        return o & 63;
+    };
+    for (int t = 0; t < PART_CROSS_TILES; ++t) {
+        uint32_t tgt;
+        const int ow = cross(i0 + (uint64_t)t * 256 + threadIdx.x, &tgt);
+        if (ow >= 0) atomicAdd(&bin[ow], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 64 && bin[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)bin[threadIdx.x]);
+    if (threadIdx.x < 64) {
+        if (bin[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)bin[threadIdx.x]);
+        bin[threadIdx.x] = 0;  // the fill pass's running cursor
+    }
+    if (!targets) return;
     __syncthreads();
-    if (ow >= 0 && targets) targets[base[ow] + rank] = tgt;
+    for (int t = 0; t < PART_CROSS_TILES; ++t) {
+        uint32_t tgt = 0;
+        const int ow = cross(i0 + (uint64_t)t * 256 + threadIdx.x, &tgt);
+        if (ow >= 0) targets[base[ow] + atomicAdd(&bin[ow], 1u)] = tgt;
+    }
 }
 
 // Kept edges of this part's chain nodes that leave the part: the local ids of their targets IN the target's part, grouped by
@@ -5751,7 +5768,7 @@ extern "C" int dbg_part_cross_targets(dbg_t *h, int part, uint64_t *counts, void
     unsigned long long *cur = (unsigned long long *)(h->d_scalars + 64);  // 64 words: the descriptor slot is free outside a build
     HIPCHK(h, hipMemsetAsync(cur, 0, 64 * 8, h->stream));
     const int me = mp->v_first + part;
-    hipLaunchKernelGGL(k_part_cross, dim3(grid_for(sub->n_nodes, 256)), dim3(256), 0, h->stream, sub->n_nodes, me, sub->d_flags,
+    hipLaunchKernelGGL(k_part_cross, dim3(grid_for(sub->n_nodes, 256 * PART_CROSS_TILES)), dim3(256), 0, h->stream, sub->n_nodes, me, sub->d_flags,
                        mp->pflags[part], sub->d_rowptr32, sub->d_col, mp->col_owner[part], cur, (uint32_t *)nullptr);
     HIPCHK(h, hipGetLastError());
     uint64_t hc[64];
@@ -5762,7 +5779,7 @@ extern "C" int dbg_part_cross_targets(dbg_t *h, int part, uint64_t *counts, void
     if (!d_targets || !total) return DBG_OK;
     if (total > capacity) { h->err = "dbg_part_cross_targets: capacity below the number of cross edges"; return DBG_E_CAPACITY; }
     HIPCHK(h, hipMemcpyAsync(cur, off, 64 * 8, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_part_cross, dim3(grid_for(sub->n_nodes, 256)), dim3(256), 0, h->stream, sub->n_nodes, me, sub->d_flags,
+    hipLaunchKernelGGL(k_part_cross, dim3(grid_for(sub->n_nodes, 256 * PART_CROSS_TILES)), dim3(256), 0, h->stream, sub->n_nodes, me, sub->d_flags,
                        mp->pflags[part], sub->d_rowptr32, sub->d_col, mp->col_owner[part], cur, (uint32_t *)d_targets);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
