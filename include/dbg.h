@@ -113,7 +113,15 @@ int dbg_abi_version(void);
  * "estimate_scale_pct" test hook: scales the distinct-k-mer estimate that sizes the node arrays (a low value
  * makes the first count launch run out of room and exercises the retry; dbg_stats_t.count_launches);
  * "refine_streaming" 1: dbg_refine_edge_order takes its pass over the reads even when the bucketed records of the build
- * are there (test hook: both ways must agree). */
+ * are there (test hook: both ways must agree).
+ * Count kernels (A/B and tests; the defaults are the measured winners): "count_kernel" k <= 31, 32-bit
+ * stamps: 2 = k_sk_count2 (default), 1 = k_sk_count, 3 = k_sk_count3; "count_kernel_u64" k <= 31, 64-bit stamps (shards, reads
+ * of 2 GiB and more): 3 = k_sk_count3 (default), 1, 2; "wcount_kernel" k > 31, 32-bit stamps: 2 = k_wsk_count2 (default),
+ * 1 = k_wsk_count; "stamp64" 1: dbg_build / dbg_build_multipass keep 64-bit stamps below 2 GiB of reads too (what larger
+ * inputs get by themselves); "resolve_sorted" 1 (2: at any size): cross-bucket successor queries grouped by their target
+ * before the resolver (measured slower: off); "wide_engine" 0: k > 31 on the global-table engine of round 1;
+ * "extract_generic" 1: the window-minimum-through-LDS extraction kernels; "shard_stamp64" 1: dbg_shard_extract hands out
+ * 64-bit rank-local stamps; "target_distinct": mean distinct k-mers per bucket the geometry aims at (0 = default). */
 int dbg_set_option(dbg_t *h, const char *name, int64_t value);
 
 /* ---- reads (replaces the `reads` list argument, debruijn.py:206; FASTA
