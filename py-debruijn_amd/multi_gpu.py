@@ -330,6 +330,11 @@ def _exchange_records(g, k, dist, xc):
     return r_w0, r_w1, r_st, recv_counts, bases, sender_buckets
 
 
+# receive buffers of an exchange in parts: sized from the first part x the number of parts x this factor (tests shrink it to
+# walk the growth path)
+PART_SLACK = 1.15
+
+
 def _exchange_records_in_parts(g, k, dist, xc, chunks):
     """_exchange_records with the rank's records cut and sent in ``chunks`` parts (dbg_shard_extract_part, k <= 31): part c
     is on the wire -- three posted all-to-alls on the communicator's stream -- while part c + 1 is extracted and split on
@@ -360,7 +365,7 @@ def _exchange_records_in_parts(g, k, dist, xc, chunks):
         big = max(sum(m_r[3 + d * bps: 3 + (d + 1) * bps]) for m_r in metas for d in range(w))
         n_in = sum(recv_counts)
         if bufs is None or cursor + n_in > cap:
-            new_cap = cursor + (int(n_in * (chunks - c) * 1.15) + 4096 if c + 1 < chunks else n_in)
+            new_cap = cursor + max(n_in, int(n_in * (chunks - c) * PART_SLACK) + (4096 if PART_SLACK >= 1 else 0))  # this part fits in any case
             xc.wait()  # (growing: the posted exchanges write into the old buffers)
             new = [torch.empty(words * new_cap, dtype=torch.int64, device=device), torch.empty(new_cap, dtype=torch.int64, device=device),
                    torch.empty(new_cap, dtype=st.dtype, device=device)]

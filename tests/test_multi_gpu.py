@@ -187,6 +187,29 @@ def test_ranks_times_passes_exchange_logic_on_cpu(ranks, n_passes, wide_stamp_ra
     assert ranks == 1 or crossing > 0
 
 
+def test_records_in_parts_when_the_receive_buffers_must_grow(monkeypatch):
+    """_exchange_records_in_parts sizes its receive buffers from the first part; a later part that does not fit makes it wait for
+    the posted exchanges, allocate larger buffers and copy what has arrived.  PART_SLACK = 0.3 forces that at every part."""
+    import multi_gpu
+    import shard_worker
+    monkeypatch.setattr(multi_gpu, "PART_SLACK", 0.3)
+    ranks, n_passes, chunks, k, n_reads, read_len = 4, 1, 4, 9, 96, 40
+
+    def one(dist, rank):
+        g = shard_worker.NumpyMultipassGraph([row.tobytes().decode() for row in rank_reads(ranks, rank, n_reads, read_len)], k)
+        multi_gpu.sharded_build_multipass(g, k, dist, n_passes, chunks=chunks)
+        return g.parts
+
+    parts = [d for rank_parts in inproc_dist.run_ranks(ranks, one) for d in rank_parts]
+    reads = np.concatenate([rank_reads(ranks, r, n_reads, read_len) for r in range(ranks)])
+    want = orc_c.build(reads.reshape(-1), np.arange(0, reads.size + 1, read_len, dtype=np.uint64), k)
+    keys = np.array([key for d in parts for key in d["keys"]], dtype=np.uint64)
+    stamps = np.concatenate([d["stamps"] for d in parts])
+    counts = np.concatenate([d["counts"].reshape(-1, 4) for d in parts])
+    o = np.argsort(stamps, kind="stable")
+    assert np.array_equal(keys[o], want["keys"]) and np.array_equal(stamps[o], want["stamps"]) and np.array_equal(counts[o], want["counts"])
+
+
 @pytest.mark.parametrize("posted", [False, True])
 def test_damaged_exchange_is_detected(posted):
     """multi_gpu.ExchangeCheck: a message that arrives with one wrong word must raise, not build a wrong graph.
