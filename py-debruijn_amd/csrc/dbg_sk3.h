@@ -12,6 +12,7 @@
 // Same descriptor, outputs and flags as k_sk_count2 (512: a 16-bit counter overflowed -> the host repeats with k_sk_count;
 // 2048: the insert and the list phase disagree).  Instantiated for both stamp widths; the host uses it for 64-bit stamps.
 #pragma once
+#include "dbg_cnt_common.h"
 #include "dbg_sk2.h"
 
 namespace dbgk {
@@ -329,77 +330,11 @@ __global__ __launch_bounds__(1024) void k_sk_count3(const SkCount2Args *__restri
                 __syncthreads();
                 continue;
             }
-            // ---- dense list of occupied slots + CSR edge offsets (k_wsk_count2)
-            {
-                unsigned long long kk[NPT];
-                uint2 cc[NPT];
-#pragma unroll
-                for (int t = 0; t < NPT; ++t) {
-                    const int i = threadIdx.x + t * NT;
-                    kk[t] = s.keys[i];
-                    cc[t] = reinterpret_cast<const uint2 *>(s.cnt2)[i];
-                }
-                unsigned long long mask[NPT];
-                uint32_t below[NPT], eexc[NPT], nn[NPT], ne[NPT], tot = 0;
-#pragma unroll
-                for (int t = 0; t < NPT; ++t) {
-                    const bool occ = kk[t] != EMPTY_KEY;
-                    const uint32_t deg = occ ? ((cc[t].x & 0xFFFFu) != 0) + ((cc[t].x >> 16) != 0) + ((cc[t].y & 0xFFFFu) != 0) + ((cc[t].y >> 16) != 0) : 0u;
-                    mask[t] = __ballot(occ);
-                    below[t] = lanes_below(mask[t]);
-                    eexc[t] = 0;
-                    ne[t] = 0;
-#pragma unroll
-                    for (int j = 1; j <= 4; ++j) {
-                        const unsigned long long mj = __ballot(deg >= (uint32_t)j);
-                        eexc[t] += lanes_below(mj);
-                        ne[t] += (uint32_t)__popcll(mj);
-                    }
-                    nn[t] = (uint32_t)__popcll(mask[t]);
-                    tot += nn[t] | (ne[t] << 16);
-                }
-                uint32_t base = 0;
-                if (tot && lane == 0) base = atomicAdd(&s.n_local, tot);
-                base = __builtin_amdgcn_readfirstlane(base);
-                // (a barrier-free hand-over: list[] and eoff[] held the quad list and the dedupe set until the insert barrier)
-#pragma unroll
-                for (int t = 0; t < NPT; ++t) {
-                    const int i = threadIdx.x + t * NT;
-                    if (lane == 0) { s.dir_mask[i >> 6] = mask[t]; s.dir_base[i >> 6] = (uint16_t)base; }
-                    if (kk[t] != EMPTY_KEY) {
-                        const uint32_t li = (base & 0xFFFFu) + below[t];
-                        s.list[li] = (uint16_t)i;
-                        s.eoff[li] = (uint16_t)((base >> 16) + eexc[t]);
-                    }
-                    base += nn[t] | (ne[t] << 16);
-                }
-            }
+            // ---- dense list of occupied slots + CSR edge offsets (list[] and eoff[] held the quad list and the dedupe set until
+            //      the insert barrier)
+            cnt_dense_list<CAP, NT>(s, s.keys);
             CNT_TICK(6);
-            if (threadIdx.x == 0) {  // the reservation is back
-                const auto &orr = fresh_args2(argp)->out;
-                const uint32_t n_local = n_new & 0xFFFFu, n_edges_local = n_new >> 16;
-                const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
-                s.gbase = base;
-                s.ebase = eb;
-                if (base + n_local > orr.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
-                if (eb + n_edges_local > orr.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
-                uint64_t ri = bucket;
-                if (cur_mask) {
-                    ri = orr.n_buckets + atomicAdd(&orr.scalars[6], 1ull);
-                    if (ri >= orr.range_cap || ri >= 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
-                }
-                s.ri = ri;
-                if (!s.fail) {
-                    SkRange rg;
-                    rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
-                    rg.next = 0; rg.pad = 0;
-                    if (cur_mask) {
-                        rg.next = orr.ranges[bucket].next;
-                        orr.ranges[bucket].next = (uint32_t)ri;
-                    }
-                    orr.ranges[ri] = rg;
-                }
-            }
+            if (threadIdx.x == 0) cnt_take_reservation(s, fresh_args2(argp)->out, got, n_new, bucket, cur_mask, cur_val);  // the reservation is back
             CNT_TICK(9);
             __syncthreads();
             CNT_TICK(10);
@@ -414,23 +349,14 @@ __global__ __launch_bounds__(1024) void k_sk_count3(const SkCount2Args *__restri
             // ---- write nodes and their CSR rows; counters, stamp and hint of every slot read are cleared, the keys stay for the
             //      deferred lookups (cleared at the top of the next pass)
             const auto &ow = fresh_args2(argp)->out;
-            if (threadIdx.x < CAP / 64) {
-                uint32_t td = threadIdx.x;
-                asm volatile("" : "+v"(td));  // (&s.dir_mask[tid] computed here, not hoisted and spilled: dbg_wsk2.h)
-                SkDirEnt de;
-                de.mask = s.dir_mask[td];
-                de.base = (uint32_t)(gbase + s.dir_base[td]);
-                de.pad = s.ri < ow.n_buckets ? 1u : 0u;
-                const uint64_t di = s.ri < ow.n_buckets ? s.ri - ow.own_lo : ow.own_cnt + (s.ri - ow.n_buckets);
-                ow.dirs[di * (CAP / 64) + td] = de;
-            }
+            cnt_write_directory<CAP>(s, ow, gbase);
             // successor of the k-mer in slot `sl` by base b, CSR position e: table lookup; a miss becomes a query (the rare
             // path of an edge that found no room on its wave's list)
             auto resolve = [&](uint32_t sl, uint32_t b, uint64_t e) {
                 const uint64_t sk = ((s.keys[sl] << 2) | (uint64_t)b) & kmask;
                 const int f = lds_find<CAP>(s.keys, sk);
                 if (f >= 0) {
-                    const uint32_t ix = (uint32_t)s.dir_base[f >> 6] + (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                    const uint32_t ix = cnt_local_index(s, (uint32_t)f);
                     ow.col[e] = (uint32_t)(gbase + ix) | ow.id_tag;
                     return;
                 }
@@ -475,7 +401,7 @@ __global__ __launch_bounds__(1024) void k_sk_count3(const SkCount2Args *__restri
                     uint32_t hcol = 0;
                     if (nzm & (1u << hb)) {
                         const uint32_t f = hnt & (CAP - 1);
-                        const uint32_t ix = (uint32_t)s.dir_base[f >> 6] + (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                        const uint32_t ix = cnt_local_index(s, (uint32_t)f);
                         hcol = (uint32_t)(gbase + ix) | ow.id_tag;
                     }
 #pragma unroll
@@ -525,7 +451,7 @@ __global__ __launch_bounds__(1024) void k_sk_count3(const SkCount2Args *__restri
                     sk = ((s.keys[sl] << 2) | (uint64_t)(sb & 3u)) & kmask;
                     const int f = lds_find<CAP>(s.keys, sk);
                     if (f >= 0) {
-                        const uint32_t ix = (uint32_t)s.dir_base[f >> 6] + (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                        const uint32_t ix = cnt_local_index(s, (uint32_t)f);
                         ow.col[e] = (uint32_t)(gbase + ix) | ow.id_tag;
                     } else {
                         miss = true;

@@ -21,6 +21,7 @@
 // Same inputs, same outputs (node order within a bucket = slot order), same flags as k_wsk_count.  32-bit stamps only: with
 // 64-bit stamps the hint array does not fit beside the table (those builds keep k_wsk_count).
 #pragma once
+#include "dbg_cnt_common.h"
 #include "dbg_sk2.h"
 #include "dbg_wsk.h"
 
@@ -394,77 +395,10 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
                 __syncthreads();
                 continue;
             }
-            // ---- dense list of occupied slots + CSR edge offsets (k_wsk_count)
-            {
-                constexpr int NB = WCAP / WCNT_NT;
-                unsigned long long kk[NB];
-                uint2 cc[NB];
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    const int i = threadIdx.x + t * WCNT_NT;
-                    kk[t] = s.khi[i];
-                    cc[t] = reinterpret_cast<const uint2 *>(s.cnt2)[i];
-                }
-                unsigned long long mask[NB];
-                uint32_t below[NB], eexc[NB], nn[NB], ne[NB], tot = 0;
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    const bool occ = kk[t] != EMPTY_KEY;
-                    const uint32_t deg = occ ? ((cc[t].x & 0xFFFFu) != 0) + ((cc[t].x >> 16) != 0) + ((cc[t].y & 0xFFFFu) != 0) + ((cc[t].y >> 16) != 0) : 0u;
-                    mask[t] = __ballot(occ);
-                    below[t] = lanes_below(mask[t]);
-                    eexc[t] = 0;
-                    ne[t] = 0;
-#pragma unroll
-                    for (int j = 1; j <= 4; ++j) {
-                        const unsigned long long mj = __ballot(deg >= (uint32_t)j);
-                        eexc[t] += lanes_below(mj);
-                        ne[t] += (uint32_t)__popcll(mj);
-                    }
-                    nn[t] = (uint32_t)__popcll(mask[t]);
-                    tot += nn[t] | (ne[t] << 16);
-                }
-                uint32_t base = 0;
-                if (tot && (threadIdx.x & 63) == 0) base = atomicAdd(&s.n_local, tot);
-                base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    const int i = threadIdx.x + t * WCNT_NT;
-                    if ((threadIdx.x & 63) == 0) { s.dir_mask[i >> 6] = mask[t]; s.dir_base[i >> 6] = (uint16_t)base; }
-                    if (kk[t] != EMPTY_KEY) {
-                        const uint32_t li = (base & 0xFFFFu) + below[t];
-                        s.list[li] = (uint16_t)i;
-                        s.eoff[li] = (uint16_t)((base >> 16) + eexc[t]);
-                    }
-                    base += nn[t] | (ne[t] << 16);
-                }
-            }
+            // ---- dense list of occupied slots + CSR edge offsets
+            cnt_dense_list<WCAP, WCNT_NT>(s, s.khi);
             CNT_TICK(6);
-            if (threadIdx.x == 0) {  // the reservation is back
-                const auto &orr = *wfresh_args(outp);
-                const uint32_t n_local = n_new & 0xFFFFu, n_edges_local = n_new >> 16;
-                const unsigned long long base = got & 0xFFFFFFFFull, eb = got >> 32;
-                s.gbase = base;
-                s.ebase = eb;
-                if (base + n_local > orr.node_cap || base + n_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
-                if (eb + n_edges_local > orr.edge_cap || eb + n_edges_local > 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 16ull); s.fail = 1; }
-                uint64_t ri = bucket;
-                if (cur_mask) {
-                    ri = orr.n_buckets + atomicAdd(&orr.scalars[6], 1ull);
-                    if (ri >= orr.range_cap || ri >= 0xFFFFFFF0ull) { atomicOr(&orr.scalars[0], 32ull); s.fail = 1; }
-                }
-                s.ri = ri;
-                if (!s.fail) {
-                    SkRange rg;
-                    rg.bucket = (uint32_t)bucket; rg.mask = cur_mask; rg.val = cur_val; rg.node_cnt = n_local; rg.node_base = base;
-                    rg.next = 0; rg.pad = 0;
-                    if (cur_mask) {
-                        rg.next = orr.ranges[bucket].next;
-                        orr.ranges[bucket].next = (uint32_t)ri;
-                    }
-                    orr.ranges[ri] = rg;
-                }
-            }
+            if (threadIdx.x == 0) cnt_take_reservation(s, *wfresh_args(outp), got, n_new, bucket, cur_mask, cur_val);  // the reservation is back
             CNT_TICK(9);
             __syncthreads();
             CNT_TICK(10);
@@ -486,25 +420,13 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
             const unsigned long long ww0_ = clock64();  // per-wave clocks of the node write + deferred lookups instead of the insert
 #endif
             const auto &ow = *wfresh_args(outp);  // loaded here, not kept in SGPRs across the whole bucket loop
-            if (threadIdx.x < WCAP / 64) {
-                // (the index goes through an opaque move: &s.dir_mask[tid] and &s.dir_base[tid] are then computed here; hoisted out
-                // of the bucket loop they were kept across all phases and, at the 128-register limit, spilled to scratch --
-                // two memory round trips per pass to reload two additions)
-                uint32_t td = threadIdx.x;
-                asm volatile("" : "+v"(td));
-                SkDirEnt de;
-                de.mask = s.dir_mask[td];
-                de.base = (uint32_t)(gbase + s.dir_base[td]);
-                de.pad = s.ri < ow.n_buckets ? 1u : 0u;
-                const uint64_t di = s.ri < ow.n_buckets ? s.ri - ow.own_lo : ow.own_cnt + (s.ri - ow.n_buckets);
-                ow.dirs[di * (WCAP / 64) + td] = de;
-            }
+            cnt_write_directory<WCAP>(s, ow, gbase);
             // successor of the k-mer in slot `sl` by base b, CSR position e: table lookup; a miss becomes a query
             auto resolve = [&](uint32_t sl, uint32_t b, uint64_t e) {
                 const K128 sk = k128_append(K128{s.khi[sl], s.klo[sl]}, b, k);
                 const int f = wlds_find(s.khi, s.klo, sk);
                 if (f >= 0) {
-                    const uint32_t ix = (uint32_t)s.dir_base[f >> 6] + (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                    const uint32_t ix = cnt_local_index(s, (uint32_t)f);
                     ow.col[e] = (uint32_t)(gbase + ix) | ow.id_tag;
                     return;
                 }
@@ -552,7 +474,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
                     uint32_t hcol = 0;
                     if (nzm & (1u << hb)) {
                         const uint32_t f = hnt & (WCAP - 1);
-                        const uint32_t ix = (uint32_t)s.dir_base[f >> 6] + (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                        const uint32_t ix = cnt_local_index(s, (uint32_t)f);
                         hcol = (uint32_t)(gbase + ix) | ow.id_tag;
                     }
 #pragma unroll
@@ -604,7 +526,7 @@ __global__ __launch_bounds__(WCNT_NT) void k_wsk_count2(const uint64_t *__restri
                     sk = k128_append(K128{s.khi[sl], s.klo[sl]}, sb & 3u, k);
                     const int f = wlds_find(s.khi, s.klo, sk);
                     if (f >= 0) {
-                        const uint32_t ix = (uint32_t)s.dir_base[f >> 6] + (uint32_t)__popcll(s.dir_mask[f >> 6] & ((1ull << (f & 63)) - 1ull));
+                        const uint32_t ix = cnt_local_index(s, (uint32_t)f);
                         ow.col[e] = (uint32_t)(gbase + ix) | ow.id_tag;
                     } else {
                         miss = true;
