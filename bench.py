@@ -286,7 +286,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange-check", action="store_true", help="sharded builds: skip the per-message digests")
-    ap.add_argument("--chunks", type=int, default=1, help="sharded builds, k <= 31: cut and send the records in this many parts, the "
+    ap.add_argument("--chunks", type=int, default=1, help="sharded builds: cut and send the records in this many parts, the "
                     "exchange of one under the extraction of the next (multi_gpu._exchange_records_in_parts); 1 = one exchange")
     ap.add_argument("--table-hint", type=int, default=0)
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (rest of the path, error-free variant)")

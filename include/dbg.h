@@ -335,7 +335,8 @@ int dbg_device_views(dbg_t *h, const void **d_keys, const void **d_counts, const
  * each owner, contiguous and in owner order */
 int dbg_shard_extract(dbg_t *h, int k, int n_shards, uint64_t *send_counts, const void **d_w0, const void **d_w1,
                       const void **d_st);
-/* dbg_shard_extract for part `part` of n_parts (1..4) slices of this rank's reads, k <= 31: slices of the position space cut at
+/* dbg_shard_extract for part `part` of n_parts (1..4) slices of this rank's reads (k <= 31: super-k-mer records; k > 31: the
+ * records by value of the LDS engine, reads below 2 GiB): slices of the position space cut at
  * tile borders -- a k-mer belongs to the slice its first base lies in, so the parts' records together are exactly those of
  * dbg_shard_extract; the stamps are positions in ALL of the rank's reads either way.  The arrays of part p stay valid until
  * part p is extracted again (own buffers per part): multi_gpu.sharded_build_multipass(chunks=...) has part p on the wire

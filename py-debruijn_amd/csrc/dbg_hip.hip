@@ -3797,7 +3797,7 @@ __global__ __launch_bounds__(256) void k_wsk_iota128(uint64_t n, uint64_t *w0) {
 // part 1: 2-bit packed reads + records (position, meta, stamp) in one private segment per persistent workgroup (set 0)
 template <class ST>
 static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64_t *w1[2], ST *st[2], uint64_t **seg_start_out,
-                       uint64_t **seg_cnt_out, uint32_t *n_seg_out, uint64_t *n_rec_out) {
+                       uint64_t **seg_cnt_out, uint32_t *n_seg_out, uint64_t *n_rec_out, int part = 0, int n_parts = 1) {
     const int m = SK_MAX_M, w = k - m + 1;
     unsigned long long *sc_dev = (unsigned long long *)h->d_scalars;
     uint64_t sc[8] = {0};
@@ -3807,7 +3807,11 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
     HIPCHK(h, hipMemsetAsync(pk + pk_words, 0, 8 * 8, h->stream));
     if (pk_words)
         hipLaunchKernelGGL(k_wpack, dim3(grid_for(pk_words, 256)), dim3(256), 0, h->stream, h->d_bases, h->n_bytes, pk_words, pk);
-    const uint64_t tiles = (h->n_bytes + TILE - 1) / TILE;
+    // part p of n_parts: the k-mers whose first base lies in the tiles [T p / n, T (p + 1) / n) (dbg_shard_extract_part); the
+    // 2-bit packed reads above are whole either way (a record's bases may lie beyond its slice)
+    const uint64_t all_tiles = (h->n_bytes + TILE - 1) / TILE;
+    const uint64_t tile_first = all_tiles * (uint64_t)part / (uint64_t)n_parts;
+    const uint64_t tiles = all_tiles * (uint64_t)(part + 1) / (uint64_t)n_parts - tile_first;
     const bool reg_kernel = (w >= 20 && w <= 51) && !h->extract_generic;  // k = 32..63: the register kernel (256 threads, several workgroups per CU)
     const uint32_t n_wg = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), reg_kernel ? 2048 : 1024);
     CHK(buf_ensure(h, h->ar_misc[0], (uint64_t)n_wg * 4 * 8));
@@ -3835,7 +3839,7 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
         if (tiles && reg_kernel) {  // one instantiation per window w = k - 12 (the doubling-table kernel stays as the generic fallback)
 #define DBG_WEXW_CASE(W_) case W_: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wsk_extract_w<ST, W_>), dim3(n_wg), dim3(256), 0, h->stream, \
                                                        h->d_bases, h->n_bytes, h->d_startbits, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, \
-                                                       seg_nk, seg_ne, sc_dev); break;
+                                                       seg_nk, seg_ne, sc_dev, tile_first); break;
             switch (w) {
                 DBG_WEXW_CASE(20) DBG_WEXW_CASE(21) DBG_WEXW_CASE(22) DBG_WEXW_CASE(23) DBG_WEXW_CASE(24) DBG_WEXW_CASE(25)
                 DBG_WEXW_CASE(26) DBG_WEXW_CASE(27) DBG_WEXW_CASE(28) DBG_WEXW_CASE(29) DBG_WEXW_CASE(30) DBG_WEXW_CASE(31)
@@ -3850,7 +3854,7 @@ static int wsk_extract(dbg *h, int k, uint64_t **pk_out, uint64_t *w0[2], uint64
             auto ekern = k_wsk_extract<ST>;
             HIPCHK(h, hipFuncSetAttribute((const void *)ekern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(WSkLds)));
             hipLaunchKernelGGL(ekern, dim3(n_wg), dim3(WSK_NT), sizeof(WSkLds), h->stream, h->d_bases, h->n_bytes,
-                               h->d_startbits, k, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev);
+                               h->d_startbits, k, tiles, w0[0], w1[0], st[0], seg_cap, seg_cnt, seg_nk, seg_ne, sc_dev, tile_first);
         }
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipMemcpyAsync(sc, h->d_scalars, 8, hipMemcpyDeviceToHost, h->stream));
@@ -4437,7 +4441,7 @@ static int shard_build_wide(dbg *h, int k, int n_shards, int my_shard, const uin
 //      (the instance tuples of shard_extract_wide are 24 bytes each).  The receiver takes the received bases as its
 //      packed reads: record i sits at base position 128 i.
 static int shard_extract_wsk(dbg *h, int k, int n_shards, uint64_t *send_counts, const void **d_rb, const void **d_w1,
-                             const void **d_st) {
+                             const void **d_st, int part = 0, int n_parts = 1) {
     free_build(h);
     h->stats = dbg_stats_t{};
     CHK(compute_alphabet(h));
@@ -4445,7 +4449,13 @@ static int shard_extract_wsk(dbg *h, int k, int n_shards, uint64_t *send_counts,
     uint64_t *pk = nullptr, *w0[2], *w1[2], *seg_start = nullptr, *seg_cnt = nullptr, n_rec = 0;
     uint32_t *st[2];
     uint32_t n_seg = 0;
-    CHK(wsk_extract<uint32_t>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec));
+    CHK(wsk_extract<uint32_t>(h, k, &pk, w0, w1, st, &seg_start, &seg_cnt, &n_seg, &n_rec, part, n_parts));
+    if (n_parts > 1) {  // what travels (meta words, stamps; the gathered bases below) keeps buffers of its own per part
+        CHK(buf_ensure(h, h->ar_part[part][1], (n_rec + 16) * 8));
+        CHK(buf_ensure(h, h->ar_part[part][2], (n_rec + 16) * 4));
+        w1[1] = (uint64_t *)h->ar_part[part][1].p;
+        st[1] = (uint32_t *)h->ar_part[part][2].p;
+    }
     const int nb1 = 512;
     CHK(buf_ensure(h, h->ar_misc[1], (uint64_t)nb1 * 16));
     uint64_t *c1_start = (uint64_t *)h->ar_misc[1].p, *c1_cnt = c1_start + nb1;
@@ -4455,8 +4465,9 @@ static int shard_extract_wsk(dbg *h, int k, int n_shards, uint64_t *send_counts,
                                           h->ar_misc[4], 0, nullptr, nullptr, h->host_seg_cnt.data())));
     std::vector<uint64_t> cnt(nb1);
     HIPCHK(h, hipMemcpyAsync(cnt.data(), c1_cnt, nb1 * 8, hipMemcpyDeviceToHost, h->stream));
-    CHK(buf_ensure(h, h->ar_wide[2], (n_rec + 1) * 32));
-    uint4 *rec_b = (uint4 *)h->ar_wide[2].p;
+    dbg::Buf &b_rb = n_parts > 1 ? h->ar_part[part][0] : h->ar_wide[2];
+    CHK(buf_ensure(h, b_rb, (n_rec + 1) * 32));
+    uint4 *rec_b = (uint4 *)b_rb.p;
     if (n_rec)
         hipLaunchKernelGGL(k_wsk_gather, dim3(grid_for(n_rec, 256)), dim3(256), 0, h->stream, w0[1], w1[1], n_rec, pk, k, rec_b);
     HIPCHK(h, hipGetLastError());
@@ -4471,7 +4482,7 @@ static int shard_extract_wsk(dbg *h, int k, int n_shards, uint64_t *send_counts,
     ShardState &sh = shard_of(h);
     sh.n_shards = n_shards;
     sh.k = k;
-    sh.n_kmer_inst_local = h->n_kmer_inst;
+    sh.n_kmer_inst_local = (part ? sh.n_kmer_inst_local : 0) + h->n_kmer_inst;
     sh.l1_counts = cnt;
     sh.rec_words = 4;
     sh.rec_stamp_bytes = 4;
@@ -4593,10 +4604,14 @@ extern "C" int dbg_shard_extract_part(dbg_t *h, int k, int n_shards, int part, i
                                       const void **d_w0, const void **d_w1, const void **d_st) {
     CHK(shard_args_ok(h, k, n_shards));
     if (!send_counts || !d_w0 || !d_w1 || !d_st || !h->d_offsets) { h->err = "bad argument / no reads"; return DBG_E_ARG; }
-    if (k > 31) { h->err = "dbg_shard_extract_part: k <= 31 (two-word records travel whole: dbg_shard_extract)"; return DBG_E_ARG; }
     if (n_parts < 1 || n_parts > 4 || part < 0 || part >= n_parts) { h->err = "dbg_shard_extract_part: 1 <= n_parts <= 4, 0 <= part < n_parts"; return DBG_E_ARG; }
     const bool st64 = h->n_bytes >= (1ull << 31) || h->shard_stamp64;
     HIPCHK(h, hipSetDevice(h->device));
+    if (k > 31) {  // two-word k-mers: records by value (the LDS engine), 32-bit rank-local stamps
+        if (h->wide_engine != 1) { h->err = "dbg_shard_extract_part: two-word k-mers on the LDS engine (\"wide_engine\" 1)"; return DBG_E_ARG; }
+        if (h->n_bytes >= (1ull << 31)) { h->err = "a shard's reads must stay below 2 GiB for k > 31 (32-bit local stamps)"; return DBG_E_ARG; }
+        return shard_extract_wsk(h, k, n_shards, send_counts, d_w0, d_w1, d_st, part, n_parts);
+    }
     return st64 ? shard_extract_sk<uint64_t>(h, k, n_shards, send_counts, d_w0, d_w1, d_st, part, n_parts)
                 : shard_extract_sk<uint32_t>(h, k, n_shards, send_counts, d_w0, d_w1, d_st, part, n_parts);
 }

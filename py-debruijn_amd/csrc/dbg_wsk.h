@@ -99,13 +99,14 @@ __global__ __launch_bounds__(WSK_NT) void k_wsk_extract(const char *__restrict__
                                                         const uint32_t *__restrict__ startbits, int k, uint64_t n_tiles,
                                                         uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
                                                         uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
-                                                        unsigned long long *scalars /* [0] err */) {
+                                                        unsigned long long *scalars /* [0] err */,
+                                                        uint64_t tile_first /* the n_tiles tiles from here on (dbg_shard_extract_part) */) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsk_raw[];
     WSkLds &s = *reinterpret_cast<WSkLds *>(wsk_raw);
     __shared__ uint64_t red[2 * (WSK_NT / 64)];
     constexpr int m = SK_MAX_M;
     const int w = k - m + 1;
-    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t t_beg = tile_first + n_tiles * blockIdx.x / gridDim.x, t_end = tile_first + n_tiles * (blockIdx.x + 1) / gridDim.x;
     const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
     uint64_t cursor = 0;
     const uint64_t mid_mask = (1ull << (k - 1)) - 1ull;
@@ -280,13 +281,13 @@ __global__ __launch_bounds__(256, 2) void k_wsk_extract_w(const char *__restrict
                                                           const uint32_t *__restrict__ startbits, uint64_t n_tiles,
                                                           uint64_t *rec_w0, uint64_t *rec_w1, ST *rec_st, uint64_t seg_cap,
                                                           uint64_t *seg_cnt, uint64_t *seg_nk, uint64_t *seg_ne,
-                                                          unsigned long long *scalars /* [0] err */) {
+                                                          unsigned long long *scalars /* [0] err */, uint64_t tile_first) {
     constexpr int M = SK_MAX_M, K = W + M - 1, NV = 32 + W - 1;
     static_assert(TILE == 256 * 32, "one lane per 32 positions");
     static_assert(K >= 32 && K <= 63 && NV + M - 1 <= 96 && 32 + K <= 96 && WSK_HALO >= 96, "window must fit three 32-base registers");
     __shared__ WSkLdsW s;
     __shared__ uint64_t red[8];
-    const uint64_t t_beg = n_tiles * blockIdx.x / gridDim.x, t_end = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    const uint64_t t_beg = tile_first + n_tiles * blockIdx.x / gridDim.x, t_end = tile_first + n_tiles * (blockIdx.x + 1) / gridDim.x;
     const uint64_t seg0 = (uint64_t)blockIdx.x * seg_cap;
     uint64_t cursor = 0;
     constexpr uint64_t mid_mask = (1ull << (K - 1)) - 1ull;

@@ -336,7 +336,7 @@ PART_SLACK = 1.15
 
 
 def _exchange_records_in_parts(g, k, dist, xc, chunks):
-    """_exchange_records with the rank's records cut and sent in ``chunks`` parts (dbg_shard_extract_part, k <= 31): part c
+    """_exchange_records with the rank's records cut and sent in ``chunks`` parts (dbg_shard_extract_part): part c
     is on the wire -- three posted all-to-alls on the communicator's stream -- while part c + 1 is extracted and split on
     the library's stream.  The receiver sees chunks x world senders: sender c * world + r = part c of rank r, all parts of a
     rank with that rank's stamp base.  The receive buffers are sized from the first part (parts are equal slices of the
@@ -393,11 +393,11 @@ def sharded_build_multipass(g, k, dist, n_passes, check=True, chunks=1):
     owned by another rank are resolved pass by pass -- the same p on every rank at a time: keys out, part-local node ids
     back (two all-to-alls per pass).  Afterwards ``g.export_part(p)`` / ``g.part_tensors(p)`` hold the rank's parts with
     ``col_part`` = the virtual shard of every successor.
-    chunks > 1 (k <= 31): the records are cut and sent in that many parts, the exchange of one part under the extraction of the
+    chunks > 1: the records are cut and sent in that many parts, the exchange of one part under the extraction of the
     next (_exchange_records_in_parts); the graph is the same."""
     w, me, P = dist.get_world_size(), dist.get_rank(), int(n_passes)
     xc = ExchangeCheck(dist) if check else _NoCheck(dist)
-    if chunks > 1 and k <= 31 and hasattr(g, "shard_extract_part"):
+    if chunks > 1 and hasattr(g, "shard_extract_part"):
         r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records_in_parts(g, k, dist, xc, int(chunks))
     else:
         r_w0, r_w1, r_st, recv_counts, bases, sender_buckets = _exchange_records(g, k, dist, xc)

@@ -288,7 +288,7 @@ def test_two_ranks_on_one_gpu(k, n_reads, read_len, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,world,n_passes,chunks", [(31, 2, 2, 1), (63, 4, 1, 1), (31, 2, 1, 2)])
+@pytest.mark.parametrize("k,world,n_passes,chunks", [(31, 2, 2, 1), (63, 4, 1, 1), (31, 2, 1, 2), (40, 2, 1, 3)])
 def test_traversal_in_parts_over_real_processes(k, world, n_passes, chunks, tmp_path):
     """part_traversal with one PROCESS per rank (gloo; the ranks share the box's GPU): every rank ends with the same
     branch_kmer / already_pull_out / contigs as the reference restatement on all reads, and the pull-out flags of the ranks,
